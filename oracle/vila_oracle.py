@@ -1,0 +1,400 @@
+"""CPU oracle for the NVILA hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  Nothing under `vila_amd/` imports it; the product path raises if the HIP library is missing.
+
+What this is: a plain fp32 torch-CPU restatement of the reference's algorithm for SURVEY.md §8 rows
+a2-a12 (+ the loss of a11), written from the reference files cited on every function.  It does not
+import `/root/reference` or `transformers`, so it travels to the GPU box.
+
+How it is pinned: the reference ships no tests, golden vectors or fixtures for this path,
+so `oracle/make_golden.py` EXECUTES the reference's own `modeling_siglip.py` and `base_projector.py`
+(loaded by file path) and HF `Qwen2ForCausalLM` (the third-party dependency the reference pins at
+`pyproject.toml:17`, transformers==4.46.0; 5.15.0 is what is installed here) on seeded tiny configs and
+commits their outputs under `tests/golden/`.  `tests/test_oracle_golden.py` checks this restatement
+against those fixtures.  The HF-LLM leg is therefore pinned against transformers 5.15.0, not the 4.46.0
+the reference names — same arithmetic (cf. the in-tree mirror
+`llava/model/language_model/fp8activationqwen2.py:992-1055`), but say so: the LLM boundary is
+"pinned against a newer release of the un-vendored dependency".
+
+All tensors fp32 unless noted.  `w` is a flat dict keyed by the reference's state_dict names
+(SURVEY.md Appendix C).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+IGNORE_INDEX = -100  # llava/constants.py:26
+
+VT = "vision_tower.vision_tower.vision_model."
+PJ = "mm_projector.layers."
+LM = "llm."
+
+
+# ----------------------------------------------------------------------------------------------
+# a2: SiglipVisionEmbeddings.forward  (llava/model/multimodal_encoder/siglip/modeling_siglip.py:320-329)
+# ----------------------------------------------------------------------------------------------
+def siglip_embeddings(pixels: torch.Tensor, w: Dict[str, torch.Tensor], vcfg) -> torch.Tensor:
+    """Conv2d(k=s=patch, valid) -> flatten(2).transpose(1,2) -> + position_embedding[0:N]."""
+    B, C, H, W = pixels.shape
+    P = vcfg.patch_size
+    gh, gw = H // P, W // P
+    # patchify: token (gy,gx) row-major (:323); K index = c*P*P + ky*P + kx (= weight.view(out, C*P*P))
+    x = pixels.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+    wt = w[VT + "embeddings.patch_embedding.weight"].reshape(vcfg.hidden_size, -1)
+    y = x @ wt.t() + w[VT + "embeddings.patch_embedding.bias"]
+    return y + w[VT + "embeddings.position_embedding.weight"][None, : gh * gw]
+
+
+# ----------------------------------------------------------------------------------------------
+# a3: SiglipEncoderLayer.forward (:728-764), SiglipAttention eager (:389-439), SiglipMLP (:711-715)
+# ----------------------------------------------------------------------------------------------
+def siglip_attention(x: torch.Tensor, w, prefix: str, num_heads: int) -> torch.Tensor:
+    B, N, D = x.shape
+    hd = D // num_heads
+    q = F.linear(x, w[prefix + "q_proj.weight"], w[prefix + "q_proj.bias"])
+    k = F.linear(x, w[prefix + "k_proj.weight"], w[prefix + "k_proj.bias"])
+    v = F.linear(x, w[prefix + "v_proj.weight"], w[prefix + "v_proj.bias"])
+    q = q.view(B, N, num_heads, hd).transpose(1, 2)
+    k = k.view(B, N, num_heads, hd).transpose(1, 2)
+    v = v.view(B, N, num_heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(2, 3)) * (hd ** -0.5)            # :408 scale = head_dim**-0.5, non-causal
+    p = torch.softmax(s.float(), dim=-1)                  # :424 softmax in fp32
+    o = (p @ v).transpose(1, 2).reshape(B, N, D)
+    return F.linear(o, w[prefix + "out_proj.weight"], w[prefix + "out_proj.bias"])
+
+
+def siglip_mlp(x, w, prefix):
+    h = F.linear(x, w[prefix + "fc1.weight"], w[prefix + "fc1.bias"])
+    h = F.gelu(h, approximate="tanh")                     # hidden_act = gelu_pytorch_tanh (so400m config)
+    return F.linear(h, w[prefix + "fc2.weight"], w[prefix + "fc2.bias"])
+
+
+def siglip_encoder_layer(x, w, i: int, vcfg) -> torch.Tensor:
+    l = f"{VT}encoder.layers.{i}."
+    D = x.shape[-1]
+    r = x
+    h = F.layer_norm(x, (D,), w[l + "layer_norm1.weight"], w[l + "layer_norm1.bias"], vcfg.layer_norm_eps)
+    x = r + siglip_attention(h, w, l + "self_attn.", vcfg.num_attention_heads)
+    r = x
+    h = F.layer_norm(x, (D,), w[l + "layer_norm2.weight"], w[l + "layer_norm2.bias"], vcfg.layer_norm_eps)
+    return r + siglip_mlp(h, w, l + "mlp.")
+
+
+# ----------------------------------------------------------------------------------------------
+# a4: VisionTower.forward + feature_select (llava/model/multimodal_encoder/vision_encoder.py:44-52,133-177)
+# ----------------------------------------------------------------------------------------------
+def vision_tower_forward(pixels, w, vcfg, return_all: bool = False):
+    """hidden_states[select_layer] with select_feature="cls_patch" (keeps every token; SigLIP has no CLS).
+
+    The reference runs all L layers (+post_layernorm) and indexes hidden_states; layers past the selected
+    index cannot affect it (modeling_siglip.py:994-1011), so the oracle stops there.
+    """
+    x = siglip_embeddings(pixels, w, vcfg)
+    hs = [x]
+    n_used = vcfg.select_layer if vcfg.select_layer >= 0 else vcfg.num_hidden_layers + 1 + vcfg.select_layer
+    for i in range(n_used):
+        x = siglip_encoder_layer(x, w, i, vcfg)
+        hs.append(x)
+    return hs if return_all else x
+
+
+# ----------------------------------------------------------------------------------------------
+# a5: DownSampleBlock.flat_square / flat_square_2x2 / flat_square_3x3 + MultimodalProjector.forward
+#     (llava/model/multimodal_projector/base_projector.py:58-71, 84-97, 110-123, 145-174, 248-252)
+# ----------------------------------------------------------------------------------------------
+def flat_square(x: torch.Tensor, k: int) -> torch.Tensor:
+    """[n, w, h, c] -> [n, ceil(w/k), ceil(h/k), k*k*c]; zero pad first (2x2: odd only, 3x3: to a multiple)."""
+    n, w_, h_, c = x.shape
+    if w_ % k != 0:
+        x = torch.cat([x, torch.zeros((n, k - w_ % k, h_, c), dtype=x.dtype)], dim=1)
+        n, w_, h_, c = x.shape
+    if h_ % k != 0:
+        x = torch.cat([x, torch.zeros((n, w_, k - h_ % k, c), dtype=x.dtype)], dim=2)
+        n, w_, h_, c = x.shape
+    x = x.contiguous().view(n, w_, h_ // k, c * k)
+    x = x.permute(0, 2, 1, 3).contiguous()
+    x = x.view(n, h_ // k, w_ // k, c * k * k)
+    x = x.permute(0, 2, 1, 3).contiguous()
+    return x
+
+
+def downsample_block(x: torch.Tensor, k: int) -> torch.Tensor:
+    B, N, C = x.shape
+    g = int(N ** 0.5)
+    y = flat_square(x.reshape(B, g, g, C), k)
+    return y.reshape(B, -1, y.shape[-1])
+
+
+def projector_forward(x: torch.Tensor, w, ptype: str) -> torch.Tensor:
+    def lin(t, i):
+        return F.linear(t, w[f"{PJ}{i}.weight"], w[f"{PJ}{i}.bias"])
+
+    def ln(t, i):
+        return F.layer_norm(t, (t.shape[-1],), w[f"{PJ}{i}.weight"], w[f"{PJ}{i}.bias"], 1e-5)
+
+    if ptype in ("mlp_downsample", "mlp_downsample_2x2_fix"):
+        x = downsample_block(x, 2)
+        return lin(F.gelu(lin(ln(x, 1), 2)), 4)           # nn.GELU() = erf form (:150)
+    if ptype == "mlp_downsample_3x3_fix":
+        x = downsample_block(x, 3)
+        x = F.gelu(lin(ln(x, 1), 2))
+        x = F.gelu(lin(ln(x, 4), 5))
+        return lin(x, 7)
+    raise ValueError(f"Unknown projector type: {ptype}")
+
+
+# ----------------------------------------------------------------------------------------------
+# a6/a7: encode_images plain branch (llava_arch.py:366-394), BasicImageEncoder.forward (encoders/image/basic.py:41-79)
+# ----------------------------------------------------------------------------------------------
+def encode_images(pixels, w, cfg) -> torch.Tensor:
+    return projector_forward(vision_tower_forward(pixels, w, cfg.vision), w, cfg.mm_projector_type)
+
+
+def embed_tokens(ids: torch.Tensor, w) -> torch.Tensor:
+    return w[LM + "model.embed_tokens.weight"][ids]
+
+
+def basic_image_encoder(images: Sequence[torch.Tensor], w, cfg) -> List[torch.Tensor]:
+    """stack -> encode_images -> append embed(tokenizer("\\n")) to each image's tokens."""
+    feats = encode_images(torch.stack(list(images), 0), w, cfg)
+    end = embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+    return [torch.cat([f, end], 0) for f in feats]
+
+
+# ----------------------------------------------------------------------------------------------
+# a8: LlavaMetaForCausalLM._embed + __batchify_sequence (llava_arch.py:412-490, 528-555)
+# ----------------------------------------------------------------------------------------------
+def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, cfg,
+                 labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 padding_side: str = "right"):
+    """Returns (inputs_embeds [B,S,H], labels [B,S] i64, attention_mask [B,S] bool)."""
+    labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
+    attention_mask = attention_mask if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
+    text = embed_tokens(input_ids, w)
+    B = input_ids.shape[0]
+    queue = list(media_embeds)
+    ins, labs = [], []
+    for k in range(B):
+        ids_k = input_ids[k][attention_mask[k]]      # :449-450 remove padding
+        te_k = text[k][attention_mask[k]]
+        lb_k = labels[k][attention_mask[k]]
+        pi, pl = [], []
+        for pos in range(len(ids_k)):                # :459-477 (run-length form of the while loop)
+            if int(ids_k[pos]) == cfg.image_token_id:
+                m = queue.pop(0)
+                pi.append(m)
+                pl.append(torch.full((m.shape[0],), IGNORE_INDEX, dtype=lb_k.dtype))
+            else:
+                pi.append(te_k[pos:pos + 1])
+                pl.append(lb_k[pos:pos + 1])
+        ins.append(torch.cat(pi, 0))
+        labs.append(torch.cat(pl, 0))
+    if queue:
+        raise ValueError("Not all image embeddings are consumed!")   # :481-484
+    S = max(x.shape[0] for x in ins)
+    H = ins[0].shape[1]
+    out_e = torch.zeros((B, S, H), dtype=ins[0].dtype)
+    out_l = torch.full((B, S), IGNORE_INDEX, dtype=labels.dtype)
+    out_m = torch.zeros((B, S), dtype=torch.bool)
+    for k in range(B):
+        n = ins[k].shape[0]
+        sl = slice(0, n) if padding_side == "right" else slice(S - n, S)
+        out_e[k, sl] = ins[k]
+        out_l[k, sl] = labs[k]
+        out_m[k, sl] = True
+    return out_e, out_l, out_m
+
+
+# ----------------------------------------------------------------------------------------------
+# a9: repack_multimodal_data non-SP branch (llava_arch.py:744-800) + packing._get_unpad_data (utils/packing.py:12-21)
+# ----------------------------------------------------------------------------------------------
+def repack(inputs_embeds, attention_mask, labels):
+    """-> (embeds [1,ΣS+1,H], mask [1,ΣS+1] i32, position_ids [1,ΣS+1] i32, labels [1,ΣS+1], seqlens [B])."""
+    B = inputs_embeds.shape[0]
+    seqlens = [int(attention_mask[k].sum()) for k in range(B)]
+    e = [inputs_embeds[k][attention_mask[k]] for k in range(B)]
+    m = [torch.ones(n, dtype=torch.int32) for n in seqlens]
+    p = [torch.arange(n, dtype=torch.int32) for n in seqlens]
+    l = [labels[k][attention_mask[k]].clone() for k in range(B)]
+    e.append(torch.zeros(1, inputs_embeds.shape[-1], dtype=inputs_embeds.dtype))   # :754-758 dummy token
+    m.append(torch.tensor([0], dtype=torch.int32))
+    p.append(torch.tensor([0], dtype=torch.int32))
+    l.append(torch.tensor([IGNORE_INDEX], dtype=labels.dtype))
+    for x in l:
+        x[0] = IGNORE_INDEX                                                          # :760-762
+    return (torch.cat(e, 0)[None], torch.cat(m, 0)[None], torch.cat(p, 0)[None], torch.cat(l, 0)[None],
+            torch.tensor(seqlens, dtype=torch.int32))
+
+
+def get_unpad_data(attention_mask: torch.Tensor, seqlens_in_batch: Optional[torch.Tensor] = None):
+    if seqlens_in_batch is None:
+        seqlens_in_batch = attention_mask.sum(dim=1)
+    indices = torch.nonzero(attention_mask.flatten(), as_tuple=False).flatten()
+    cu = F.pad(torch.cumsum(seqlens_in_batch, 0, dtype=torch.int32), (1, 0))
+    return indices, cu, int(seqlens_in_batch.max())
+
+
+# ----------------------------------------------------------------------------------------------
+# a10/a11: HF Qwen2 (transformers/models/qwen2/modeling_qwen2.py — third-party, pinned ==4.46.0 at
+# pyproject.toml:17, NOT under /root/reference; call sites language_model/builder.py:178-180,
+# llava_llama.py:134-141, llava_arch.py:833; in-tree mirror of the attention math
+# llava/model/language_model/fp8activationqwen2.py:992-1055).  Arithmetic per SURVEY.md Appendix B.
+# ----------------------------------------------------------------------------------------------
+def rms_norm(x, weight, eps):
+    x32 = x.float()
+    y = x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)
+    return weight * y.to(x.dtype)
+
+
+def rope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float):
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = position_ids.float()[..., None] * inv          # [..., hd/2]
+    emb = torch.cat([fr, fr], -1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], -1)
+
+
+def qwen2_attention(x, w, l: str, lcfg, cos, sin, attn_bias, past: Optional[Tuple[torch.Tensor, torch.Tensor]]):
+    B, S, _ = x.shape
+    nq, nk, hd = lcfg.num_attention_heads, lcfg.num_key_value_heads, lcfg.head_dim
+    q = F.linear(x, w[l + "q_proj.weight"], w[l + "q_proj.bias"]).view(B, S, nq, hd).transpose(1, 2)
+    k = F.linear(x, w[l + "k_proj.weight"], w[l + "k_proj.bias"]).view(B, S, nk, hd).transpose(1, 2)
+    v = F.linear(x, w[l + "v_proj.weight"], w[l + "v_proj.bias"]).view(B, S, nk, hd).transpose(1, 2)
+    c, s_ = cos[:, None], sin[:, None]
+    q = q * c + rotate_half(q) * s_
+    k = k * c + rotate_half(k) * s_
+    if past is not None:
+        k = torch.cat([past[0], k], 2)
+        v = torch.cat([past[1], v], 2)
+    new_past = (k, v)
+    rep = nq // nk
+    kk = k.repeat_interleave(rep, 1)                    # repeat_kv
+    vv = v.repeat_interleave(rep, 1)
+    s = (q @ kk.transpose(2, 3)) * (hd ** -0.5) + attn_bias
+    p = torch.softmax(s.float(), -1)
+    o = (p @ vv).transpose(1, 2).reshape(B, S, nq * hd)
+    return F.linear(o, w[l + "o_proj.weight"]), new_past
+
+
+def qwen2_mlp(x, w, l: str):
+    return F.linear(F.silu(F.linear(x, w[l + "gate_proj.weight"])) * F.linear(x, w[l + "up_proj.weight"]),
+                    w[l + "down_proj.weight"])
+
+
+def causal_bias(S_q: int, S_k: int, key_mask: Optional[torch.Tensor] = None,
+                segment_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B or 1, 1, S_q, S_k] additive mask: causal (queries are the last S_q keys), optional key padding,
+    optional block-diagonal segments (what flash-attn varlen does for the packed row, packing.py:12-21)."""
+    i = torch.arange(S_q)[:, None] + (S_k - S_q)
+    j = torch.arange(S_k)[None, :]
+    ok = (j <= i)[None, None]
+    if key_mask is not None:
+        ok = ok & key_mask[:, None, None, :].bool()
+    if segment_ids is not None:
+        ok = ok & (segment_ids[:, None, :, None] == segment_ids[:, None, None, :])
+    bias = torch.zeros(ok.shape, dtype=torch.float32)
+    return bias.masked_fill(~ok, float("-inf"))
+
+
+def qwen2_forward(inputs_embeds, w, lcfg, position_ids: Optional[torch.Tensor] = None,
+                  attention_mask: Optional[torch.Tensor] = None, past=None,
+                  segment_ids: Optional[torch.Tensor] = None, return_hidden: bool = False):
+    """-> (logits [B,S,V] fp32, new_past, hidden_states list if asked)."""
+    B, S, _ = inputs_embeds.shape
+    n_past = 0 if past is None else past[0][0].shape[2]
+    if position_ids is None:
+        position_ids = torch.arange(n_past, n_past + S)[None].expand(B, S)
+    cos, sin = rope_cos_sin(position_ids, lcfg.head_dim, lcfg.rope_theta)
+    bias = causal_bias(S, n_past + S, attention_mask, segment_ids)
+    if attention_mask is not None:
+        # fully-masked (padding) query rows: keep softmax finite, output is ignored downstream
+        dead = torch.isinf(bias).all(-1, keepdim=True)
+        bias = torch.where(dead, torch.zeros_like(bias), bias)
+    x = inputs_embeds
+    hs = [x]
+    new_past = []
+    for i in range(lcfg.num_hidden_layers):
+        l = f"{LM}model.layers.{i}."
+        h = rms_norm(x, w[l + "input_layernorm.weight"], lcfg.rms_norm_eps)
+        a, kv = qwen2_attention(h, w, l + "self_attn.", lcfg, cos, sin, bias, None if past is None else past[i])
+        new_past.append(kv)
+        x = x + a
+        h = rms_norm(x, w[l + "post_attention_layernorm.weight"], lcfg.rms_norm_eps)
+        x = x + qwen2_mlp(h, w, l + "mlp.")
+        hs.append(x)
+    x = rms_norm(x, w[LM + "model.norm.weight"], lcfg.rms_norm_eps)
+    head = w[LM + "lm_head.weight"] if (LM + "lm_head.weight") in w else w[LM + "model.embed_tokens.weight"]
+    logits = F.linear(x, head).float()
+    return (logits, new_past, hs) if return_hidden else (logits, new_past)
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor, num_items_in_batch: Optional[int] = None):
+    """HF ForCausalLMLoss: shift by one, fp32 CE, sum / num_items_in_batch when supplied else mean
+    (patched compute_loss supplies the GLOBAL count: llava/train/transformer_normalize_monkey_patch.py:261-268)."""
+    lg = logits[..., :-1, :].float().reshape(-1, logits.shape[-1])
+    lb = labels[..., 1:].reshape(-1)
+    if num_items_in_batch is None:
+        return F.cross_entropy(lg, lb, ignore_index=IGNORE_INDEX, reduction="mean")
+    return F.cross_entropy(lg, lb, ignore_index=IGNORE_INDEX, reduction="sum") / num_items_in_batch
+
+
+# ----------------------------------------------------------------------------------------------
+# a12: LlavaMetaForCausalLM.generate (llava_arch.py:823-833) -> HF GenerationMixin greedy (do_sample=False)
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def greedy_generate(inputs_embeds, w, cfg, max_new_tokens: int, stop_at_eos: bool = True,
+                    forced_ids: Optional[Sequence[int]] = None):
+    """Batch-1 greedy decode with KV cache.  Returns (ids [n], per-step fp32 logits [n,V]).
+    forced_ids = teacher forcing (feed these ids, still record argmax-able logits) for margin-aware parity."""
+    lcfg = cfg.llm
+    logits, past = qwen2_forward(inputs_embeds, w, lcfg)
+    ids, step_logits = [], []
+    last = logits[:, -1]
+    for t in range(max_new_tokens):
+        step_logits.append(last[0].clone())
+        nxt = int(last[0].argmax())
+        ids.append(nxt)
+        if stop_at_eos and forced_ids is None and nxt == lcfg.eos_token_id:
+            break
+        feed = nxt if forced_ids is None else int(forced_ids[t])
+        e = embed_tokens(torch.tensor([[feed]]), w)
+        logits, past = qwen2_forward(e, w, lcfg, past=past)
+        last = logits[:, -1]
+    return torch.tensor(ids, dtype=torch.int64), torch.stack(step_logits)
+
+
+@torch.no_grad()
+def vlm_prefill_embeds(pixels_list: Sequence[torch.Tensor], input_ids: torch.Tensor, w, cfg):
+    """generate()'s `_embed` leg for a batch-1 prompt: images -> tokens(+\\n) -> spliced embeds [1,S,H]."""
+    media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
+    e, _, m = embed_splice(input_ids[None] if input_ids.dim() == 1 else input_ids, media, w, cfg)
+    return e, m
+
+
+@torch.no_grad()
+def vlm_generate(pixels_list, input_ids, w, cfg, max_new_tokens: int, **kw):
+    e, _ = vlm_prefill_embeds(pixels_list, input_ids, w, cfg)
+    return greedy_generate(e, w, cfg, max_new_tokens, **kw)
+
+
+def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True):
+    """Training forward of llava_llama.py:94-159 (packing branch): _embed -> repack -> llm(..., labels)."""
+    media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
+    e, l, m = embed_splice(input_ids, media, w, cfg, labels=labels, attention_mask=attention_mask)
+    if packed:
+        pe, pm, pp, pl, seqlens = repack(e, m, l)
+        seg = torch.repeat_interleave(torch.arange(len(seqlens) + 1),
+                                      torch.cat([seqlens.long(), torch.tensor([1])]))[None]
+        logits, _ = qwen2_forward(pe, w, cfg.llm, position_ids=pp.long(), segment_ids=seg)
+        return causal_lm_loss(logits, pl, num_items_in_batch)
+    logits, _ = qwen2_forward(e, w, cfg.llm, attention_mask=m)
+    return causal_lm_loss(logits, l, num_items_in_batch)

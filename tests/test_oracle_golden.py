@@ -1,0 +1,112 @@
+"""Pin the CPU oracle against fixtures produced by EXECUTING the reference's own modules
+(oracle/make_golden.py: reference modeling_siglip.py + base_projector.py by file path, HF Qwen2ForCausalLM)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vila_oracle as O
+from vila_amd import configs, synthetic
+
+CASES = {
+    "tiny_2x2": (configs.tiny("mlp_downsample"), 0),
+    "tiny_2x2fix": (configs.tiny("mlp_downsample_2x2_fix", image=70), 1),
+    "tiny_3x3_tied": (configs.tiny("mlp_downsample_3x3_fix", tied=True), 2),
+}
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _close(a, b, tol=2e-5):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).norm() / (b.norm() + 1e-30)
+    assert err < tol, f"rel L2 {err:.3e}"
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request, golden_dir):
+    cfg, seed = CASES[request.param]
+    fx = _load(golden_dir, request.param)
+    w = synthetic.make_weights(cfg, seed)
+    chk = sum(float(w[k].double().abs().sum()) for k in sorted(w))
+    assert abs(chk - float(fx["weight_checksum"])) < 1e-6 * chk, "synthetic weight generator drifted"
+    return cfg, seed, fx, w
+
+
+def test_flat_square_matches_reference(golden_dir):
+    fx = _load(golden_dir, "flat_square")
+    for g in (4, 5, 7, 32):
+        x = torch.arange(g * g * 3, dtype=torch.float32).reshape(1, g * g, 3) + 1
+        np.testing.assert_array_equal(O.downsample_block(x, 2).numpy(), fx[f"ds2_{g}"])
+        np.testing.assert_array_equal(O.downsample_block(x, 2).numpy(), fx[f"ds2fix_{g}"])
+        np.testing.assert_array_equal(O.downsample_block(x, 3).numpy(), fx[f"ds3fix_{g}"])
+
+
+def test_vision_tower(case):
+    cfg, seed, fx, w = case
+    px = synthetic.make_pixels(cfg, 2, seed)
+    hs = O.vision_tower_forward(px, w, cfg.vision, return_all=True)
+    _close(hs[0], fx["vit_embeddings"])
+    _close(hs[1], fx["vit_layer1"])
+    _close(hs[-1], fx["vit_selected"])
+
+
+def test_projector(case):
+    cfg, seed, fx, w = case
+    _close(O.projector_forward(torch.from_numpy(fx["vit_selected"]), w, cfg.mm_projector_type), fx["projector_out"])
+
+
+def test_splice_and_llm(case):
+    cfg, seed, fx, w = case
+    px = synthetic.make_pixels(cfg, 2, seed)
+    ids = torch.from_numpy(fx["input_ids"])
+    e, m = O.vlm_prefill_embeds([px[0]], ids, w, cfg)
+    _close(e, fx["spliced_embeds"])
+    assert bool(m.all())
+    logits, _, hs = O.qwen2_forward(e, w, cfg.llm, return_hidden=True)
+    _close(hs[1], fx["llm_hidden1"])
+    _close(logits[0, -1], fx["llm_logits_last"], 5e-5)
+    assert abs(float(logits.double().abs().sum()) - float(fx["llm_logits_all_sha"])) < 1e-4 * float(fx["llm_logits_all_sha"])
+
+
+def test_greedy_ids_bit_exact(case):
+    cfg, seed, fx, w = case
+    e = torch.from_numpy(fx["spliced_embeds"])
+    n = len(fx["greedy_ids"])
+    ids, _ = O.greedy_generate(e, w, cfg, n, stop_at_eos=False)
+    np.testing.assert_array_equal(ids.numpy(), fx["greedy_ids"])
+
+
+def test_train_loss_padded(case):
+    cfg, seed, fx, w = case
+    e = torch.from_numpy(fx["train_embeds"])
+    m = torch.from_numpy(fx["train_mask"]).bool()
+    lab = torch.from_numpy(fx["train_labels"])
+    logits, _ = O.qwen2_forward(e, w, cfg.llm, attention_mask=m)
+    loss = O.causal_lm_loss(logits, lab, int(fx["train_num_items"]))
+    assert abs(float(loss) - float(fx["train_loss"])) < 2e-5 * abs(float(fx["train_loss"]))
+
+
+def test_packed_equals_padded(case):
+    """repack (llava_arch.py:744-800) + block-diagonal varlen attention gives the per-sample losses of the padded
+    batch, except that the FIRST label of every sample is masked (:760-762)."""
+    cfg, seed, fx, w = case
+    e = torch.from_numpy(fx["train_embeds"])
+    m = torch.from_numpy(fx["train_mask"]).bool()
+    lab = torch.from_numpy(fx["train_labels"]).clone()
+    pe, pm, pp, pl, seqlens = O.repack(e, m, lab)
+    assert pe.shape[1] == int(m.sum()) + 1 and int(pm.sum()) == int(m.sum())
+    seg = torch.repeat_interleave(torch.arange(len(seqlens) + 1), torch.cat([seqlens.long(), torch.tensor([1])]))[None]
+    lg_p, _ = O.qwen2_forward(pe, w, cfg.llm, position_ids=pp.long(), segment_ids=seg)
+    n_items = int((pl[:, 1:] != -100).sum())
+    loss_p = O.causal_lm_loss(lg_p, pl, n_items)
+    lg, _ = O.qwen2_forward(e, w, cfg.llm, attention_mask=m)
+    loss = O.causal_lm_loss(lg, lab, n_items)  # first-label masking does not matter after the shift: label[0] is never a target
+    assert abs(float(loss_p) - float(loss)) < 1e-5 * abs(float(loss))
+    idx, cu, mx = O.get_unpad_data(pm, seqlens)
+    assert cu.tolist() == [0] + torch.cumsum(seqlens, 0).tolist() and mx == int(seqlens.max())
