@@ -1,0 +1,172 @@
+/* vila_hip.h — C ABI of libvila_hip.so: the MI355X (gfx950) implementation of NVILA's forward hot path.
+ *
+ * The reference (NVlabs/VILA) has no FFI/plugin API: its seams are Python module contracts.
+ * Every entry point below names the reference interface it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer in the caller's current HIP context unless marked [host];
+ *   - the caller (PyTorch) owns weights, activations, KV cache and workspace; the library allocates nothing
+ *     and keeps no device memory between calls;
+ *   - all work is enqueued asynchronously on `stream`; nothing synchronises the device;
+ *   - layouts are the reference's: nn.Linear.weight [out,in] row-major bf16, activations [tokens, channels] bf16,
+ *     conv weight [out, C, P, P];
+ *   - return 0 on success, <0 on error; vila_last_error() gives a thread-local message.  The Python shim turns a
+ *     non-zero status into ValueError/RuntimeError with the reference's wording where one exists.
+ *   - re-entrant per (device, stream); no thread-local HIP state is assumed (backward runs on autograd threads).
+ */
+#ifndef VILA_HIP_H
+#define VILA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vila_stream_t; /* hipStream_t */
+
+const char* vila_last_error(void);
+int vila_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Vision tower — replaces SiglipVisionTower / VisionTower.forward + feature_select
+ *   llava/model/multimodal_encoder/vision_encoder.py:44-52,133-177  (hidden_states[select_layer], "cls_patch")
+ *   llava/model/multimodal_encoder/siglip/modeling_siglip.py:320-329 (embeddings), :728-764 (encoder layer),
+ *   :389-439 (attention), :711-715 (MLP)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int hidden, inter, heads, image, patch, channels;
+    int n_layers_run;   /* layers actually executed = index of hidden_states[select_layer] (26 for so400m, -2) */
+    float ln_eps;
+} VilaVitShape;
+typedef struct {
+    const void *ln1_w, *ln1_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} VilaVitLayer;
+typedef struct {
+    VilaVitShape shape;
+    const void* patch_w;          /* [hidden, C, P, P] */
+    const void* patch_b;          /* [hidden] */
+    const void* pos_emb;          /* [ (image/patch)^2, hidden ] */
+    const VilaVitLayer* layers;   /* [host] array of n_layers_run entries */
+} VilaVitWeights;
+size_t vila_vit_workspace_bytes(const VilaVitShape* s, int n_images);
+/* pixels [B, C, image, image] bf16 NCHW  ->  out [B, (image/patch)^2, hidden] bf16 */
+int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int n_images, void* out,
+                     void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mm_projector — replaces MultimodalProjector.forward (llava/model/multimodal_projector/base_projector.py:248-252)
+ * for mlp_downsample (:145-153), mlp_downsample_2x2_fix (:155-162), mlp_downsample_3x3_fix (:163-174), including the
+ * space-to-depth blocks flat_square / flat_square_2x2 / flat_square_3x3 (:58-71, :84-97, :110-123).
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { VILA_PROJ_MLP_DOWNSAMPLE = 0, VILA_PROJ_MLP_DOWNSAMPLE_2X2_FIX = 1, VILA_PROJ_MLP_DOWNSAMPLE_3X3_FIX = 2 };
+typedef struct {
+    int kind;
+    int in_dim;    /* vision hidden C */
+    int out_dim;   /* LLM hidden */
+    const void *ln1_w, *ln1_b;   /* layers.1 */
+    const void *fc1_w, *fc1_b;   /* layers.2 */
+    const void *ln2_w, *ln2_b;   /* layers.4 (3x3 only) */
+    const void *fc2_w, *fc2_b;   /* layers.4 (2x2) / layers.5 (3x3) */
+    const void *fc3_w, *fc3_b;   /* layers.7 (3x3 only) */
+} VilaProjWeights;
+size_t vila_proj_workspace_bytes(const VilaProjWeights* w, int n_images, int n_tokens);
+int vila_proj_out_tokens(int kind, int n_tokens);
+/* feat [B, N, C] bf16 (N a perfect square) -> out [B, N', out_dim] bf16 */
+int vila_proj_forward(const VilaProjWeights* w, const void* feat, int n_images, int n_tokens, void* out,
+                      void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Embedding + splice — replaces llm.model.embed_tokens (llava_arch.py:429, encoders/image/basic.py:22-27) and the
+ * per-token python splice loop of LlavaMetaForCausalLM._embed (llava_arch.py:457-479): dst[dst_row[i]] = src[src_row[i]].
+ * The caller computes the row maps (integer work on the ids, no per-token host sync).
+ * ------------------------------------------------------------------------------------------------------------ */
+int vila_embed_tokens(const void* table, int64_t vocab, int hidden, const int64_t* ids, int n, void* out, vila_stream_t stream);
+int vila_copy_rows(const void* src, void* dst, const int32_t* src_row /*nullable*/, const int32_t* dst_row /*nullable*/,
+                   int n, int hidden, vila_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LLM — replaces HF Qwen2ForCausalLM.forward / .generate as called from
+ *   llava/model/language_model/llava_llama.py:134-141 (forward(inputs_embeds, attention_mask, position_ids, labels))
+ *   llava/model/llava_arch.py:833 (llm.generate(inputs_embeds=..., attention_mask=...))
+ * (third-party transformers==4.46.0, pyproject.toml:17; arithmetic per SURVEY.md Appendix B).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int hidden, inter, n_layers, q_heads, kv_heads, head_dim, vocab;
+    float rms_eps, rope_theta;
+} VilaLlmShape;
+typedef struct {
+    const void *ln1_w, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *ln2_w, *w_gate, *w_up, *w_down;
+} VilaLlmLayer;
+typedef struct {
+    VilaLlmShape shape;
+    const void* embed;            /* [vocab, hidden] */
+    const VilaLlmLayer* layers;   /* [host] */
+    const void* norm_w;
+    const void* lm_head;          /* [vocab, hidden] (== embed when tied) */
+} VilaLlmWeights;
+typedef struct {
+    void* k;        /* [n_layers][n_slots][kv_heads][max_ctx][head_dim] bf16 */
+    void* v;
+    int max_ctx, n_slots;
+} VilaKvCache;
+
+size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int total_tokens);
+/* Prefill / teacher-forced forward over a packed token stream.
+ *   embeds      [total_tokens, hidden] bf16 (spliced image+text embeddings)
+ *   positions   [total_tokens] i32   (restart per sequence, llava_arch.py:751)
+ *   cu_seqlens  [n_seq+1] i32 or NULL (one sequence)  — flash-attn varlen semantics of model/utils/packing.py:12-21
+ *   seq_of_tok  [total_tokens] i32 or NULL: KV-cache slot per token
+ *   cache       nullable: K/V are appended at `positions`
+ *   last_rows   [n_last] i32 or NULL: rows whose logits are wanted -> last_logits [n_last, vocab] fp32
+ *   all_logits  nullable [total_tokens, vocab] fp32 (training / parity)
+ *   final_hidden nullable [total_tokens, hidden] bf16: output of model.norm
+ *   layer_hidden nullable [(n_layers+1), total_tokens, hidden] bf16: residual stream taps (parity tests)
+ */
+int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, const int32_t* positions, const int32_t* cu_seqlens,
+                     int n_seq, int total_tokens, int max_seqlen, const int32_t* seq_of_tok, const VilaKvCache* cache,
+                     const int32_t* last_rows, int n_last, float* last_logits, float* all_logits, void* final_hidden,
+                     void* layer_hidden, void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
+/* Greedy decode state for one sequence (slot 0 of the cache); everything lives on the device so a step can be
+ * replayed from a hipGraph with no host round trip (replaces the python loop of GenerationMixin greedy search). */
+typedef struct {
+    int32_t* pos;        /* scalar: number of tokens already in the cache = position of the next token */
+    int64_t* token;      /* scalar: token to feed (in) / token chosen by argmax (out) */
+    int64_t* out_ids;    /* [max_out] generated ids, appended every step */
+    int32_t* n_out;      /* scalar */
+    int max_out;
+    float* logits;       /* [vocab] fp32 logits of the last step (kept for parity tests) */
+} VilaDecodeState;
+size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx);
+int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
+                         void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
+/* hipGraph helpers: capture whatever is enqueued on `stream` between begin/end, replay it later. */
+int vila_graph_begin(vila_stream_t stream);
+int vila_graph_end(vila_stream_t stream, void** graph_exec_out);
+int vila_graph_launch(void* graph_exec, vila_stream_t stream);
+int vila_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Operator-level entry points (used by the parity tests and by autograd wrappers)
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { VILA_EPI_NONE = 0, VILA_EPI_GELU_TANH = 1, VILA_EPI_GELU_ERF = 2, VILA_EPI_GATEUP = 3 };
+/* C[M,N] = epi(A[M,K] W[N,K]^T + bias[N]) + residual[M,N];  EPI_GATEUP: C = silu(A W^T) * (A W2^T) */
+int vila_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
+                   const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
+                   vila_stream_t stream);
+int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream);
+int vila_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, float eps, vila_stream_t stream);
+int vila_space_to_depth_bf16(const void* x, void* y, int n_images, int grid, int channels, int k, vila_stream_t stream);
+/* q,k,v,o: [tokens][heads][head_dim] views given by element strides; cu_seqlens NULL => n_seq sequences of max_seqlen */
+int vila_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t q_tok_stride, int64_t k_tok_stride,
+                       int64_t v_tok_stride, int64_t o_tok_stride, int q_head_stride, int k_head_stride, int v_head_stride,
+                       int o_head_stride, const int32_t* cu_seqlens, int n_seq, int total_tokens, int max_seqlen,
+                       int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, float* lse, vila_stream_t stream);
+int vila_gemv_bf16(const void* x, const void* norm_w, float eps, const void* W, const void* W2, const void* bias,
+                   const void* residual, void* y_bf16, float* y_f32, int N, int K, int mode, vila_stream_t stream);
+int vila_argmax_f32(const float* logits, int n, int64_t* out, void* workspace /* >= 4 KiB */, vila_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,236 @@
+"""GPU parity tests, operator level: every HIP kernel (called through the C-ABI) against a plain PyTorch fp32
+reference of the same op on the same seeded bf16 inputs.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+from tests.gpu_util import max_abs, randn_bf16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from vila_amd import _lib, ops as _ops
+    _lib.load()
+    return _ops
+
+
+GEMM_SHAPES = [
+    (128, 128, 64), (16, 16, 8), (1, 24, 40), (200, 264, 136), (130, 132, 72),
+    (769, 3584, 3584), (289, 512, 3584), (1024, 4304, 1152), (1024, 1152, 4304), (256, 3584, 4608),
+    (1024, 1152, 592), (7, 1000, 512),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain_bias_residual(ops, M, N, K):
+    """bf16 in / fp32 accumulate / bf16 out.  Tolerance: rel-L2 <= 4e-3 (one bf16 rounding of the output ~ 2^-9)."""
+    a = randn_bf16(M, K, seed=1)
+    w = randn_bf16(N, K, seed=2, scale=K ** -0.5)
+    bias = randn_bf16(N, seed=3)
+    res = randn_bf16(M, N, seed=4)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w)
+    assert rel_l2(out, ref) < 4e-3, f"plain rel={rel_l2(out, ref):.3e}"
+    out = ops.gemm(a, w, bias=bias, residual=res)
+    ref2 = ref + bias.float() + res.float()
+    assert rel_l2(out, ref2) < 4e-3, f"bias+res rel={rel_l2(out, ref2):.3e}"
+    out32 = ops.gemm(a, w, out_f32=True)
+    assert out32.dtype == torch.float32
+    assert rel_l2(out32, ref) < 2e-5, f"fp32-out rel={rel_l2(out32, ref):.3e}"
+
+
+def test_gemm_detects_transpose_and_identity(ops):
+    """A = I with an asymmetric W must give exactly W^T rows (guide rule: symmetric inputs hide a swapped C layout)."""
+    n = 256
+    a = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+    w = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 251 - 125).to(torch.bfloat16)
+    out = ops.gemm(a, w, out_f32=True)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+def test_gemm_strided_views_and_inplace_residual(ops):
+    M, N, K = 300, 256, 192
+    big_a = randn_bf16(M, K + 64, seed=5)
+    a = big_a[:, :K]                      # lda != K
+    w = randn_bf16(N, K, seed=6, scale=K ** -0.5)
+    x = randn_bf16(M, N, seed=7)
+    ref = x.float() + a.float() @ w.float().t()
+    ops.gemm(a, w, residual=x, out=x)     # x += a w^T in place (how the residual stream is updated)
+    assert rel_l2(x, ref) < 4e-3
+
+
+@pytest.mark.parametrize("epi,fn", [(1, lambda t: torch.nn.functional.gelu(t, approximate="tanh")),
+                                    (2, lambda t: torch.nn.functional.gelu(t))])
+def test_gemm_gelu_epilogues(ops, epi, fn):
+    M, N, K = 257, 272, 144
+    a = randn_bf16(M, K, seed=8)
+    w = randn_bf16(N, K, seed=9, scale=K ** -0.5)
+    b = randn_bf16(N, seed=10)
+    ref = fn(a.float() @ w.float().t() + b.float())
+    out = ops.gemm(a, w, bias=b, epi=epi)
+    assert rel_l2(out, ref) < 5e-3, f"rel={rel_l2(out, ref):.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(769, 18944, 3584), (100, 1088, 512), (33, 40, 64)])
+def test_gemm_gateup(ops, M, N, K):
+    a = randn_bf16(M, K, seed=11)
+    wg = randn_bf16(N, K, seed=12, scale=K ** -0.5)
+    wu = randn_bf16(N, K, seed=13, scale=K ** -0.5)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    out = ops.gemm(a, wg, w2=wu, epi=3)
+    assert out.shape == (M, N)
+    assert rel_l2(out, ref) < 5e-3, f"rel={rel_l2(out, ref):.3e}"
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    a = randn_bf16(8, 12)
+    w = randn_bf16(8, 12)
+    with pytest.raises(ValueError, match="multiple of 8"):
+        ops.gemm(a, w)
+
+
+@pytest.mark.parametrize("rows,cols", [(1024, 1152), (256, 4608), (121, 10368), (5, 144), (3, 16384)])
+def test_layernorm_rmsnorm(ops, rows, cols):
+    x = randn_bf16(rows, cols, seed=14, scale=2.0) + 0.5
+    w = randn_bf16(cols, seed=15, scale=0.1) + 1
+    b = randn_bf16(cols, seed=16, scale=0.1)
+    ref = torch.nn.functional.layer_norm(x.float(), (cols,), w.float(), b.float(), 1e-6)
+    out = ops.layernorm(x, w, b, 1e-6)
+    assert rel_l2(out, ref) < 3e-3, f"ln rel={rel_l2(out, ref):.3e}"
+    x32 = x.float()
+    y = (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+    ref = (w * y).float()                        # HF: weight * bf16(normalised)  (Qwen2RMSNorm)
+    out = ops.rmsnorm(x, w, 1e-6)
+    assert rel_l2(out, ref) < 3e-3, f"rms rel={rel_l2(out, ref):.3e}"
+
+
+@pytest.mark.parametrize("g,k", [(4, 2), (5, 2), (7, 2), (32, 2), (4, 3), (5, 3), (7, 3), (32, 3)])
+def test_space_to_depth_bit_exact(ops, g, k):
+    from oracle import vila_oracle as O
+    C = 16
+    x = (torch.arange(2 * g * g * C, dtype=torch.float32).reshape(2, g * g, C) % 255) - 127
+    ref = O.downsample_block(x, k)
+    out = ops.space_to_depth(x.to("cuda", torch.bfloat16), k)
+    assert torch.equal(out.float().cpu(), ref)
+
+
+def _attn_ref(q, k, v, causal, cu=None):
+    """fp32 reference: softmax(QK^T/sqrt(d) + mask) V per sequence, GQA by repeat."""
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    qf, kf, vf = q.float(), k.float().repeat_interleave(Hq // Hkv, 1), v.float().repeat_interleave(Hq // Hkv, 1)
+    out = torch.zeros_like(qf)
+    bounds = [0, T] if cu is None else cu.tolist()
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        s = torch.einsum("qhd,khd->hqk", qf[a:b], kf[a:b]) * D ** -0.5
+        if causal:
+            n = b - a
+            s = s.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool, device=q.device), 1), float("-inf"))
+        out[a:b] = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vf[a:b])
+    return out
+
+
+@pytest.mark.parametrize("T,Hq,Hkv,D,causal", [
+    (1024, 16, 16, 72, False), (16, 2, 2, 72, False), (100, 4, 4, 72, False),
+    (769, 28, 4, 128, True), (5, 4, 2, 128, True), (289, 4, 2, 128, True), (200, 4, 4, 64, True), (130, 2, 2, 128, False),
+])
+def test_attention_forward(ops, T, Hq, Hkv, D, causal):
+    """Tolerance: rel-L2 <= 8e-3 (P is rounded to bf16 before PV, output rounded to bf16)."""
+    qkv = randn_bf16(T, (Hq + 2 * Hkv) * D, seed=17)
+    q = qkv[:, : Hq * D].view(T, Hq, D)                       # strided views of a fused buffer, as in the model
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    ref = _attn_ref(q, k, v, causal)
+    out, lse = ops.attn_fwd(q, k, v, causal, return_lse=True)
+    assert rel_l2(out, ref) < 8e-3, f"rel={rel_l2(out, ref):.3e} max={max_abs(out, ref):.3e}"
+    kf = k.float().repeat_interleave(Hq // Hkv, 1)
+    s = torch.einsum("qhd,khd->hqk", q.float(), kf) * D ** -0.5
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+    assert max_abs(lse, torch.logsumexp(s, -1)) < 2e-2
+
+
+def test_attention_varlen_and_batched(ops):
+    Hq, Hkv, D = 4, 2, 128
+    cu = torch.tensor([0, 100, 357, 400, 401], dtype=torch.int32, device="cuda")
+    T = 401
+    q, k, v = randn_bf16(T, Hq, D, seed=18), randn_bf16(T, Hkv, D, seed=19), randn_bf16(T, Hkv, D, seed=20)
+    ref = _attn_ref(q, k, v, True, cu)
+    out = ops.attn_fwd(q, k, v, True, cu_seqlens=cu, max_seqlen=257)
+    assert rel_l2(out, ref) < 8e-3, f"varlen rel={rel_l2(out, ref):.3e}"
+    # uniform batches without cu_seqlens (the ViT path: B images x N tokens)
+    B, N = 3, 196
+    q, k, v = randn_bf16(B * N, 2, 72, seed=21), randn_bf16(B * N, 2, 72, seed=22), randn_bf16(B * N, 2, 72, seed=23)
+    cu2 = torch.arange(0, B * N + 1, N, dtype=torch.int32, device="cuda")
+    ref = _attn_ref(q, k, v, False, cu2)
+    out = ops.attn_fwd(q, k, v, False, n_seq=B)
+    assert rel_l2(out, ref) < 8e-3, f"batched rel={rel_l2(out, ref):.3e}"
+
+
+def test_attention_running_max_jump(ops):
+    """Force the online-softmax rescale branch: a late key dominates (guide rule 26): full-tensor reference."""
+    T, H, D = 300, 2, 128
+    q, k, v = randn_bf16(T, H, D, seed=24), randn_bf16(T, H, D, seed=25), randn_bf16(T, H, D, seed=26)
+    k[200] = (q[250].float() * 1.5).to(torch.bfloat16)       # key 200 (4th KV tile) spikes against query 250
+    k[70] = (q[10].float() * -2.0).to(torch.bfloat16)
+    for causal in (False, True):
+        ref = _attn_ref(q, k, v, causal)
+        out = ops.attn_fwd(q, k, v, causal)
+        assert rel_l2(out, ref) < 8e-3, f"causal={causal} rel={rel_l2(out, ref):.3e}"
+        assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("N,K", [(3584, 3584), (4608, 3584), (3584, 18944), (1000, 512), (6, 64)])
+def test_gemv_plain_and_fused(ops, N, K):
+    x = randn_bf16(K, seed=27)
+    w = randn_bf16(N, K, seed=28, scale=K ** -0.5)
+    b = randn_bf16(N, seed=29)
+    r = randn_bf16(N, seed=30)
+    g = randn_bf16(K, seed=31, scale=0.1) + 1
+    ref = w.float() @ x.float()
+    out = ops.gemv(x, w, out_f32=True)
+    assert rel_l2(out, ref) < 1e-4, f"f32 rel={rel_l2(out, ref):.3e}"
+    out = ops.gemv(x, w, bias=b, residual=r)
+    ref2 = (ref + b.float()).to(torch.bfloat16).float() + r.float()
+    assert rel_l2(out, ref2) < 4e-3, f"bias+res rel={rel_l2(out, ref2):.3e}"
+    x32 = x.float()
+    xn = (g * (x32 * torch.rsqrt(x32.pow(2).mean() + 1e-6)).to(torch.bfloat16)).float()
+    out = ops.gemv(x, w, norm_w=g, eps=1e-6, out_f32=True)
+    assert rel_l2(out, w.float() @ xn) < 2e-3, f"norm rel={rel_l2(out, w.float() @ xn):.3e}"
+
+
+def test_gemv_gateup(ops):
+    K, N = 3584, 18944
+    x = randn_bf16(K, seed=32)
+    wg, wu = randn_bf16(N, K, seed=33, scale=K ** -0.5), randn_bf16(N, K, seed=34, scale=K ** -0.5)
+    ref = torch.nn.functional.silu(wg.float() @ x.float()) * (wu.float() @ x.float())
+    out = ops.gemv(x, wg, w2=wu)
+    assert rel_l2(out, ref) < 8e-3, f"rel={rel_l2(out, ref):.3e}"
+
+
+def test_argmax_first_maximum(ops):
+    g = torch.Generator().manual_seed(35)
+    x = torch.randn(152064, generator=g).cuda()
+    assert int(ops.argmax(x)) == int(torch.argmax(x))
+    x[1234] = 50.0
+    x[99999] = 50.0
+    assert int(ops.argmax(x)) == 1234          # ties -> first index
+    y = torch.full((1000,), -3.0, device="cuda")
+    assert int(ops.argmax(y)) == 0
+
+
+def test_embed_and_copy_rows(ops):
+    table = randn_bf16(1000, 512, seed=36)
+    ids = torch.tensor([[3, 999, 0], [7, 7, 512]])
+    out = ops.embed_tokens(table, ids)
+    assert torch.equal(out, table[ids.cuda()])
+    dst = torch.zeros(10, 512, device="cuda", dtype=torch.bfloat16)
+    src_row = torch.tensor([5, 6, 900], dtype=torch.int32, device="cuda")
+    dst_row = torch.tensor([9, 0, 4], dtype=torch.int32, device="cuda")
+    ops.copy_rows(table, dst, src_row, dst_row, 3)
+    assert torch.equal(dst[9], table[5]) and torch.equal(dst[0], table[6]) and torch.equal(dst[4], table[900])
+    assert float(dst[1].float().abs().sum()) == 0

@@ -1,0 +1,71 @@
+"""Kernel micro-benchmarks on one MI355X (HIP-event timed on the current stream).  python tools/microbench.py [gemm|gemv|attn|all]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vila_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, device="cuda") * scale).to(torch.bfloat16)
+
+
+def bench_gemm():
+    print("== GEMM bf16 (TFLOP/s) ==")
+    for M, N, K, epi in [(769, 4608, 3584, 0), (769, 3584, 3584, 0), (769, 18944, 3584, 3), (769, 3584, 18944, 0),
+                         (1024, 3456, 1152, 0), (1024, 1152, 1152, 0), (1024, 4304, 1152, 1), (1024, 1152, 4304, 0),
+                         (4096, 4096, 4096, 0), (8192, 8192, 8192, 0), (3076, 18944, 3584, 3)]:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        w2 = rnd(N, K, scale=K ** -0.5) if epi == 3 else None
+        t = timeit(lambda: ops.gemm(a, w, w2=w2, epi=epi), iters=10)
+        fl = 2.0 * M * N * K * (2 if epi == 3 else 1)
+        tt = timeit(lambda: torch.matmul(a, w.t()), iters=10)
+        print(f"M={M:5d} N={N:6d} K={K:6d} epi={epi}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s   (torch/hipBLASLt {2.0*M*N*K/tt/1e12:7.1f} TF/s)")
+
+
+def bench_gemv():
+    print("== GEMV bf16 (GB/s of weight bytes) ==")
+    for N, K, mode in [(4608, 3584, 0), (3584, 3584, 0), (18944, 3584, 1), (3584, 18944, 0), (152064, 3584, 0)]:
+        x, w = rnd(K), rnd(N, K, scale=K ** -0.5)
+        w2 = rnd(N, K, scale=K ** -0.5) if mode else None
+        g = rnd(K)
+        t = timeit(lambda: ops.gemv(x, w, w2=w2, norm_w=g if K == 3584 else None, eps=1e-6), iters=50)
+        by = N * K * 2 * (2 if mode else 1)
+        print(f"N={N:6d} K={K:6d} mode={mode}: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s")
+
+
+def bench_attn():
+    print("== attention fwd (TFLOP/s, 4*T*T*D*H (x0.5 causal)) ==")
+    for T, Hq, Hkv, D, causal, nseq in [(1024, 16, 16, 72, False, 1), (8192, 16, 16, 72, False, 8), (769, 28, 4, 128, True, 1),
+                                         (4096, 28, 4, 128, True, 1), (16384, 28, 4, 128, True, 1)]:
+        q, k, v = rnd(T, Hq, D), rnd(T, Hkv, D), rnd(T, Hkv, D)
+        t = timeit(lambda: ops.attn_fwd(q, k, v, causal, n_seq=nseq), iters=10)
+        n = T // nseq
+        fl = 4.0 * n * n * D * Hq * nseq * (0.5 if causal else 1.0)
+        print(f"T={T:6d} Hq={Hq} Hkv={Hkv} D={D} causal={causal} nseq={nseq}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    print(torch.cuda.get_device_name(0))
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("gemv", "all"):
+        bench_gemv()
+    if what in ("attn", "all"):
+        bench_attn()

@@ -1,0 +1,130 @@
+"""ctypes binding of libvila_hip.so (include/vila_hip.h).  No CPU fallback: if the library is missing or a symbol
+is absent this module raises, and every op raises if handed a non-GPU tensor."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvila_hip.so")
+
+c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class VilaVitShape(C.Structure):
+    _fields_ = [("hidden", c_int), ("inter", c_int), ("heads", c_int), ("image", c_int), ("patch", c_int),
+                ("channels", c_int), ("n_layers_run", c_int), ("ln_eps", c_float)]
+
+
+class VilaVitLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo",
+                                        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VilaVitWeights(C.Structure):
+    _fields_ = [("shape", VilaVitShape), ("patch_w", c_void_p), ("patch_b", c_void_p), ("pos_emb", c_void_p),
+                ("layers", C.POINTER(VilaVitLayer))]
+
+
+class VilaProjWeights(C.Structure):
+    _fields_ = [("kind", c_int), ("in_dim", c_int), ("out_dim", c_int)] + \
+               [(n, c_void_p) for n in ("ln1_w", "ln1_b", "fc1_w", "fc1_b", "ln2_w", "ln2_b", "fc2_w", "fc2_b", "fc3_w", "fc3_b")]
+
+
+class VilaLlmShape(C.Structure):
+    _fields_ = [("hidden", c_int), ("inter", c_int), ("n_layers", c_int), ("q_heads", c_int), ("kv_heads", c_int),
+                ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("rope_theta", c_float)]
+
+
+class VilaLlmLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "ln2_w", "w_gate", "w_up", "w_down")]
+
+
+class VilaLlmWeights(C.Structure):
+    _fields_ = [("shape", VilaLlmShape), ("embed", c_void_p), ("layers", C.POINTER(VilaLlmLayer)),
+                ("norm_w", c_void_p), ("lm_head", c_void_p)]
+
+
+class VilaKvCache(C.Structure):
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int), ("n_slots", c_int)]
+
+
+class VilaDecodeState(C.Structure):
+    _fields_ = [("pos", c_void_p), ("token", c_void_p), ("out_ids", c_void_p), ("n_out", c_void_p),
+                ("max_out", c_int), ("logits", c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/vila_hip.h declares
+PROTOTYPES = {
+    "vila_last_error": (C.c_char_p, []),
+    "vila_abi_version": (c_int, []),
+    "vila_vit_workspace_bytes": (c_size_t, [C.POINTER(VilaVitShape), c_int]),
+    "vila_vit_forward": (c_int, [C.POINTER(VilaVitWeights), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vila_proj_workspace_bytes": (c_size_t, [C.POINTER(VilaProjWeights), c_int, c_int]),
+    "vila_proj_out_tokens": (c_int, [c_int, c_int]),
+    "vila_proj_forward": (c_int, [C.POINTER(VilaProjWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vila_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vila_copy_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vila_llm_prefill_workspace_bytes": (c_size_t, [C.POINTER(VilaLlmShape), c_int]),
+    "vila_llm_prefill": (c_int, [C.POINTER(VilaLlmWeights), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                 C.POINTER(VilaKvCache), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "vila_llm_decode_workspace_bytes": (c_size_t, [C.POINTER(VilaLlmShape), c_int]),
+    "vila_llm_decode_step": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeState),
+                                     c_void_p, c_size_t, c_void_p]),
+    "vila_graph_begin": (c_int, [c_void_p]),
+    "vila_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "vila_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "vila_graph_destroy": (c_int, [c_void_p]),
+    "vila_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                               c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "vila_rmsnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "vila_space_to_depth_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_attn_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_float, c_void_p, c_void_p]),
+    "vila_gemv_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_int, c_int, c_void_p]),
+    "vila_argmax_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class VilaHipError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = False) -> C.CDLL:
+    """Load the library.  Never falls back to anything else: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build as _b
+            _b.build()
+        else:
+            raise VilaHipError(f"{LIB_PATH} not found. Build it with `python -m vila_amd.build` (needs hipcc); "
+                               "vila_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VilaHipError(f"libvila_hip.so does not export `{name}` (stale build? run python -m vila_amd.build --force)") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = load().vila_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(msg)         # argument / shape errors: the reference raises ValueError for these
+    raise VilaHipError(f"{what}: {msg} (status {rc})")

@@ -1,0 +1,398 @@
+// C-ABI of libvila_hip.so (include/vila_hip.h): model-level chaining of the kernels on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/vila_hip.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void vila_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* vila_last_error(void) { return g_err; }
+extern "C" int vila_abi_version(void) { return 1; }
+
+namespace {
+struct Arena {
+    char* base; size_t size, off;
+    Arena(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+    template <typename T> T* take(size_t count) {
+        off = align_up(off, 256);
+        T* r = (T*)(base + off);
+        off += count * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= size; }
+};
+inline hipStream_t S(vila_stream_t s) { return (hipStream_t)s; }
+inline const bf16_t* B(const void* p) { return (const bf16_t*)p; }
+inline bf16_t* B(void* p) { return (bf16_t*)p; }
+
+int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const bf16_t* res, int64_t ldr,
+         void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = B(W); g.ldw = ldw; g.W2 = B(W2); g.bias = B(bias); g.residual = res; g.ldr = ldr;
+    g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.M = M; g.N = N; g.K = K; g.epi = epi;
+    return launch_gemm(g, s);
+}
+}  // namespace
+
+// =================================================================================================
+// Vision tower
+// =================================================================================================
+static inline int vit_kp(const VilaVitShape* s) { return (int)align_up((size_t)s->channels * s->patch * s->patch, 8); }
+
+extern "C" size_t vila_vit_workspace_bytes(const VilaVitShape* s, int n_images) {
+    const size_t g = s->image / s->patch, M = (size_t)n_images * g * g, D = s->hidden, F = s->inter, Kp = vit_kp(s);
+    size_t b = 0;
+    b += align_up(M * Kp * 2, 256) + align_up(D * Kp * 2, 256);     // patches, padded conv weight
+    b += 2 * align_up(M * D * 2, 256);                               // x, h
+    b += align_up(M * 3 * D * 2, 256);                               // qkv
+    b += align_up(M * F * 2, 256);                                   // mlp hidden
+    return b + 4096;
+}
+
+extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int n_images, void* out,
+                                void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    const VilaVitShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    VILA_REQUIRE(n_images > 0, "vit: n_images must be positive");
+    VILA_REQUIRE(sh.image % sh.patch == 0, "vit: image size %d is not a multiple of patch size %d", sh.image, sh.patch);
+    VILA_REQUIRE(sh.hidden % sh.heads == 0, "embed_dim must be divisible by num_heads (got `embed_dim`: %d and `num_heads`: %d).", sh.hidden, sh.heads);
+    VILA_REQUIRE(workspace_bytes >= vila_vit_workspace_bytes(&sh, n_images), "vit: workspace too small");
+    const int g = sh.image / sh.patch, N = g * g, M = n_images * N, D = sh.hidden, F = sh.inter, hd = D / sh.heads;
+    const int Kc = sh.channels * sh.patch * sh.patch, Kp = vit_kp(&sh);
+    Arena a(workspace, workspace_bytes);
+    bf16_t* patches = a.take<bf16_t>((size_t)M * Kp);
+    bf16_t* wpad = a.take<bf16_t>((size_t)D * Kp);
+    bf16_t* x = a.take<bf16_t>((size_t)M * D);
+    bf16_t* h = a.take<bf16_t>((size_t)M * D);
+    bf16_t* qkv = a.take<bf16_t>((size_t)M * 3 * D);
+    bf16_t* f = a.take<bf16_t>((size_t)M * F);
+    VILA_REQUIRE(a.ok(), "vit: workspace arena overflow");
+
+    // a2: patch embed = im2col + GEMM (+bias) + position embedding as the residual operand, per image
+    VILA_TRY(launch_im2col(B(pixels), patches, n_images, sh.channels, sh.image, sh.image, sh.patch, Kp, s));
+    VILA_TRY(launch_pad_rows(B(w->patch_w), wpad, D, Kc, Kp, s));
+    bf16_t* x0 = (sh.n_layers_run == 0) ? B(out) : x;
+    for (int b = 0; b < n_images; ++b)
+        VILA_TRY(gemm(patches + (size_t)b * N * Kp, Kp, wpad, Kp, w->patch_b, B(w->pos_emb), D, x0 + (size_t)b * N * D, D, N, D, Kp, EPI_NONE, s));
+
+    for (int l = 0; l < sh.n_layers_run; ++l) {
+        const VilaVitLayer& L = w->layers[l];
+        bf16_t* xo = (l == sh.n_layers_run - 1) ? B(out) : x;   // last layer writes straight into `out`
+        VILA_TRY(launch_layernorm(x, B(L.ln1_w), B(L.ln1_b), h, M, D, sh.ln_eps, s));
+        const bool fused = (B(L.wk) == B(L.wq) + (size_t)D * D) && (B(L.wv) == B(L.wk) + (size_t)D * D) &&
+                           (B(L.bk) == B(L.bq) + D) && (B(L.bv) == B(L.bk) + D);
+        if (fused) {
+            VILA_TRY(gemm(h, D, L.wq, D, L.bq, nullptr, 0, qkv, 3 * D, M, 3 * D, D, EPI_NONE, s));
+        } else {
+            VILA_TRY(gemm(h, D, L.wq, D, L.bq, nullptr, 0, qkv, 3 * D, M, D, D, EPI_NONE, s));
+            VILA_TRY(gemm(h, D, L.wk, D, L.bk, nullptr, 0, qkv + D, 3 * D, M, D, D, EPI_NONE, s));
+            VILA_TRY(gemm(h, D, L.wv, D, L.bv, nullptr, 0, qkv + 2 * D, 3 * D, M, D, D, EPI_NONE, s));
+        }
+        AttnArgs at{};
+        at.q = qkv; at.k = qkv + D; at.v = qkv + 2 * D; at.o = h;
+        at.q_tok_stride = at.k_tok_stride = at.v_tok_stride = 3 * D; at.o_tok_stride = D;
+        at.q_head_stride = at.k_head_stride = at.v_head_stride = at.o_head_stride = hd;
+        at.cu_seqlens = nullptr; at.n_seq = n_images; at.total_tokens = M; at.max_seqlen = N;
+        at.n_q_heads = at.n_kv_heads = sh.heads; at.head_dim = hd; at.causal = 0; at.scale = 1.0f / sqrtf((float)hd);
+        at.lse = nullptr;
+        VILA_TRY(launch_attn_fwd(at, s));
+        VILA_TRY(gemm(h, D, L.wo, D, L.bo, x, D, x, D, M, D, D, EPI_NONE, s));               // x += out_proj(attn)
+        VILA_TRY(launch_layernorm(x, B(L.ln2_w), B(L.ln2_b), h, M, D, sh.ln_eps, s));
+        VILA_TRY(gemm(h, D, L.fc1_w, D, L.fc1_b, nullptr, 0, f, F, M, F, D, EPI_GELU_TANH, s));
+        VILA_TRY(gemm(f, F, L.fc2_w, F, L.fc2_b, x, D, xo, D, M, D, F, EPI_NONE, s));        // x += fc2(gelu(fc1))
+    }
+    return 0;
+}
+
+// =================================================================================================
+// Projector
+// =================================================================================================
+extern "C" int vila_proj_out_tokens(int kind, int n_tokens) {
+    const int g = (int)(sqrt((double)n_tokens) + 0.5);
+    const int k = (kind == VILA_PROJ_MLP_DOWNSAMPLE_3X3_FIX) ? 3 : 2;
+    const int gd = (g + k - 1) / k;
+    return gd * gd;
+}
+extern "C" size_t vila_proj_workspace_bytes(const VilaProjWeights* w, int n_images, int n_tokens) {
+    const int k = (w->kind == VILA_PROJ_MLP_DOWNSAMPLE_3X3_FIX) ? 3 : 2;
+    const size_t T = (size_t)n_images * vila_proj_out_tokens(w->kind, n_tokens);
+    const size_t C = w->in_dim, H = w->out_dim;
+    return align_up(T * k * k * C * 2, 256) + align_up(T * 3 * C * 2, 256) + 2 * align_up(T * H * 2, 256) + 4096;
+}
+extern "C" int vila_proj_forward(const VilaProjWeights* w, const void* feat, int n_images, int n_tokens, void* out,
+                                 void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    hipStream_t s = S(stream);
+    const int g = (int)(sqrt((double)n_tokens) + 0.5);
+    VILA_REQUIRE(g * g == n_tokens, "projector: token count %d is not a perfect square", n_tokens);
+    VILA_REQUIRE(w->kind >= 0 && w->kind <= 2, "Unknown projector type: %d", w->kind);
+    VILA_REQUIRE(workspace_bytes >= vila_proj_workspace_bytes(w, n_images, n_tokens), "projector: workspace too small");
+    const int k = (w->kind == VILA_PROJ_MLP_DOWNSAMPLE_3X3_FIX) ? 3 : 2;
+    const int T = n_images * vila_proj_out_tokens(w->kind, n_tokens);
+    const int C = w->in_dim, H = w->out_dim, C1 = k * k * C;
+    Arena a(workspace, workspace_bytes);
+    bf16_t* y = a.take<bf16_t>((size_t)T * C1);
+    bf16_t* mid = a.take<bf16_t>((size_t)T * 3 * C);
+    bf16_t* h1 = a.take<bf16_t>((size_t)T * H);
+    VILA_REQUIRE(a.ok(), "projector: workspace arena overflow");
+    VILA_TRY(launch_space_to_depth(B(feat), y, n_images, g, C, k, s));
+    VILA_TRY(launch_layernorm(y, B(w->ln1_w), B(w->ln1_b), y, T, C1, 1e-5f, s));
+    if (k == 2) {
+        VILA_TRY(gemm(y, C1, w->fc1_w, C1, w->fc1_b, nullptr, 0, h1, H, T, H, C1, EPI_GELU_ERF, s));
+        VILA_TRY(gemm(h1, H, w->fc2_w, H, w->fc2_b, nullptr, 0, out, H, T, H, H, EPI_NONE, s));
+    } else {
+        VILA_TRY(gemm(y, C1, w->fc1_w, C1, w->fc1_b, nullptr, 0, mid, 3 * C, T, 3 * C, C1, EPI_GELU_ERF, s));
+        VILA_TRY(launch_layernorm(mid, B(w->ln2_w), B(w->ln2_b), mid, T, 3 * C, 1e-5f, s));
+        VILA_TRY(gemm(mid, 3 * C, w->fc2_w, 3 * C, w->fc2_b, nullptr, 0, h1, H, T, H, 3 * C, EPI_GELU_ERF, s));
+        VILA_TRY(gemm(h1, H, w->fc3_w, H, w->fc3_b, nullptr, 0, out, H, T, H, H, EPI_NONE, s));
+    }
+    return 0;
+}
+
+// =================================================================================================
+// Embedding / splice
+// =================================================================================================
+extern "C" int vila_embed_tokens(const void* table, int64_t vocab, int hidden, const int64_t* ids, int n, void* out, vila_stream_t stream) {
+    return launch_embed_gather(B(table), ids, B(out), n, hidden, vocab, S(stream));
+}
+extern "C" int vila_copy_rows(const void* src, void* dst, const int32_t* src_row, const int32_t* dst_row, int n, int hidden, vila_stream_t stream) {
+    return launch_copy_rows(B(src), B(dst), src_row, dst_row, n, hidden, S(stream));
+}
+
+// =================================================================================================
+// LLM prefill
+// =================================================================================================
+extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T) {
+    const size_t H = s->hidden, F = s->inter, QKV = (size_t)(s->q_heads + 2 * s->kv_heads) * s->head_dim;
+    size_t b = 0;
+    b += 2 * align_up((size_t)T * H * 2, 256);                 // x, h
+    b += align_up((size_t)T * QKV * 2, 256);                   // qkv
+    b += align_up((size_t)T * F * 2, 256);                     // act
+    b += 2 * align_up((size_t)T * (s->head_dim / 2) * 4, 256); // rope cos/sin
+    b += align_up((size_t)T * H * 2, 256);                     // gathered last rows / final norm
+    return b + 8192;
+}
+
+extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, const int32_t* positions, const int32_t* cu_seqlens,
+                                int n_seq, int T, int max_seqlen, const int32_t* seq_of_tok, const VilaKvCache* cache,
+                                const int32_t* last_rows, int n_last, float* last_logits, float* all_logits, void* final_hidden,
+                                void* layer_hidden, void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    const VilaLlmShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    VILA_REQUIRE(T > 0 && n_seq > 0, "llm_prefill: empty input");
+    VILA_REQUIRE(sh.q_heads % sh.kv_heads == 0, "llm: q heads must be a multiple of kv heads");
+    VILA_REQUIRE(cu_seqlens != nullptr || n_seq == 1, "llm_prefill: n_seq > 1 needs cu_seqlens");
+    VILA_REQUIRE(workspace_bytes >= vila_llm_prefill_workspace_bytes(&sh, T), "llm_prefill: workspace too small");
+    const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd, KS = sh.kv_heads * hd, QKV = QS + 2 * KS;
+    Arena a(workspace, workspace_bytes);
+    bf16_t* x = a.take<bf16_t>((size_t)T * H);
+    bf16_t* h = a.take<bf16_t>((size_t)T * H);
+    bf16_t* qkv = a.take<bf16_t>((size_t)T * QKV);
+    bf16_t* act = a.take<bf16_t>((size_t)T * F);
+    float* cs = a.take<float>((size_t)T * hd / 2);
+    float* sn = a.take<float>((size_t)T * hd / 2);
+    bf16_t* lastbuf = a.take<bf16_t>((size_t)T * H);
+    VILA_REQUIRE(a.ok(), "llm_prefill: workspace arena overflow");
+    if (cache != nullptr) VILA_REQUIRE(max_seqlen <= cache->max_ctx, "llm_prefill: sequence (%d) longer than the KV cache (%d)", max_seqlen, cache->max_ctx);
+
+    VILA_HIP(hipMemcpyAsync(x, embeds, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
+    VILA_TRY(launch_rope_table(positions, cs, sn, T, hd, sh.rope_theta, s));
+    bf16_t* taps = B(layer_hidden);
+    if (taps) VILA_HIP(hipMemcpyAsync(taps, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
+
+    for (int l = 0; l < sh.n_layers; ++l) {
+        const VilaLlmLayer& L = w->layers[l];
+        VILA_TRY(launch_rmsnorm(x, B(L.ln1_w), h, T, H, sh.rms_eps, s));
+        const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
+                           (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
+        if (fused) {
+            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QKV, H, EPI_NONE, s));
+        } else {
+            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QS, H, EPI_NONE, s));
+            VILA_TRY(gemm(h, H, L.wk, H, L.bk, nullptr, 0, qkv + QS, QKV, T, KS, H, EPI_NONE, s));
+            VILA_TRY(gemm(h, H, L.wv, H, L.bv, nullptr, 0, qkv + QS + KS, QKV, T, KS, H, EPI_NONE, s));
+        }
+        bf16_t* kc = nullptr; bf16_t* vc = nullptr; int max_ctx = 0;
+        if (cache != nullptr) {
+            const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
+            kc = B(cache->k) + l * per_layer; vc = B(cache->v) + l * per_layer; max_ctx = cache->max_ctx;
+        }
+        VILA_TRY(launch_rope_kv(qkv, cs, sn, positions, seq_of_tok, kc, vc, T, sh.q_heads, sh.kv_heads, hd, max_ctx, s));
+        AttnArgs at{};
+        at.q = qkv; at.k = qkv + QS; at.v = qkv + QS + KS; at.o = h;
+        at.q_tok_stride = at.k_tok_stride = at.v_tok_stride = QKV; at.o_tok_stride = QS;
+        at.q_head_stride = at.k_head_stride = at.v_head_stride = at.o_head_stride = hd;
+        at.cu_seqlens = cu_seqlens; at.n_seq = n_seq; at.total_tokens = T; at.max_seqlen = (cu_seqlens ? max_seqlen : T);
+        at.n_q_heads = sh.q_heads; at.n_kv_heads = sh.kv_heads; at.head_dim = hd; at.causal = 1;
+        at.scale = 1.0f / sqrtf((float)hd); at.lse = nullptr;
+        VILA_REQUIRE(QS == H, "llm: q_heads*head_dim (%d) must equal hidden (%d) for the in-place attention buffer", QS, H);
+        VILA_TRY(launch_attn_fwd(at, s));
+        VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s));                   // x += o_proj(attn)
+        VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
+        VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, T, F, H, EPI_GATEUP, s, L.w_up));  // silu(gate)*up
+        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, T, H, F, EPI_NONE, s));                // x += down(...)
+        if (taps) VILA_HIP(hipMemcpyAsync(taps + (size_t)(l + 1) * T * H, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
+    }
+
+    if (final_hidden != nullptr || all_logits != nullptr) {
+        bf16_t* fh = final_hidden ? B(final_hidden) : h;
+        VILA_TRY(launch_rmsnorm(x, B(w->norm_w), fh, T, H, sh.rms_eps, s));
+        if (all_logits) VILA_TRY(gemm(fh, H, w->lm_head, H, nullptr, nullptr, 0, all_logits, sh.vocab, T, sh.vocab, H, EPI_NONE, s, nullptr, 1));
+    }
+    if (n_last > 0 && last_logits != nullptr) {
+        VILA_REQUIRE(last_rows != nullptr, "llm_prefill: last_rows is NULL");
+        VILA_TRY(launch_copy_rows(x, lastbuf, last_rows, nullptr, n_last, H, s));
+        if (n_last == 1) {
+            GemvArgs g{};
+            g.x = lastbuf; g.norm_w = B(w->norm_w); g.eps = sh.rms_eps; g.W = B(w->lm_head); g.y_f32 = last_logits;
+            g.N = sh.vocab; g.K = H; g.mode = 0;
+            VILA_TRY(launch_gemv(g, s));
+        } else {
+            VILA_TRY(launch_rmsnorm(lastbuf, B(w->norm_w), lastbuf, n_last, H, sh.rms_eps, s));
+            VILA_TRY(gemm(lastbuf, H, w->lm_head, H, nullptr, nullptr, 0, last_logits, sh.vocab, n_last, sh.vocab, H, EPI_NONE, s, nullptr, 1));
+        }
+    }
+    return 0;
+}
+
+// =================================================================================================
+// LLM decode step (batch 1, greedy)
+// =================================================================================================
+static inline int dec_splits(int max_ctx) { return cdiv(max_ctx, 64); }
+extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx) {
+    const size_t H = s->hidden, F = s->inter, QS = (size_t)s->q_heads * s->head_dim;
+    const size_t ns = dec_splits(max_ctx);
+    size_t b = 0;
+    b += 2 * align_up(H * 2, 256) + 2 * align_up(QS * 2, 256) + align_up(F * 2, 256);
+    b += align_up(ns * QS * 4, 256) + align_up(ns * s->q_heads * 2 * 4, 256);
+    b += 2 * align_up(256 * 4, 256);
+    return b + 4096;
+}
+
+extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
+                                    void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    const VilaLlmShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    VILA_REQUIRE(cache != nullptr && st != nullptr, "llm_decode: cache/state is NULL");
+    VILA_REQUIRE(workspace_bytes >= vila_llm_decode_workspace_bytes(&sh, cache->max_ctx), "llm_decode: workspace too small");
+    const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd, KS = sh.kv_heads * hd;
+    const int ns = dec_splits(cache->max_ctx);
+    Arena a(workspace, workspace_bytes);
+    bf16_t* x = a.take<bf16_t>(H);
+    bf16_t* x2 = a.take<bf16_t>(H);
+    bf16_t* q = a.take<bf16_t>(QS);
+    bf16_t* ao = a.take<bf16_t>(QS);
+    bf16_t* act = a.take<bf16_t>(F);
+    float* part_o = a.take<float>((size_t)ns * QS);
+    float* part_ml = a.take<float>((size_t)ns * sh.q_heads * 2);
+    float* tv = a.take<float>(256);
+    int* ti = a.take<int>(256);
+    VILA_REQUIRE(a.ok(), "llm_decode: workspace arena overflow");
+
+    VILA_TRY(launch_embed_token(B(w->embed), st->token, x, H, sh.vocab, s));
+    bf16_t* cur = x; bf16_t* nxt = x2;
+    for (int l = 0; l < sh.n_layers; ++l) {
+        const VilaLlmLayer& L = w->layers[l];
+        const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
+        bf16_t* kc = B(cache->k) + l * per_layer; bf16_t* vc = B(cache->v) + l * per_layer;
+        const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
+                           (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
+        VILA_REQUIRE(fused, "llm_decode: q/k/v projection weights and biases must be views of one fused [q+2kv, hidden] buffer");
+        QkvDecodeArgs qa{};
+        qa.x = cur; qa.norm_w = B(L.ln1_w); qa.eps = sh.rms_eps; qa.Wqkv = B(L.wq); qa.bqkv = B(L.bq); qa.q_out = q;
+        qa.kcache = kc; qa.vcache = vc; qa.pos_ptr = st->pos; qa.K = H; qa.nq = sh.q_heads; qa.nkv = sh.kv_heads; qa.hd = hd;
+        qa.max_ctx = cache->max_ctx; qa.theta = sh.rope_theta;
+        VILA_TRY(launch_qkv_decode(qa, s));
+        AttnDecodeArgs ad{};
+        ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
+        ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
+        VILA_TRY(launch_attn_decode(ad, s));
+        GemvArgs o{};
+        o.x = ao; o.W = B(L.wo); o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
+        VILA_TRY(launch_gemv(o, s));
+        GemvArgs gu{};
+        gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.W = B(L.w_gate); gu.W2 = B(L.w_up); gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
+        VILA_TRY(launch_gemv(gu, s));
+        GemvArgs dn{};
+        dn.x = act; dn.W = B(L.w_down); dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0;
+        VILA_TRY(launch_gemv(dn, s));
+    }
+    GemvArgs lm{};
+    lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
+    VILA_TRY(launch_gemv(lm, s));
+    VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
+    VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
+    return 0;
+}
+
+// =================================================================================================
+// hipGraph helpers
+// =================================================================================================
+extern "C" int vila_graph_begin(vila_stream_t stream) {
+    VILA_HIP(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int vila_graph_end(vila_stream_t stream, void** graph_exec_out) {
+    hipGraph_t g = nullptr;
+    VILA_HIP(hipStreamEndCapture(S(stream), &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (err != hipSuccess) VILA_FAIL(-2, "hipGraphInstantiate failed: %s", hipGetErrorString(err));
+    *graph_exec_out = (void*)e;
+    return 0;
+}
+extern "C" int vila_graph_launch(void* graph_exec, vila_stream_t stream) {
+    VILA_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, S(stream)));
+    return 0;
+}
+extern "C" int vila_graph_destroy(void* graph_exec) {
+    if (graph_exec) VILA_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+// =================================================================================================
+// Operator-level exports
+// =================================================================================================
+extern "C" int vila_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
+                              const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
+                              vila_stream_t stream) {
+    return gemm(B(A), lda, W, ldw, bias, B(residual), ldr, C, ldc, M, N, K, epi, S(stream), W2, out_f32);
+}
+extern "C" int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream) {
+    return launch_layernorm(B(x), B(w), B(b), B(y), rows, cols, eps, S(stream));
+}
+extern "C" int vila_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, float eps, vila_stream_t stream) {
+    return launch_rmsnorm(B(x), B(w), B(y), rows, cols, eps, S(stream));
+}
+extern "C" int vila_space_to_depth_bf16(const void* x, void* y, int n_images, int grid, int channels, int k, vila_stream_t stream) {
+    return launch_space_to_depth(B(x), B(y), n_images, grid, channels, k, S(stream));
+}
+extern "C" int vila_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t q_tok_stride, int64_t k_tok_stride,
+                                  int64_t v_tok_stride, int64_t o_tok_stride, int q_head_stride, int k_head_stride, int v_head_stride,
+                                  int o_head_stride, const int32_t* cu_seqlens, int n_seq, int total_tokens, int max_seqlen,
+                                  int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, float* lse, vila_stream_t stream) {
+    AttnArgs at{};
+    at.q = B(q); at.k = B(k); at.v = B(v); at.o = B(o);
+    at.q_tok_stride = q_tok_stride; at.k_tok_stride = k_tok_stride; at.v_tok_stride = v_tok_stride; at.o_tok_stride = o_tok_stride;
+    at.q_head_stride = q_head_stride; at.k_head_stride = k_head_stride; at.v_head_stride = v_head_stride; at.o_head_stride = o_head_stride;
+    at.cu_seqlens = cu_seqlens; at.n_seq = n_seq; at.total_tokens = total_tokens; at.max_seqlen = max_seqlen;
+    at.n_q_heads = n_q_heads; at.n_kv_heads = n_kv_heads; at.head_dim = head_dim; at.causal = causal; at.scale = scale; at.lse = lse;
+    return launch_attn_fwd(at, S(stream));
+}
+extern "C" int vila_gemv_bf16(const void* x, const void* norm_w, float eps, const void* W, const void* W2, const void* bias,
+                              const void* residual, void* y_bf16, float* y_f32, int N, int K, int mode, vila_stream_t stream) {
+    GemvArgs g{};
+    g.x = B(x); g.norm_w = B(norm_w); g.eps = eps; g.W = B(W); g.W2 = B(W2); g.bias = B(bias); g.residual = B(residual);
+    g.y = B(y_bf16); g.y_f32 = y_f32; g.N = N; g.K = K; g.mode = mode;
+    return launch_gemv(g, S(stream));
+}
+extern "C" int vila_argmax_f32(const float* logits, int n, int64_t* out, void* workspace, vila_stream_t stream) {
+    float* tv = (float*)workspace;
+    int* ti = (int*)((char*)workspace + 2048);
+    return launch_argmax(logits, n, out, tv, ti, S(stream));
+}

@@ -1,0 +1,297 @@
+// Flash-attention forward for the two shapes on the path:
+//   SigLIP  (modeling_siglip.py:389-439 / :461-526): non-causal, 16 heads x hd 72, N = 1024 per tile
+//   Qwen2   (HF qwen2 attention; in-tree mirror fp8activationqwen2.py:992-1055): causal GQA, hd 128,
+//           varlen over cu_seqlens (packing.py:12-21 semantics: block-diagonal causal per sample)
+//
+// Layout trick (wave64 / v_mfma_f32_16x16x32_bf16): everything is computed TRANSPOSED so that no operand ever has
+// to move between lanes:
+//   S^T[key][q] = K . Q^T      A = K tile from LDS (row-major [key][d]),  B = Q fragments straight from HBM
+//   O^T[d][q]  = V^T . P^T     A = V^T tile from LDS ([d][key], transposed while staging), B = P^T = the lane's own
+//                              S^T accumulator registers (C layout of step 1 == B layout of step 2 under the k-slot
+//                              permutation key(lg,j) = 16*(2ks + j/4) + 4*lg + j%4, applied to V^T reads as well)
+// so the softmax statistics (per q = lane&15) and the O^T accumulator columns live in the same lane.
+// Block = 4 waves x 32 query rows; KV tile = 64 keys, double-buffered in LDS, one barrier per tile.
+#include "kernels.h"
+
+#define NEG_BIG (-1.0e30f)
+
+template <int HD, int QF, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int KK = (HD + 31) / 32;      // 32-wide contraction chunks for QK^T
+    constexpr int HDP = KK * 32;
+    constexpr int DN = (HD + 15) / 16;      // 16-row output fragments of O^T
+    constexpr int CH = HD / 8;              // 16-B chunks per K/V row
+    constexpr int KSTR = HDP + 8;           // sK row stride (elements): +16 B pad => conflict-free ds_read_b128
+    constexpr int VSTR = 72;                // sVt row stride (elements): 64 keys + 16 B pad
+    constexpr int KT = 64;
+    constexpr int BQ = 4 * QF * 16;
+    constexpr int K_ITERS = (KT * CH + 255) / 256;
+    static_assert(HD % 8 == 0, "head dim must be a multiple of 8");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sK = (bf16_t*)smem;                       // [2][64][KSTR]
+    bf16_t* sV = sK + 2 * KT * KSTR;                  // [2][DN*16][VSTR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, seq = blockIdx.z;
+    const int kvh = h / (p.n_q_heads / p.n_kv_heads);
+    int tok0 = seq * p.max_seqlen, seqlen = p.max_seqlen;   // cu_seqlens == NULL: n_seq sequences of max_seqlen tokens
+    if (p.cu_seqlens != nullptr) { tok0 = p.cu_seqlens[seq]; seqlen = p.cu_seqlens[seq + 1] - tok0; }
+    const int qb0 = blockIdx.x * BQ;
+    if (qb0 >= seqlen) return;
+
+    // zero the pad columns/rows once (they are never overwritten): K cols [HD,HDP), V^T rows [HD, DN*16)
+    if constexpr (HDP > HD) {
+        for (int i = tid; i < 2 * KT * (HDP - HD); i += 256) {
+            const int row = i / (HDP - HD), c = i % (HDP - HD);
+            sK[row * KSTR + HD + c] = 0;
+        }
+    }
+    if constexpr (DN * 16 > HD) {
+        for (int b = 0; b < 2; ++b)
+            for (int i = tid; i < (DN * 16 - HD) * VSTR; i += 256) sV[b * DN * 16 * VSTR + HD * VSTR + i] = 0;
+    }
+
+    // ---- Q fragments (B operand of S^T): lane holds Q[q0 + qf*16 + l15][kk*32 + lg*8 .. +8] ----
+    const int qw0 = qb0 + wave * QF * 16;   // first query row of this wave (within the sequence)
+    bf16x8 qf_[QF][KK];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int qrow = qw0 + f * 16 + l15;
+        const bf16_t* qp = p.q + (int64_t)(tok0 + (qrow < seqlen ? qrow : seqlen - 1)) * p.q_tok_stride + h * p.q_head_stride;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int d = kk * 32 + lg * 8;
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (d < HD && qrow < seqlen) v = *(const u32x4*)(qp + d);
+            qf_[f][kk] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    f32x4 oacc[DN][QF];
+#pragma unroll
+    for (int dn = 0; dn < DN; ++dn)
+#pragma unroll
+        for (int f = 0; f < QF; ++f) oacc[dn][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) { m_run[f] = NEG_BIG; l_run[f] = 0.f; }
+
+    const float c = p.scale * 1.4426950408889634f;   // exp(x*scale) = exp2(x*c)
+    int kv_end = seqlen;
+    if (CAUSAL) { const int lim = qb0 + BQ; kv_end = lim < seqlen ? lim : seqlen; }
+    const int ntiles = (kv_end + KT - 1) / KT;
+
+    const bf16_t* kbase = p.k + (int64_t)tok0 * p.k_tok_stride + kvh * p.k_head_stride;
+    const bf16_t* vbase = p.v + (int64_t)tok0 * p.v_tok_stride + kvh * p.v_head_stride;
+
+    // staging registers
+    u32x4 rk[K_ITERS];
+    u32x4 rv[4];
+    const int v_dc = tid >> 4, v_kg = tid & 15;     // V: d-chunk, key group (4 keys)
+    auto gload = [&](int t) {
+        const int key0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {
+            const int cidx = tid + 256 * i;
+            const int key = cidx / CH, ch = cidx % CH;
+            rk[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (cidx < KT * CH && key0 + key < seqlen) rk[i] = *(const u32x4*)(kbase + (int64_t)(key0 + key) * p.k_tok_stride + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = key0 + v_kg * 4 + i;
+            rv[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (v_dc < CH && key < seqlen) rv[i] = *(const u32x4*)(vbase + (int64_t)key * p.v_tok_stride + v_dc * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+        bf16_t* dK = sK + buf * KT * KSTR;
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {
+            const int cidx = tid + 256 * i;
+            const int key = cidx / CH, ch = cidx % CH;
+            if (cidx < KT * CH) *(u32x4*)(dK + key * KSTR + ch * 8) = rk[i];
+        }
+        if (v_dc < CH) {
+            bf16_t* dV = sV + buf * DN * 16 * VSTR + (v_dc * 8) * VSTR + v_kg * 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int w = e >> 1;
+                u32x2 o;
+                if (e & 1) {
+                    o[0] = (rv[0][w] >> 16) | (rv[1][w] & 0xffff0000u);
+                    o[1] = (rv[2][w] >> 16) | (rv[3][w] & 0xffff0000u);
+                } else {
+                    o[0] = (rv[0][w] & 0xffffu) | (rv[1][w] << 16);
+                    o[1] = (rv[2][w] & 0xffffu) | (rv[3][w] << 16);
+                }
+                *(u32x2*)(dV + e * VSTR) = o;
+            }
+        }
+    };
+
+    gload(0);
+    __syncthreads();   // pad zero-fill complete before the first tile lands next to it
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const bf16_t* cK = sK + buf * KT * KSTR;
+        const bf16_t* cV = sV + buf * DN * 16 * VSTR;
+        const int key0 = t * KT;
+
+        // ---- S^T = K Q^T ----
+        f32x4 sacc[4][QF];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) sacc[jn][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const bf16x8 kf = *(const bf16x8*)(cK + (jn * 16 + l15) * KSTR + kk * 32 + lg * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    sacc[jn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf_[f][kk], sacc[jn][f], 0, 0, 0);
+            }
+        }
+
+        // ---- mask (sequence end / causal diagonal) ----
+        const bool need_mask = (key0 + KT > seqlen) || (CAUSAL && (key0 + KT - 1 > qw0));
+        if (need_mask) {
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                const int qpos = qw0 + f * 16 + l15;
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kpos = key0 + jn * 16 + lg * 4 + r;
+                        const bool ok = (kpos < seqlen) && (!CAUSAL || kpos <= qpos);
+                        if (!ok) sacc[jn][f][r] = NEG_BIG;
+                    }
+            }
+        }
+
+        // ---- online softmax (per q = lane&15; reduce over own 16 keys, then over the 4 lane groups) ----
+        bf16x8 pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mx = sacc[0][f][0];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[jn][f][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[f], mx);
+            const float alpha = exp2f((m_run[f] - m_new) * c);
+            const float mc = m_new * c;
+            m_run[f] = m_new;
+            float ps = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sacc[jn][f][r] * c - mc);
+                    pv[jn][r] = e;
+                    ps += e;
+                }
+            l_run[f] = l_run[f] * alpha + ps;
+#pragma unroll
+            for (int dn = 0; dn < DN; ++dn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dn][f][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 w;
+                w[0] = pack2bf(pv[2 * ks][0], pv[2 * ks][1]);
+                w[1] = pack2bf(pv[2 * ks][2], pv[2 * ks][3]);
+                w[2] = pack2bf(pv[2 * ks + 1][0], pv[2 * ks + 1][1]);
+                w[3] = pack2bf(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
+                pf[f][ks] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int dn = 0; dn < DN; ++dn) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16_t* vp = cV + (dn * 16 + l15) * VSTR + ks * 32 + lg * 4;
+                const u32x2 lo = *(const u32x2*)(vp);
+                const u32x2 hi = *(const u32x2*)(vp + 16);
+                const u32x4 w = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    oacc[dn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][ks], oacc[dn][f], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[q][d]; lane: q = l15, d = dn*16 + lg*4 + r ----
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int qrow = qw0 + f * 16 + l15;
+        if (qrow < seqlen) {
+            bf16_t* op = p.o + (int64_t)(tok0 + qrow) * p.o_tok_stride + h * p.o_head_stride;
+#pragma unroll
+            for (int dn = 0; dn < DN; ++dn) {
+                const int d = dn * 16 + lg * 4;
+                if (d < HD) {
+                    u32x2 o;
+                    o[0] = pack2bf(oacc[dn][f][0] * inv, oacc[dn][f][1] * inv);
+                    o[1] = pack2bf(oacc[dn][f][2] * inv, oacc[dn][f][3] * inv);
+                    *(u32x2*)(op + d) = o;
+                }
+            }
+            if (p.lse != nullptr && lg == 0)
+                p.lse[(int64_t)h * p.total_tokens + tok0 + qrow] = m_run[f] * p.scale + logf(l);
+        }
+    }
+}
+
+template <int HD, bool CAUSAL>
+static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    constexpr int QF = 2;
+    constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
+    const size_t lds = (size_t)2 * 64 * (HDP + 8) * 2 + (size_t)2 * DN * 16 * 72 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VILA_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, QF, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.max_seqlen, 4 * QF * 16), a.n_q_heads, a.n_seq);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, QF, CAUSAL>), grid, dim3(256), lds, s, a);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
+    VILA_REQUIRE(a.n_seq >= 1 && a.total_tokens >= 1 && a.max_seqlen >= 1, "attn: empty input");
+    VILA_REQUIRE(a.cu_seqlens != nullptr || (int64_t)a.n_seq * a.max_seqlen == a.total_tokens,
+                 "attn: without cu_seqlens total_tokens (%d) must equal n_seq*max_seqlen (%d*%d)", a.total_tokens, a.n_seq, a.max_seqlen);
+    VILA_REQUIRE(a.n_q_heads % a.n_kv_heads == 0, "attn: q heads (%d) must be a multiple of kv heads (%d)", a.n_q_heads, a.n_kv_heads);
+    VILA_REQUIRE(a.q_tok_stride % 8 == 0 && a.k_tok_stride % 8 == 0 && a.v_tok_stride % 8 == 0 && a.o_tok_stride % 4 == 0 &&
+                 a.q_head_stride % 8 == 0 && a.k_head_stride % 8 == 0 && a.v_head_stride % 8 == 0 && a.o_head_stride % 4 == 0,
+                 "attn: strides must keep 16-B (q,k,v) / 8-B (o) alignment");
+    VILA_REQUIRE((uintptr_t)a.q % 16 == 0 && (uintptr_t)a.k % 16 == 0 && (uintptr_t)a.v % 16 == 0 && (uintptr_t)a.o % 8 == 0, "attn: pointer alignment");
+    if (a.head_dim == 128) return a.causal ? launch_attn_t<128, true>(a, s) : launch_attn_t<128, false>(a, s);
+    if (a.head_dim == 72) return a.causal ? launch_attn_t<72, true>(a, s) : launch_attn_t<72, false>(a, s);
+    if (a.head_dim == 64) return a.causal ? launch_attn_t<64, true>(a, s) : launch_attn_t<64, false>(a, s);
+    VILA_FAIL(-1, "attn: unsupported head_dim %d (supported: 64, 72, 128)", a.head_dim);
+}

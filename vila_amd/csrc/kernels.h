@@ -1,0 +1,82 @@
+// Internal launcher declarations shared by the translation units of libvila_hip.so.
+#pragma once
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_GATEUP = 3 };
+
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]);  bf16 in, fp32 accumulate, bf16 (or fp32) out.
+// EPI_GATEUP: C[M,N] = silu(A.W^T) * (A.W2^T)   (N = intermediate size)
+struct GemmArgs {
+    const bf16_t* A = nullptr; int64_t lda = 0;
+    const bf16_t* W = nullptr; int64_t ldw = 0;
+    const bf16_t* W2 = nullptr;
+    const bf16_t* bias = nullptr;
+    const bf16_t* residual = nullptr; int64_t ldr = 0;
+    void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
+    int M = 0, N = 0, K = 0; int epi = EPI_NONE;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- normalisation / elementwise (elementwise.hip) ----
+int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int cols, float eps, hipStream_t s);
+int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t s);
+// im2col for Conv2d(k=s=P, valid): pixels [B,C,H,W] bf16 -> patches [B*gh*gw, Kp] (K = C*P*P zero-padded to Kp)
+int launch_im2col(const bf16_t* px, bf16_t* out, int B, int C, int H, int W, int P, int Kp, hipStream_t s);
+int launch_pad_rows(const bf16_t* in, bf16_t* out, int rows, int K, int Kp, hipStream_t s);
+int launch_add_pos(bf16_t* x, const bf16_t* pos, int B, int N, int D, hipStream_t s);
+// space-to-depth (flat_square k x k with zero padding) : x [B, g*g, C] -> y [B, gd*gd, k*k*C]
+int launch_space_to_depth(const bf16_t* x, bf16_t* y, int B, int g, int C, int k, hipStream_t s);
+// rope table: positions [S] i32 -> cos/sin [S][hd/2] stored as bf16-rounded fp32 (HF casts cos/sin to the act dtype)
+int launch_rope_table(const int32_t* pos, float* cs, float* sn, int S, int hd, float theta, hipStream_t s);
+// applies bias-added q,k RoPE in place on the fused qkv buffer [S][q+2kv] and scatters k,v into the cache
+int launch_rope_kv(bf16_t* qkv, const float* cs, const float* sn, const int32_t* pos, const int32_t* seq_of_tok,
+                   bf16_t* kcache, bf16_t* vcache, int S, int nq, int nkv, int hd, int max_ctx, hipStream_t s);
+int launch_embed_gather(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int H, int64_t vocab, hipStream_t s);
+int launch_copy_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_row, const int32_t* dst_row, int n, int H, hipStream_t s);
+int launch_argmax(const float* logits, int V, int64_t* out, float* tmpv, int* tmpi, hipStream_t s);
+
+// ---- attention (attn.hip) ----
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    int64_t q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride;   // elements between consecutive tokens
+    int q_head_stride, k_head_stride, v_head_stride, o_head_stride;  // elements between heads
+    const int32_t* cu_seqlens;   // [n_seq+1] device, or null => one sequence of total_tokens
+    int n_seq, total_tokens, max_seqlen;
+    int n_q_heads, n_kv_heads, head_dim;
+    int causal; float scale;
+    float* lse;                  // optional [n_q_heads][total_tokens] fp32 (natural-log LSE) for backward
+};
+int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
+
+// ---- decode (gemv.hip) ----
+struct GemvArgs {
+    const bf16_t* x;          // [K] activations (bf16)
+    const bf16_t* norm_w;     // optional RMSNorm gain fused in front (null = none)
+    float eps;
+    const bf16_t* W;          // [N][K]
+    const bf16_t* W2;         // gate/up mode: up rows
+    const bf16_t* bias;       // [N] optional
+    const bf16_t* residual;   // [N] optional, added after
+    bf16_t* y;                // [N] bf16 out (or null)
+    float* y_f32;             // [N] fp32 out (logits) (or null)
+    int N, K; int mode;       // 0 plain, 1 gate/up silu-mul
+};
+int launch_gemv(const GemvArgs& a, hipStream_t s);
+struct QkvDecodeArgs {
+    const bf16_t* x; const bf16_t* norm_w; float eps;
+    const bf16_t* Wqkv; const bf16_t* bqkv;   // fused [q+2kv][K], [q+2kv]
+    bf16_t* q_out;                             // [nq*hd]
+    bf16_t* kcache; bf16_t* vcache;            // this layer's [nkv][max_ctx][hd]
+    const int32_t* pos_ptr;                    // device scalar: position of the new token (= current context length)
+    int K, nq, nkv, hd, max_ctx; float theta;
+};
+int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s);
+struct AttnDecodeArgs {
+    const bf16_t* q; const bf16_t* kcache; const bf16_t* vcache; bf16_t* o;
+    float* part_o; float* part_ml;   // workspace: [n_splits][nq][hd], [n_splits][nq][2]
+    const int32_t* pos_ptr;          // context length BEFORE this token; keys 0..pos inclusive are attended
+    int nq, nkv, hd, max_ctx, n_splits; float scale;
+};
+int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int launch_embed_token(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, hipStream_t s);
+int launch_decode_advance(int32_t* pos, const int64_t* tok, int64_t* out_ids, int32_t* n_out, int max_out, hipStream_t s);

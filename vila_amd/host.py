@@ -1,0 +1,75 @@
+"""Host-side integer logic of the path (no GPU needed; covered by the `not gpu` tests):
+
+  * `splice_plan`  — the index arithmetic behind `_embed` + `__batchify_sequence`
+                     (llava/model/llava_arch.py:412-490, 528-555) as row maps for the gather kernels
+  * `repack`       — `repack_multimodal_data`, non-SP branch (llava_arch.py:744-800) + `_get_unpad_data`
+                     (llava/model/utils/packing.py:12-21): packed row, restarted positions, cu_seqlens
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from .configs import IGNORE_INDEX
+
+
+def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], labels: Optional[torch.Tensor],
+                media_lens: List[int], image_token_id: int, padding_side: str = "right") -> SimpleNamespace:
+    """Row maps for `out[B*S, H]`: text rows come from the embedding table (`txt_src` = token ids -> `txt_dst`), media rows
+    from the concatenated media embeddings (row i -> `img_dst[i]`).  Vectorised: no per-token `.item()`."""
+    ids = input_ids
+    B, L = ids.shape
+    mask = attention_mask.bool() if attention_mask is not None else torch.ones_like(ids, dtype=torch.bool)
+    labels = labels if labels is not None else torch.full_like(ids, IGNORE_INDEX)
+    n_img = len(media_lens)
+    is_img = (ids == image_token_id) & mask
+    n_tok_img = int(is_img.sum())
+    if n_tok_img < n_img:
+        raise ValueError("Not all image embeddings are consumed!")                    # llava_arch.py:481-484
+    if n_tok_img > n_img:
+        raise IndexError("pop from an empty deque")                                   # media_embeds[name].popleft() on exhausted media
+    lens_img = torch.tensor(media_lens, dtype=torch.long, device=ids.device)
+    order = torch.cumsum(is_img.reshape(-1).long(), 0).reshape(B, L) - 1              # j-th image, sample-major = deque order
+    one = torch.ones_like(ids)
+    lens = torch.where(is_img, lens_img[order.clamp(min=0)] if n_img else one, one) * mask.long()
+    ends = torch.cumsum(lens, 1)
+    starts = ends - lens
+    S_k = ends[:, -1]
+    S = int(S_k.max()) if B > 0 else 0
+    right = padding_side == "right"
+    base = torch.arange(B, device=ids.device)[:, None] * S + (0 if right else (S - S_k)[:, None])
+    dst = base + starts
+    is_txt = mask & ~is_img
+    txt_src = ids[is_txt].to(torch.int32)
+    txt_dst = dst[is_txt].to(torch.int32)
+    out_labels = torch.full((B * S,), IGNORE_INDEX, dtype=labels.dtype, device=ids.device)
+    out_labels[txt_dst.long()] = labels[is_txt]
+    span = torch.arange(S, device=ids.device)[None, :]
+    out_mask = (span < S_k[:, None]) if right else (span >= (S - S_k)[:, None])
+    if n_img:
+        offs = torch.cat([torch.arange(n, device=ids.device) for n in media_lens])
+        img_dst = (torch.repeat_interleave(dst[is_img], lens_img) + offs).to(torch.int32)
+    else:
+        img_dst = torch.zeros(0, dtype=torch.int32, device=ids.device)
+    return SimpleNamespace(B=B, S=S, seqlens=S_k, txt_src=txt_src, txt_dst=txt_dst, img_dst=img_dst,
+                           labels=out_labels.view(B, S), mask=out_mask)
+
+
+def repack(attention_mask: torch.Tensor, labels: torch.Tensor) -> SimpleNamespace:
+    """Packed-row plan: `rows` (flat indices into [B*S] of the kept tokens), restarted `position_ids`, `labels` with the first
+    label of every sample masked (:760-762), `cu_seqlens`.  The reference appends one dummy token with mask 0 purely to force
+    HF's unpad path (:754-758); `_get_unpad_data` drops it again, so it never reaches the kernels and is not materialised."""
+    mask = attention_mask.bool()
+    B, S = mask.shape
+    seqlens = mask.sum(1).to(torch.int32)
+    rows = torch.nonzero(mask.reshape(-1), as_tuple=False).flatten()
+    cu = torch.zeros(B + 1, dtype=torch.int32, device=mask.device)
+    cu[1:] = torch.cumsum(seqlens, 0)
+    seq_id = torch.repeat_interleave(torch.arange(B, device=mask.device), seqlens.long())
+    pos = (torch.arange(rows.numel(), device=mask.device) - cu[:-1].long()[seq_id]).to(torch.int32)
+    lab = labels.reshape(-1)[rows].clone()
+    lab[cu[:-1].long()[seqlens > 0]] = IGNORE_INDEX
+    return SimpleNamespace(rows=rows, position_ids=pos, labels=lab, cu_seqlens=cu, seqlens=seqlens,
+                           max_seqlen=int(seqlens.max()) if B else 0, seq_of_tok=seq_id.to(torch.int32))

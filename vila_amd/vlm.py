@@ -1,0 +1,166 @@
+"""The VLM glue of the reference re-stated over the HIP modules: `LlavaLlamaModel` / `LlavaMetaForCausalLM`
+(llava/model/language_model/llava_llama.py:41-159, llava/model/llava_arch.py:51-95,366-394,412-555,744-833) and
+`BasicImageEncoder` (llava/model/encoders/image/basic.py:11-79).
+
+Differences that are deliberate: the splice of `_embed` is index arithmetic + two row-gather kernels
+instead of a python loop with `.item()` per token; greedy generation never leaves the device between tokens.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .configs import IGNORE_INDEX, VilaConfig
+from .host import splice_plan
+from .modules import HipMultimodalProjector, HipQwen2ForCausalLM, HipSiglipVisionTower
+
+
+class BasicImageEncoder(nn.Module):
+    """encoders/image/basic.py:11-79: stack -> parent.encode_images -> append embed(tokenizer(end_tokens))."""
+
+    def __init__(self, parent: "HipLlavaLlamaModel", start_tokens: Optional[str] = None, end_tokens: Optional[str] = "\n"):
+        super().__init__()
+        object.__setattr__(self, "_parent", parent)
+        self.start_tokens, self.end_tokens = start_tokens, end_tokens
+
+    @property
+    def parent(self):
+        return self._parent
+
+    def embed_tokens(self, tokens: Optional[str]) -> Optional[torch.Tensor]:
+        if tokens is None:
+            return None
+        ids = self.parent.tokenizer(tokens).input_ids
+        return self.parent.llm.embed_tokens(torch.tensor(ids, device=self.parent.device))
+
+    def forward(self, images: List[torch.Tensor], config: Dict[str, Any]) -> List[torch.Tensor]:
+        images = torch.stack(list(images), dim=0)
+        feats = self.parent.encode_images(images, block_sizes=config.get("block_sizes") if config else None)
+        start, end = self.embed_tokens(self.start_tokens), self.embed_tokens(self.end_tokens)
+        out = []
+        for f in feats:
+            parts = ([start] if start is not None else []) + [f] + ([end] if end is not None else [])
+            out.append(torch.cat(parts, 0) if len(parts) > 1 else f)
+        return out
+
+
+class _SyntheticTokenizer:
+    """Stands in for the HF tokenizer the reference attaches (`self.tokenizer`): only what the hot path touches —
+    `media_token_ids`, `tokenizer("\\n").input_ids`, `padding_side`, `model_max_length`."""
+
+    def __init__(self, cfg: VilaConfig, model_max_length: int = 8192):
+        self.media_token_ids = {"image": cfg.image_token_id}
+        self.padding_side = "right"
+        self.model_max_length = model_max_length
+        self.eos_token_id = cfg.llm.eos_token_id
+        self._nl = cfg.newline_token_id
+
+    def __call__(self, text: str):
+        if text != "\n":
+            raise NotImplementedError("synthetic tokenizer only knows the image end token \"\\n\"")
+        return SimpleNamespace(input_ids=[self._nl])
+
+
+class HipLlavaLlamaModel(nn.Module):
+    """Drop-in for `LlavaLlamaModel`: same attribute names (llm, vision_tower, mm_projector, encoders, tokenizer) and the
+    same `encode_images` / `_embed` / `forward` / `generate` contracts."""
+
+    def __init__(self, cfg: VilaConfig, device="cuda", dtype=torch.bfloat16, tokenizer=None):
+        super().__init__()
+        self.cfg = cfg
+        self.llm = HipQwen2ForCausalLM(cfg, device, dtype)
+        self.vision_tower = HipSiglipVisionTower(cfg, device, dtype)
+        self.mm_projector = HipMultimodalProjector(cfg, device, dtype)
+        self.tokenizer = tokenizer if tokenizer is not None else _SyntheticTokenizer(cfg)
+        self.encoders = {"image": BasicImageEncoder(self)}
+        self.training = False
+
+    @property
+    def device(self):
+        return self.llm.device
+
+    @property
+    def dtype(self):
+        return self.llm.dtype
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_mm_projector(self):
+        return self.mm_projector
+
+    def load_weights(self, w: Dict[str, torch.Tensor]) -> None:
+        self.llm.load_weights(w, "llm.")
+        self.vision_tower.load_weights(w, "vision_tower.")
+        self.mm_projector.load_weights(w, "mm_projector.")
+
+    # llava_arch.py:366-394 (plain branch; dynamic_s2 is SURVEY §8f "next")
+    def encode_images(self, images: torch.Tensor, block_sizes=None) -> torch.Tensor:
+        if getattr(self.cfg, "dynamic_s2", False):
+            raise NotImplementedError("dynamic_s2 is not implemented (SURVEY.md §8f item 1)")
+        return self.get_mm_projector()(self.get_vision_tower()(images))
+
+    # llava_arch.py:412-490 + 528-555
+    def _embed(self, input_ids: torch.Tensor, media: Dict[str, List[torch.Tensor]], media_config: Optional[Dict[str, Dict[str, Any]]] = None,
+               labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None):
+        dev = self.device
+        media_config = media_config or {}
+        labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
+        attention_mask = attention_mask if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
+        attention_mask = attention_mask.bool()
+        images = list(media.get("image", [])) if media else []
+        media_embeds = self.encoders["image"](images, media_config.get("image", {})) if images else []
+        n_img = len(media_embeds)
+        img_id = self.tokenizer.media_token_ids["image"]
+        B, L = input_ids.shape
+        H = self.cfg.llm.hidden_size
+
+        # ---- integer work on the ids (wherever they live); no per-token sync: vila_amd.host.splice_plan ----
+        plan = splice_plan(input_ids, attention_mask, labels, [int(m.shape[0]) for m in media_embeds], img_id,
+                           getattr(self.tokenizer, "padding_side", "right"))
+        S = plan.S
+        out = torch.zeros((B * S, H), device=dev, dtype=self.dtype)
+        table = self.llm.model.embed_tokens.weight
+        ops.copy_rows(table, out, plan.txt_src.to(dev), plan.txt_dst.to(dev), int(plan.txt_src.numel()))
+        if n_img:
+            flat = torch.cat(media_embeds, 0).to(self.dtype)
+            ops.copy_rows(flat, out, None, plan.img_dst.to(dev), int(plan.img_dst.numel()))
+        return out.view(B, S, H), plan.labels.to(dev), plan.mask.to(dev)
+
+    # llava_llama.py:94-159 (inference/eval form: loss without autograd; SFT fwd+bwd lives in vila_amd.train)
+    @torch.no_grad()
+    def forward(self, input_ids=None, media=None, media_config=None, attention_mask=None, labels=None, packing: bool = True,
+                inputs_embeds=None, num_items_in_batch=None, **kw):
+        if inputs_embeds is None:
+            inputs_embeds, labels, attention_mask = self._embed(input_ids, media, media_config, labels, attention_mask)
+        return self.llm(inputs_embeds=inputs_embeds, attention_mask=attention_mask, labels=labels, num_items_in_batch=num_items_in_batch)
+
+    # llava_arch.py:823-833
+    @torch.inference_mode()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, media: Optional[Dict[str, List[torch.Tensor]]] = None,
+                 media_config: Optional[Dict[str, Dict[str, Any]]] = None, attention_mask: Optional[torch.Tensor] = None,
+                 **generation_kwargs):
+        inputs_embeds, _, attention_mask = self._embed(input_ids, media, media_config, None, attention_mask)
+        return self.llm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, **generation_kwargs)
+
+
+def build_model(cfg: VilaConfig, weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, device="cuda",
+                dtype=torch.bfloat16) -> HipLlavaLlamaModel:
+    """Construct the VLM and fill it with `weights` (reference state_dict names) or seeded synthetic weights drawn
+    directly on `device` (no checkpoints exist offline)."""
+    from . import synthetic
+    m = HipLlavaLlamaModel(cfg, device, dtype)
+    if weights is not None:
+        m.load_weights(weights)
+    else:
+        with torch.no_grad():
+            for mod, prefix, specs in ((m.llm, "llm.", synthetic.llm_specs(cfg)), (m.vision_tower, "vision_tower.", synthetic.vision_specs(cfg)),
+                                       (m.mm_projector, "mm_projector.", synthetic.projector_specs(cfg))):
+                params = dict(mod.named_parameters())
+                for name, shape, kind in specs:
+                    params[name[len(prefix):]].copy_(synthetic._draw(name, shape, kind, cfg, seed, device))
+    return m
