@@ -102,6 +102,9 @@ def load(build_if_missing: bool = False) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; ours must bind to THAT runtime instance (same SONAME: first loaded wins),
+    # otherwise streams/pointers created by torch are foreign to the runtime our kernels are launched through.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         if build_if_missing:
             from . import build as _b
