@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-decode", action="store_true", help="experiment: launch the 171 kernels per token eagerly instead of replaying a hipGraph")
     ap.add_argument("--config", default="nvila_8b", choices=["nvila_8b", "reduced"])
     return ap.parse_args()
 
@@ -141,8 +142,13 @@ def main():
         llm.decode_step(cache, st)
         g = C.c_void_p()
         _lib.check(lib.vila_graph_end(stream.cuda_stream, C.byref(g)), "graph_end")
+        def one_step():
+            if a.eager_decode:
+                llm.decode_step(cache, st)
+            else:
+                _lib.check(lib.vila_graph_launch(g, stream.cuda_stream), "graph_launch")
         for _ in range(a.warmup):
-            _lib.check(lib.vila_graph_launch(g, stream.cuda_stream), "graph_launch")
+            one_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -152,7 +158,7 @@ def main():
     with torch.cuda.stream(stream):
         ev0.record(stream)
         for _ in range(a.steps):
-            _lib.check(lib.vila_graph_launch(g, stream.cuda_stream), "graph_launch")
+            one_step()
         ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -269,7 +269,8 @@ extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max
     size_t b = 0;
     b += 2 * align_up(H * 2, 256) + 2 * align_up(QS * 2, 256) + align_up(F * 2, 256);
     b += align_up(ns * QS * 4, 256) + align_up(ns * s->q_heads * 2 * 4, 256);
-    b += 2 * align_up(256 * 4, 256);
+    b += 2 * align_up(256 * 4, 256) + align_up((size_t)s->head_dim * 4, 256);
+    b += align_up(QS * 2, 256);
     return b + 4096;
 }
 
@@ -285,15 +286,16 @@ extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* 
     bf16_t* x = a.take<bf16_t>(H);
     bf16_t* x2 = a.take<bf16_t>(H);
     bf16_t* q = a.take<bf16_t>(QS);
-    bf16_t* ao = a.take<bf16_t>(QS);
     bf16_t* act = a.take<bf16_t>(F);
     float* part_o = a.take<float>((size_t)ns * QS);
     float* part_ml = a.take<float>((size_t)ns * sh.q_heads * 2);
     float* tv = a.take<float>(256);
     int* ti = a.take<int>(256);
+    float* rope_cs = a.take<float>(hd);
+    bf16_t* ao = a.take<bf16_t>(QS);
     VILA_REQUIRE(a.ok(), "llm_decode: workspace arena overflow");
 
-    VILA_TRY(launch_embed_token(B(w->embed), st->token, x, H, sh.vocab, s));
+    VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
     bf16_t* cur = x; bf16_t* nxt = x2;
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];
@@ -305,7 +307,7 @@ extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* 
         QkvDecodeArgs qa{};
         qa.x = cur; qa.norm_w = B(L.ln1_w); qa.eps = sh.rms_eps; qa.Wqkv = B(L.wq); qa.bqkv = B(L.bq); qa.q_out = q;
         qa.kcache = kc; qa.vcache = vc; qa.pos_ptr = st->pos; qa.K = H; qa.nq = sh.q_heads; qa.nkv = sh.kv_heads; qa.hd = hd;
-        qa.max_ctx = cache->max_ctx; qa.theta = sh.rope_theta;
+        qa.max_ctx = cache->max_ctx; qa.rope_cs = rope_cs;
         VILA_TRY(launch_qkv_decode(qa, s));
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;

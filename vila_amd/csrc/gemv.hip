@@ -5,7 +5,15 @@
 // (bias, RoPE, KV-cache write, SiLU*up, residual add) are fused so a decoder layer is 6 launches.
 #include "kernels.h"
 
-#define GEMV_U 4
+#define DEC_KS 64      // keys per split of the decode attention
+#define DEC_MAXG 8     // max query heads per kv head
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ unsigned long long pack_f2(float a, float b) {
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
+__device__ __forceinline__ float lo_f2(unsigned long long v) { return __uint_as_float((uint32_t)v); }
+__device__ __forceinline__ float hi_f2(unsigned long long v) { return __uint_as_float((uint32_t)(v >> 32)); }
 
 __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 
@@ -18,7 +26,9 @@ __device__ __forceinline__ float dot8(const u32x4 w, const u32x4 x, float acc) {
     return acc;
 }
 
-// stage x (optionally RMS-normalised with gain) as bf16 into LDS; all 256 threads participate
+// ---- activation staging -------------------------------------------------------------------------
+// stage x (optionally RMS-normalised with gain, HF rounding order) as bf16 into LDS; all 256 threads participate.
+// Single pass for K <= 8192 (x kept in registers between the sum of squares and the scaling).
 __device__ __forceinline__ void stage_x(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, float eps, int K,
                                         bf16_t* sx, float* scratch) {
     const int tid = threadIdx.x, nch = K >> 3;
@@ -27,87 +37,160 @@ __device__ __forceinline__ void stage_x(const bf16_t* __restrict__ x, const bf16
         __syncthreads();
         return;
     }
+    constexpr int MAXC = 4;
+    const bool small = nch <= 256 * MAXC;
+    u32x4 v[MAXC];
     float s = 0.f;
-    for (int c = tid; c < nch; c += 256) {
-        const u32x4 v = *(const u32x4*)(x + c * 8);
+    if (small) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const float a = lo_bf(v[k]), b = hi_bf(v[k]); s += a * a + b * b; }
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = tid + 256 * i;
+            v[i] = (c < nch) ? *(const u32x4*)(x + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float a = lo_bf(v[i][k]), b = hi_bf(v[i][k]); s += a * a + b * b; }
+        }
+    } else {
+        for (int c = tid; c < nch; c += 256) {
+            const u32x4 t = *(const u32x4*)(x + c * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float a = lo_bf(t[k]), b = hi_bf(t[k]); s += a * a + b * b; }
+        }
     }
     s = wave_sum(s);
     if ((tid & 63) == 0) scratch[tid >> 6] = s;
     __syncthreads();
     const float rstd = rsqrtf((scratch[0] + scratch[1] + scratch[2] + scratch[3]) / K + eps);
-    for (int c = tid; c < nch; c += 256) {
-        const u32x4 v = *(const u32x4*)(x + c * 8);
-        const u32x4 g = *(const u32x4*)(norm_w + c * 8);
-        u32x4 o;
+    if (small) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(v[k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(v[k]) * rstd));
-        *(u32x4*)(sx + c * 8) = o;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nch) {
+                const u32x4 g = *(const u32x4*)(norm_w + c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(v[i][k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(v[i][k]) * rstd));
+                *(u32x4*)(sx + c * 8) = o;
+            }
+        }
+    } else {
+        for (int c = tid; c < nch; c += 256) {
+            const u32x4 t = *(const u32x4*)(x + c * 8);
+            const u32x4 g = *(const u32x4*)(norm_w + c * 8);
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(t[k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(t[k]) * rstd));
+            *(u32x4*)(sx + c * 8) = o;
+        }
     }
     __syncthreads();
 }
 
-// R rows x K dot products for one wave; rows given by pointers
-template <int R>
-__device__ __forceinline__ void wave_rows_dot(const bf16_t* const (&wrow)[R], const bf16_t* sx, int K, int lane, float (&acc)[R]) {
+// stage x = merged split-KV attention output (flash-decoding combine fused into the o_proj GEMV):
+//   o[h][d] = sum_s exp(m_s - M) part_o[s][h][d] / sum_s exp(m_s - M) l_s ,  rounded to bf16 like the reference's attn output
+__device__ __forceinline__ void stage_x_attn(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active,
+                                             int nq, bf16_t* sx, float* wsm /* [n_active*nq] */) {
+    const int tid = threadIdx.x;
+    for (int h = tid; h < nq; h += 256) {
+        float M = -INFINITY;
+        for (int s = 0; s < n_active; ++s) M = fmaxf(M, part_ml[((int64_t)s * nq + h) * 2]);
+        float L = 0.f;
+        for (int s = 0; s < n_active; ++s) {
+            const float* ml = part_ml + ((int64_t)s * nq + h) * 2;
+            L += __expf(ml[0] - M) * ml[1];
+        }
+        const float invL = 1.f / L;
+        for (int s = 0; s < n_active; ++s) wsm[s * nq + h] = __expf(part_ml[((int64_t)s * nq + h) * 2] - M) * invL;
+    }
+    __syncthreads();
+    const int n4 = nq * 32;   // float4 chunks
+    for (int i = tid; i < n4; i += 256) {
+        const int h = i >> 5;
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_active; ++s) {
+            const f32x4 pv = *(const f32x4*)(part_o + ((int64_t)s * nq) * 128 + i * 4);
+            const float w = wsm[s * nq + h];
+            o[0] = fmaf(w, pv[0], o[0]); o[1] = fmaf(w, pv[1], o[1]); o[2] = fmaf(w, pv[2], o[2]); o[3] = fmaf(w, pv[3], o[3]);
+        }
+        u32x2 r; r[0] = pack2bf(o[0], o[1]); r[1] = pack2bf(o[2], o[3]);
+        *(u32x2*)(sx + i * 4) = r;
+    }
+    __syncthreads();
+}
+
+// ---- weight streaming -----------------------------------------------------------------------------
+template <int R, int U> struct Batch { u32x4 v[U][R]; };
+
+template <int R, int U>
+__device__ __forceinline__ void load_batch(const bf16_t* const (&wrow)[R], int c0, int lane, int nch, Batch<R, U>& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) b.v[u][r] = (c < nch) ? ldg_nt(wrow[r] + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+template <int R, int U>
+__device__ __forceinline__ void fma_batch(const Batch<R, U>& b, const bf16_t* sx, int c0, int lane, int nch, float (&acc)[R]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 + lane;
+        const u32x4 xv = (c < nch) ? *(const u32x4*)(sx + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = dot8(b.v[u][r], xv, acc[r]);
+    }
+}
+// dot products of R rows with x (LDS) for chunks [c_start, nch); accumulates into acc, then reduces across the wave
+template <int R, int U>
+__device__ __forceinline__ void wave_rows_dot(const bf16_t* const (&wrow)[R], const bf16_t* sx, int K, int lane, float (&acc)[R], int c_start) {
     const int nch = K >> 3;
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    for (int c0 = 0; c0 < nch; c0 += 64 * GEMV_U) {
-        u32x4 wv[GEMV_U][R];
-#pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
-            const int c = c0 + u * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < R; ++r) wv[u][r] = (c < nch) ? ldg_nt(wrow[r] + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
-            const int c = c0 + u * 64 + lane;
-            const u32x4 xv = (c < nch) ? *(const u32x4*)(sx + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = dot8(wv[u][r], xv, acc[r]);
-        }
+    for (int c0 = c_start; c0 < nch; c0 += 64 * U) {
+        Batch<R, U> b;
+        load_batch<R, U>(wrow, c0, lane, nch, b);
+        fma_batch<R, U>(b, sx, c0, lane, nch, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// generic GEMV: y = W x (+bias) (+residual)   |   gate/up: y = silu(Wg x) * (Wu x)
+// generic GEMV: y = W x (+bias) (+residual)   |   gate/up: y = silu(Wg x) * (Wu x)   |   x from attention partials
+// The first weight batch of every wave is issued BEFORE the activation is staged, so the HBM latency of the first
+// loads overlaps the norm / merge prologue.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// U = 16-B loads in flight per row and lane: 7 covers a whole K = 3584 row in ONE round trip (the short K=hidden GEMVs are
+// latency-bound), 4 is enough for the long rows (K = 18944) where many iterations pipeline anyway.
+template <int MODE, int U>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
-    stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
-        if (MODE == 1) {
-            // two (gate, up) pairs per wave iteration
-            const int n = g * 2;
-            const int n1 = (n + 1 < p.N) ? n + 1 : n;
-            const bf16_t* const rows[4] = {p.W + (int64_t)n * p.K, p.W2 + (int64_t)n * p.K, p.W + (int64_t)n1 * p.K, p.W2 + (int64_t)n1 * p.K};
-            float acc[4];
-            wave_rows_dot<4>(rows, sx, p.K, lane, acc);
-            if (lane == 0) {
+    const int nch = p.K >> 3;
+    constexpr int R = (MODE == 1) ? 4 : 2;
+    const int stride = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wave;
+
+    auto rows_of = [&](int gg, const bf16_t* (&rows)[R]) {
+        const int n = gg * 2;
+        const int n1 = (n + 1 < p.N) ? n + 1 : n;
+        if constexpr (MODE == 1) {
+            rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W2 + (int64_t)n * p.K;
+            rows[2] = p.W + (int64_t)n1 * p.K; rows[3] = p.W2 + (int64_t)n1 * p.K;
+        } else {
+            rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
+        }
+    };
+    auto finish = [&](int gg, float (&acc)[R]) {
+        const int n = gg * 2;
+        if constexpr (MODE == 1) {
+            if (lane < 2 && n + lane < p.N) {
                 // HF: down(act(gate(x)) * up(x)) with every tensor rounded to bf16
-                const float g0 = bfround(acc[0]), u0 = bfround(acc[1]);
-                p.y[n] = f2bf(bfround(silu_f(g0)) * u0);
-                if (n + 1 < p.N) {
-                    const float g1 = bfround(acc[2]), u1 = bfround(acc[3]);
-                    p.y[n + 1] = f2bf(bfround(silu_f(g1)) * u1);
-                }
+                const float gv = bfround(lane == 0 ? acc[0] : acc[2]), uv = bfround(lane == 0 ? acc[1] : acc[3]);
+                p.y[n + lane] = f2bf(bfround(silu_f(gv)) * uv);
             }
         } else {
-            const int n = g * 2;
-            const int n1 = (n + 1 < p.N) ? n + 1 : n;
-            const bf16_t* const rows[2] = {p.W + (int64_t)n * p.K, p.W + (int64_t)n1 * p.K};
-            float acc[2];
-            wave_rows_dot<2>(rows, sx, p.K, lane, acc);
             if (lane < 2 && n + lane < p.N) {
                 const int nn = n + lane;
                 float v = lane == 0 ? acc[0] : acc[1];
@@ -119,21 +202,57 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
                 }
             }
         }
+    };
+
+    const bf16_t* rows[R];
+    Batch<R, U> b0;
+    const bool has = g < n_groups;
+    if (has) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
+    if constexpr (MODE == 2) {
+        const int n_active = (*p.pos_ptr + DEC_KS) / DEC_KS;     // ceil((pos+1)/KS)
+        stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+    } else {
+        stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+    }
+    if (has) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        fma_batch<R, U>(b0, sx, 0, lane, nch, acc);
+        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 64 * U);
+        finish(g, acc);
+        g += stride;
+    }
+    for (; g < n_groups; g += stride) {
+        rows_of(g, rows);
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 0);
+        finish(g, acc);
     }
 }
 
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
-    VILA_REQUIRE((uintptr_t)a.W % 16 == 0 && (uintptr_t)a.x % 16 == 0, "gemv: pointer alignment");
+    VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
     const int n_groups = cdiv(a.N, 2);
     int grid = cdiv(n_groups, 4);
     if (grid > 2048) grid = 2048;
-    const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
+    size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
+    const bool short_k = a.K <= 3584;
     if (a.mode == 1) {
-        VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr, "gemv: gate/up mode needs W2 and bf16 y");
-        hipLaunchKernelGGL(gemv_kernel<1>, dim3(grid), dim3(256), lds, s, a, n_groups);
+        VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr && (uintptr_t)a.x % 16 == 0, "gemv: gate/up mode needs W2, bf16 y, aligned x");
+        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
+    } else if (a.mode == 2) {
+        VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
+        lds += (size_t)a.n_splits * (a.K / 128) * 4;
+        if (grid > 256) grid = 256;     // the merge prologue is paid per block: keep ~1 block per CU
+        hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
     } else {
-        hipLaunchKernelGGL(gemv_kernel<0>, dim3(grid), dim3(256), lds, s, a, n_groups);
+        VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
     }
     VILA_LAUNCH_CHECK();
     return 0;
@@ -142,82 +261,102 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // fused RMSNorm + QKV projection + bias + RoPE + KV-cache append for one new token.
 // Group = 4 rows: q/k heads -> rows {d, d+1, d+hd/2, d+hd/2+1} of one head (the two rotate-half pairs),
-// v heads -> 4 consecutive rows.
+// v heads -> 4 consecutive rows.  cos/sin of the token's position come from the per-token table written by
+// decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
+template <int U>
 __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
-    stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = p.hd, half = hd >> 1;
     const int gph = hd >> 2;                                   // groups per head
     const int n_groups = (p.nq + 2 * p.nkv) * gph;
-    const int pos = *p.pos_ptr;
-    for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
-        const int head = g / gph, gi = g % gph;
-        const bool is_v = head >= p.nq + p.nkv;
-        int rows_i[4];
-        if (is_v) {
+    const int nch = p.K >> 3;
+    const int stride = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wave;
+
+    int rows_i[4];
+    const bf16_t* rows[4];
+    auto rows_of = [&](int gg) {
+        const int head = gg / gph, gi = gg % gph;
+        if (head >= p.nq + p.nkv) {
+#pragma unroll
             for (int r = 0; r < 4; ++r) rows_i[r] = head * hd + gi * 4 + r;
         } else {
             const int d = gi * 2;
             rows_i[0] = head * hd + d; rows_i[1] = head * hd + d + 1;
             rows_i[2] = head * hd + d + half; rows_i[3] = head * hd + d + half + 1;
         }
-        const bf16_t* const rows[4] = {p.Wqkv + (int64_t)rows_i[0] * p.K, p.Wqkv + (int64_t)rows_i[1] * p.K,
-                                       p.Wqkv + (int64_t)rows_i[2] * p.K, p.Wqkv + (int64_t)rows_i[3] * p.K};
-        float acc[4];
-        wave_rows_dot<4>(rows, sx, p.K, lane, acc);
-        if (lane == 0) {
-            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = bfround(acc[r] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[r]]) : 0.f));
-            if (!is_v) {
-                const int d = gi * 2;
+        for (int r = 0; r < 4; ++r) rows[r] = p.Wqkv + (int64_t)rows_i[r] * p.K;
+    };
+    auto finish = [&](int gg, float (&acc)[4]) {
+        if (lane >= 4) return;
+        const int head = gg / gph, gi = gg % gph;
+        const bool is_v = head >= p.nq + p.nkv;
+        const int pos = *p.pos_ptr;
+        float v[4];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float inv = 1.0f / powf(p.theta, (float)(2 * (d + e)) / (float)hd);
-                    const float ang = (float)pos * inv;
-                    const float c = bfround(cosf(ang)), sn = bfround(sinf(ang));
-                    const float lo = v[e], hi = v[2 + e];
-                    v[e] = bfround(bfround(lo * c) + bfround(-hi * sn));
-                    v[2 + e] = bfround(bfround(hi * c) + bfround(lo * sn));
-                }
-            }
-            if (head < p.nq) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p.q_out[rows_i[r]] = f2bf(v[r]);
-            } else if (pos < p.max_ctx) {
-                const int kvh = is_v ? head - p.nq - p.nkv : head - p.nq;
-                bf16_t* dst = (is_v ? p.vcache : p.kcache) + ((int64_t)kvh * p.max_ctx + pos) * hd;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[rows_i[r] - head * hd] = f2bf(v[r]);
-            }
+        for (int r = 0; r < 4; ++r) v[r] = bfround(acc[r] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[r]]) : 0.f));
+        float out = v[lane & 3];
+        if (!is_v) {
+            const int e = lane & 1, hi_half = lane >> 1, d = gi * 2 + e;
+            const float c = p.rope_cs[d], sn = p.rope_cs[half + d];
+            const float lo = v[e], hi = v[2 + e];
+            out = hi_half ? bfround(bfround(hi * c) + bfround(lo * sn)) : bfround(bfround(lo * c) + bfround(-hi * sn));
         }
+        const int row = rows_i[lane & 3];
+        if (head < p.nq) {
+            p.q_out[row] = f2bf(out);
+        } else if (pos < p.max_ctx) {
+            const int kvh = is_v ? head - p.nq - p.nkv : head - p.nq;
+            bf16_t* dst = (is_v ? p.vcache : p.kcache) + ((int64_t)kvh * p.max_ctx + pos) * hd;
+            dst[row - head * hd] = f2bf(out);
+        }
+    };
+
+    Batch<4, U> b0;
+    const bool has = g < n_groups;
+    if (has) { rows_of(g); load_batch<4, U>(rows, 0, lane, nch, b0); }
+    stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+    if (has) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        fma_batch<4, U>(b0, sx, 0, lane, nch, acc);
+        wave_rows_dot<4, U>(rows, sx, p.K, lane, acc, 64 * U);
+        finish(g, acc);
+        g += stride;
+    }
+    for (; g < n_groups; g += stride) {
+        rows_of(g);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        wave_rows_dot<4, U>(rows, sx, p.K, lane, acc, 0);
+        finish(g, acc);
     }
 }
 
 int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s) {
-    VILA_REQUIRE(a.K % 8 == 0 && a.hd % 4 == 0, "qkv_decode: K=%d hd=%d", a.K, a.hd);
+    VILA_REQUIRE(a.K % 8 == 0 && a.hd % 4 == 0 && a.rope_cs != nullptr, "qkv_decode: K=%d hd=%d", a.K, a.hd);
     const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 4);
     const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
-    hipLaunchKernelGGL(qkv_decode_kernel, dim3(cdiv(n_groups, 4)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(cdiv(n_groups, 4)), dim3(256), lds, s, a);   // U=7 measured slower (2 waves/SIMD)
     VILA_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// split-KV decode attention (q_len = 1, GQA): grid (n_splits, nkv); block handles G = nq/nkv query heads over
-// a 64-key slice of the cache, writes un-normalised partial O and (m, l); a second kernel merges the splits.
-// hd must be 128 (16 lanes x 8 elements per key row).
+// split-KV decode attention (q_len = 1, GQA, hd = 128): grid (n_splits, nkv); a block handles the G = nq/nkv query
+// heads of one kv head over a 64-key slice of the cache and writes the un-normalised partial O and (m, l).
+// The merge over splits is fused into the o_proj GEMV (gemv_kernel<2>).
+//   scores : thread = (key, quarter of d): 32 FMAs per head, 2 cross-lane adds
+//   P.V    : thread = (4 keys, 8-wide d chunk): 56 accumulators, reduced over the 16 key groups through LDS
 // ------------------------------------------------------------------------------------------------
-#define DEC_KS 64
-#define DEC_MAXG 8
 __global__ __launch_bounds__(256) void attn_decode_partial(AttnDecodeArgs p) {
-    __shared__ float sq[DEC_MAXG][128];
-    __shared__ float sc[DEC_MAXG][DEC_KS];
-    __shared__ float so[4][DEC_MAXG][128];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sq = (float*)smem;                       // [G][128]  (pre-scaled)
+    float* sc = sq + DEC_MAXG * 128;                // [G][64]
+    float* red = sc + DEC_MAXG * DEC_KS;            // [16][G][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x, kvh = blockIdx.y;
     const int G = p.nq / p.nkv;
@@ -228,78 +367,80 @@ __global__ __launch_bounds__(256) void attn_decode_partial(AttnDecodeArgs p) {
     const bf16_t* kb = p.kcache + ((int64_t)kvh * p.max_ctx + k0) * 128;
     const bf16_t* vb = p.vcache + ((int64_t)kvh * p.max_ctx + k0) * 128;
 
-    // issue all K and V loads up front: thread -> (key = tid/16 + 16 i, chunk = tid%16)
-    const int ch = tid & 15, kr = tid >> 4;
+    const int kq = tid >> 2, qd = tid & 3;          // scores: key, d quarter
+    const int vkg = tid >> 4, vch = tid & 15;       // P.V: key group (4 keys), d chunk
     u32x4 kv_[4], vv_[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int key = kr + 16 * i;
-        kv_[i] = (u32x4){0u, 0u, 0u, 0u}; vv_[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (key < kn) { kv_[i] = *(const u32x4*)(kb + key * 128 + ch * 8); vv_[i] = *(const u32x4*)(vb + key * 128 + ch * 8); }
+    for (int j = 0; j < 4; ++j) {
+        kv_[j] = (kq < kn) ? *(const u32x4*)(kb + kq * 128 + qd * 32 + j * 8) : (u32x4){0u, 0u, 0u, 0u};
+        const int key = vkg * 4 + j;
+        vv_[j] = (key < kn) ? *(const u32x4*)(vb + key * 128 + vch * 8) : (u32x4){0u, 0u, 0u, 0u};
     }
-    for (int i = tid; i < G * 128; i += 256) sq[i >> 7][i & 127] = bf2f(p.q[(kvh * G + (i >> 7)) * 128 + (i & 127)]);
+    for (int i = tid; i < G * 128; i += 256) sq[i] = bf2f(p.q[kvh * G * 128 + i]) * p.scale;
     __syncthreads();
 
-    // scores: 16 lanes cooperate on one key
+    for (int g = 0; g < G; ++g) {
+        float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int key = kr + 16 * i;
-        for (int g = 0; g < G; ++g) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a = fmaf(lo_bf(kv_[i][k]), sq[g][ch * 8 + 2 * k], a);
-                a = fmaf(hi_bf(kv_[i][k]), sq[g][ch * 8 + 2 * k + 1], a);
-            }
-            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
-            if (ch == 0) sc[g][key] = key < kn ? a * p.scale : -INFINITY;
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 q0 = *(const f32x4*)(sq + g * 128 + qd * 32 + j * 8);
+            const f32x4 q1 = *(const f32x4*)(sq + g * 128 + qd * 32 + j * 8 + 4);
+            a = fmaf(lo_bf(kv_[j][0]), q0[0], a); a = fmaf(hi_bf(kv_[j][0]), q0[1], a);
+            a = fmaf(lo_bf(kv_[j][1]), q0[2], a); a = fmaf(hi_bf(kv_[j][1]), q0[3], a);
+            a = fmaf(lo_bf(kv_[j][2]), q1[0], a); a = fmaf(hi_bf(kv_[j][2]), q1[1], a);
+            a = fmaf(lo_bf(kv_[j][3]), q1[2], a); a = fmaf(hi_bf(kv_[j][3]), q1[3], a);
         }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (qd == 0) sc[g * DEC_KS + kq] = kq < kn ? a : -INFINITY;
     }
     __syncthreads();
 
-    // softmax statistics per head: wave w handles heads w, w+4; lane = key
-    for (int g = wave; g < G; g += 4) {
-        const float s = sc[g][lane];
+    for (int g = wave; g < G; g += 4) {             // softmax statistics: one wave per head, lane = key
+        const float s = sc[g * DEC_KS + lane];
         const float m = wave_max(s);
         const float e = __expf(s - m);
         const float l = wave_sum(e);
-        sc[g][lane] = e;
+        sc[g * DEC_KS + lane] = e;
         if (lane == 0) {
-            float* ml = p.part_ml + ((int64_t)split * p.nq + kvh * G + g) * 2;
-            ml[0] = m; ml[1] = l;
+            // (m, l) as ONE 8-byte write-through (sc1) store: the combine below reads it with sc1 loads, no fences needed
+            gu64* ml = (gu64*)(p.part_ml + ((int64_t)split * p.nq + kvh * G + g) * 2);
+            __hip_atomic_store(ml, pack_f2(m, l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
 
-    // partial O: thread accumulates its 4 keys x 8 d for every head, then reduce over the 16 key rows
     for (int g = 0; g < G; ++g) {
         float o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float pr = sc[g][kr + 16 * i];
+        for (int j = 0; j < 4; ++j) {
+            const float pr = sc[g * DEC_KS + vkg * 4 + j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[2 * k] = fmaf(pr, lo_bf(vv_[i][k]), o[2 * k]);
-                o[2 * k + 1] = fmaf(pr, hi_bf(vv_[i][k]), o[2 * k + 1]);
+                o[2 * k] = fmaf(pr, lo_bf(vv_[j][k]), o[2 * k]);
+                o[2 * k + 1] = fmaf(pr, hi_bf(vv_[j][k]), o[2 * k + 1]);
             }
         }
-        // lanes with equal ch inside a wave differ in kr by 1,2,3 -> xor 16, 32
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { o[k] += __shfl_xor(o[k], 16, 64); o[k] += __shfl_xor(o[k], 32, 64); }
-        if (lane < 16) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) so[wave][g][ch * 8 + k] = o[k];
-        }
+        float* r = red + ((vkg * G + g) * 128 + vch * 8);
+        *(f32x4*)r = (f32x4){o[0], o[1], o[2], o[3]};
+        *(f32x4*)(r + 4) = (f32x4){o[4], o[5], o[6], o[7]};
     }
     __syncthreads();
-    for (int i = tid; i < G * 128; i += 256) {
-        const int g = i >> 7, d = i & 127;
-        p.part_o[((int64_t)split * p.nq + kvh * G + g) * 128 + d] = so[0][g][d] + so[1][g][d] + so[2][g][d] + so[3][g][d];
+    // partial O as 8-byte write-through (sc1) stores (guide G16 R1: payload sc1 -> every storing wave drains -> flag)
+    for (int i = tid; i < G * 64; i += 256) {
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) { o0 += red[kg * G * 128 + 2 * i]; o1 += red[kg * G * 128 + 2 * i + 1]; }
+        gu64* dst = (gu64*)(p.part_o + ((int64_t)split * p.nq + kvh * G) * 128 + 2 * i);
+        __hip_atomic_store(dst, pack_f2(o0, o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
+// merge of the split partials.  Measured alternatives (profiles/r01 notes in DESIGN.md §4.3): combine by the last-arriving
+// block inside the partial kernel (fences: 14.6 us, sc1 stores+loads: 16.3 us) and combine inside the o_proj GEMV prologue
+// (18.0 us for o_proj) are all no faster than this separate 7 us launch, so the simplest form is kept.
 __global__ __launch_bounds__(128) void attn_decode_merge(AttnDecodeArgs p) {
     const int h = blockIdx.x, d = threadIdx.x;
     const int nkeys = *p.pos_ptr + 1;
@@ -320,22 +461,42 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.hd == 128, "attn_decode: head_dim must be 128 (got %d)", a.hd);
     VILA_REQUIRE(a.nq % a.nkv == 0 && a.nq / a.nkv <= DEC_MAXG, "attn_decode: GQA group %d/%d unsupported (max %d)", a.nq, a.nkv, DEC_MAXG);
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
-    hipLaunchKernelGGL(attn_decode_partial, dim3(a.n_splits, a.nkv), dim3(256), 0, s, a);
+    const size_t lds = (size_t)(DEC_MAXG * 128 + DEC_MAXG * DEC_KS + 16 * DEC_MAXG * 128) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VILA_HIP(hipFuncSetAttribute((const void*)attn_decode_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_decode_partial, dim3(a.n_splits, a.nkv), dim3(256), lds, s, a);
     VILA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_decode_merge, dim3(a.nq), dim3(128), 0, s, a);
-    VILA_LAUNCH_CHECK();
+    if (a.o != nullptr) {
+        hipLaunchKernelGGL(attn_decode_merge, dim3(a.nq), dim3(128), 0, s, a);
+        VILA_LAUNCH_CHECK();
+    }
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void embed_token_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ tok, bf16_t* __restrict__ out, int H, int64_t vocab) {
+// per-token prologue: x = embed[token]; rope table for the token's position: cs[0:hd/2] = cos, cs[hd/2:hd] = sin,
+// both rounded to bf16 (HF casts cos/sin to the activation dtype before use)
+__global__ void decode_prologue_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ tok, bf16_t* __restrict__ out, int H,
+                                       int64_t vocab, const int32_t* __restrict__ pos, float* __restrict__ rope_cs, int hd, float theta) {
     int64_t id = *tok;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < (H >> 3); c += gridDim.x * blockDim.x)
         *(u32x4*)(out + c * 8) = *(const u32x4*)(table + id * H + c * 8);
+    if (blockIdx.x == 0 && (int)threadIdx.x < (hd >> 1)) {
+        const int d = threadIdx.x;
+        const float inv = 1.0f / powf(theta, (float)(2 * d) / (float)hd);
+        const float ang = (float)(*pos) * inv;
+        rope_cs[d] = bfround(cosf(ang));
+        rope_cs[(hd >> 1) + d] = bfround(sinf(ang));
+    }
 }
-int launch_embed_token(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, hipStream_t s) {
-    hipLaunchKernelGGL(embed_token_kernel, dim3(cdiv(H / 8, 256)), dim3(256), 0, s, table, tok, out, H, vocab);
+int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
+                           int hd, float theta, hipStream_t s) {
+    VILA_REQUIRE(hd / 2 <= 256, "decode_prologue: head_dim too large");
+    hipLaunchKernelGGL(decode_prologue_kernel, dim3(cdiv(H / 8, 256)), dim3(256), 0, s, table, tok, out, H, vocab, pos, rope_cs, hd, theta);
     VILA_LAUNCH_CHECK();
     return 0;
 }

@@ -59,7 +59,8 @@ struct GemvArgs {
     const bf16_t* residual;   // [N] optional, added after
     bf16_t* y;                // [N] bf16 out (or null)
     float* y_f32;             // [N] fp32 out (logits) (or null)
-    int N, K; int mode;       // 0 plain, 1 gate/up silu-mul
+    int N, K; int mode;       // 0 plain, 1 gate/up silu-mul, 2 plain with x = merge of the decode-attention partials
+    const float* part_o; const float* part_ml; const int32_t* pos_ptr; int n_splits;   // mode 2
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
 struct QkvDecodeArgs {
@@ -68,15 +69,18 @@ struct QkvDecodeArgs {
     bf16_t* q_out;                             // [nq*hd]
     bf16_t* kcache; bf16_t* vcache;            // this layer's [nkv][max_ctx][hd]
     const int32_t* pos_ptr;                    // device scalar: position of the new token (= current context length)
-    int K, nq, nkv, hd, max_ctx; float theta;
+    const float* rope_cs;                      // [hd] cos | sin of that position (decode_prologue_kernel)
+    int K, nq, nkv, hd, max_ctx;
 };
 int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s);
 struct AttnDecodeArgs {
-    const bf16_t* q; const bf16_t* kcache; const bf16_t* vcache; bf16_t* o;
+    const bf16_t* q; const bf16_t* kcache; const bf16_t* vcache;
+    bf16_t* o;                       // [nq*hd] merged output (second launch); null = partials only
     float* part_o; float* part_ml;   // workspace: [n_splits][nq][hd], [n_splits][nq][2]
     const int32_t* pos_ptr;          // context length BEFORE this token; keys 0..pos inclusive are attended
     int nq, nkv, hd, max_ctx, n_splits; float scale;
 };
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
-int launch_embed_token(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, hipStream_t s);
+int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
+                           int hd, float theta, hipStream_t s);
 int launch_decode_advance(int32_t* pos, const int64_t* tok, int64_t* out_ids, int32_t* n_out, int max_out, hipStream_t s);
