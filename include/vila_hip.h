@@ -166,6 +166,43 @@ int vila_gemv_bf16(const void* x, const void* norm_w, float eps, const void* W, 
                    const void* residual, void* y_bf16, float* y_f32, int N, int K, int mode, vila_stream_t stream);
 int vila_argmax_f32(const float* logits, int n, int64_t* out, void* workspace /* >= 4 KiB */, vila_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SFT step: backward and optimizer operators.  They replace what autograd + cuBLAS +
+ * flash_attn backward + torch.optim.AdamW do under HF Trainer.training_step (llava/train/transformer_normalize_monkey_patch.py:183-249).
+ * dgrad / wgrad are vila_gemm_bf16 on transposed operands (vila_transpose_bf16).
+ * ------------------------------------------------------------------------------------------------------------ */
+int vila_transpose_bf16(const void* in, void* out, int rows, int cols, int64_t ld_in, int64_t ld_out, vila_stream_t stream);
+int vila_act_fwd_bf16(const void* z, void* y, int64_t n, int act /*1 tanh-GELU, 2 erf-GELU*/, vila_stream_t stream);
+int vila_act_bwd_bf16(const void* z, const void* dy, void* dz, int64_t n, int act, vila_stream_t stream);
+int vila_silu_mul_fwd_bf16(const void* gate, const void* up, void* act, int64_t n, vila_stream_t stream);
+int vila_silu_mul_bwd_bf16(const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, vila_stream_t stream);
+int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_t stream);
+/* out[c] (+)= sum_r x[r][c]; period > 0: out[p][c] = sum over rows r == p (mod period)  (position-embedding gradient) */
+int vila_colsum_bf16(const void* x, void* out, int rows, int cols, int64_t ld, int accumulate, int period, vila_stream_t stream);
+/* LayerNorm (rms=0) / RMSNorm (rms=1) backward; scratch = 2*cols fp32 */
+int vila_norm_bwd_bf16(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, float* scratch, int rows, int cols,
+                       float eps, int rms, int accumulate, vila_stream_t stream);
+/* softmax-CE over fp32 logits rows: loss += sum_i (lse_i - z_i[label_i]) * scale ; dlogits = (softmax - onehot) * scale (bf16) */
+int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, int rows, int vocab, int64_t ld_logits,
+                     float scale, vila_stream_t stream);
+int vila_scatter_add_rows_bf16(const void* src, void* dst, const int32_t* rows, int n, int hidden, vila_stream_t stream);
+int vila_depth_to_space_bf16(const void* dy, void* dx, int n_images, int grid, int channels, int k, vila_stream_t stream);
+int vila_im2col_bf16(const void* pixels, void* out, int n_images, int channels, int H, int W, int patch, int k_padded, vila_stream_t stream);
+int vila_rope_table_f32(const int32_t* positions, float* cos_out, float* sin_out, int n_tokens, int head_dim, float theta, vila_stream_t stream);
+int vila_rope_fwd_bf16(void* qkv, const float* cos_t, const float* sin_t, const int32_t* positions, int n_tokens, int q_heads, int kv_heads,
+                       int head_dim, vila_stream_t stream);
+int vila_rope_bwd_bf16(void* dqkv, const float* cos_t, const float* sin_t, int n_tokens, int q_heads, int kv_heads, int head_dim, vila_stream_t stream);
+/* flash-attention backward; tok_strides / head_strides: [8] host arrays for q,k,v,o,do,dq,dk,dv (elements) */
+int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                       const int64_t* tok_strides, const int32_t* head_strides, const int32_t* cu_seqlens, int n_seq, int total_tokens,
+                       int max_seqlen, int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, const float* lse, float* delta,
+                       vila_stream_t stream);
+/* torch.optim.AdamW semantics on flat buffers: fp32 master/m/v, bf16 grad in (times grad_scale), bf16 param out */
+int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);
+int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,27 @@ PROTOTYPES = {
     "vila_gemv_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_void_p]),
     "vila_argmax_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    # ---- SFT step operators ----
+    "vila_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "vila_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vila_act_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vila_silu_mul_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vila_silu_mul_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vila_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vila_colsum_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "vila_norm_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vila_ce_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),
+    "vila_scatter_add_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vila_depth_to_space_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_rope_table_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "vila_rope_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_rope_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_attn_bwd_bf16": (c_int, [c_void_p] * 8 + [C.POINTER(c_int64), C.POINTER(C.c_int32), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                c_float, c_void_p]),
+    "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include "../../include/vila_hip.h"
 #include "kernels.h"
+#include "train.h"
 
 static thread_local char g_err[512] = "";
 void vila_set_error(const char* fmt, ...) {
@@ -398,3 +399,71 @@ extern "C" int vila_argmax_f32(const float* logits, int n, int64_t* out, void* w
     int* ti = (int*)((char*)workspace + 2048);
     return launch_argmax(logits, n, out, tv, ti, S(stream));
 }
+
+// =================================================================================================
+// Training operator exports (backward kernels + optimizer); orchestrated by vila_amd/train.py
+// =================================================================================================
+extern "C" int vila_transpose_bf16(const void* in, void* out, int R, int C, int64_t ldi, int64_t ldo, vila_stream_t stream) {
+    return launch_transpose(B(in), B(out), R, C, ldi, ldo, S(stream));
+}
+extern "C" int vila_act_fwd_bf16(const void* z, void* y, int64_t n, int act, vila_stream_t stream) { return launch_act_fwd(B(z), B(y), n, act, S(stream)); }
+extern "C" int vila_act_bwd_bf16(const void* z, const void* dy, void* dz, int64_t n, int act, vila_stream_t stream) {
+    return launch_act_bwd(B(z), B(dy), B(dz), n, act, S(stream));
+}
+extern "C" int vila_silu_mul_fwd_bf16(const void* g, const void* u, void* a, int64_t n, vila_stream_t stream) {
+    return launch_silu_mul_fwd(B(g), B(u), B(a), n, S(stream));
+}
+extern "C" int vila_silu_mul_bwd_bf16(const void* g, const void* u, const void* da, void* dg, void* du, int64_t n, vila_stream_t stream) {
+    return launch_silu_mul_bwd(B(g), B(u), B(da), B(dg), B(du), n, S(stream));
+}
+extern "C" int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_t stream) { return launch_add(B(a), B(b), B(y), n, S(stream)); }
+extern "C" int vila_colsum_bf16(const void* x, void* out, int R, int C, int64_t ld, int accumulate, int period, vila_stream_t stream) {
+    return launch_colsum(B(x), B(out), R, C, ld, accumulate, period, S(stream));
+}
+extern "C" int vila_norm_bwd_bf16(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, float* scratch, int rows, int cols,
+                                  float eps, int rms, int accumulate, vila_stream_t stream) {
+    return launch_norm_bwd(B(x), B(w), B(dy), B(dx), B(dw), B(db), scratch, rows, cols, eps, rms, accumulate, S(stream));
+}
+extern "C" int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, int rows, int V, int64_t ldl, float scale,
+                                vila_stream_t stream) {
+    return launch_ce(logits, labels, B(dlogits), loss, rows, V, ldl, scale, S(stream));
+}
+extern "C" int vila_scatter_add_rows_bf16(const void* src, void* dst, const int32_t* rows, int n, int H, vila_stream_t stream) {
+    return launch_scatter_add_rows(B(src), B(dst), rows, n, H, S(stream));
+}
+extern "C" int vila_depth_to_space_bf16(const void* dy, void* dx, int n_images, int grid, int channels, int k, vila_stream_t stream) {
+    return launch_depth_to_space(B(dy), B(dx), n_images, grid, channels, k, S(stream));
+}
+extern "C" int vila_im2col_bf16(const void* pixels, void* out, int n_images, int channels, int H, int W, int P, int Kp, vila_stream_t stream) {
+    return launch_im2col(B(pixels), B(out), n_images, channels, H, W, P, Kp, S(stream));
+}
+extern "C" int vila_rope_table_f32(const int32_t* positions, float* cos_out, float* sin_out, int S_, int head_dim, float theta, vila_stream_t stream) {
+    return launch_rope_table(positions, cos_out, sin_out, S_, head_dim, theta, S(stream));
+}
+extern "C" int vila_rope_fwd_bf16(void* qkv, const float* cs, const float* sn, const int32_t* positions, int S_, int nq, int nkv, int hd,
+                                  vila_stream_t stream) {
+    return launch_rope_kv(B(qkv), cs, sn, positions, nullptr, nullptr, nullptr, S_, nq, nkv, hd, 0, S(stream));
+}
+extern "C" int vila_rope_bwd_bf16(void* dqkv, const float* cs, const float* sn, int S_, int nq, int nkv, int hd, vila_stream_t stream) {
+    return launch_rope_bwd(B(dqkv), cs, sn, S_, nq, nkv, hd, S(stream));
+}
+extern "C" int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                                  const int64_t* tok_strides /*[8] q,k,v,o,do,dq,dk,dv*/, const int32_t* head_strides /*[8]*/,
+                                  const int32_t* cu_seqlens, int n_seq, int total_tokens, int max_seqlen, int n_q_heads, int n_kv_heads,
+                                  int head_dim, int causal, float scale, const float* lse, float* delta, vila_stream_t stream) {
+    AttnBwdArgs a{};
+    a.q = B(q); a.k = B(k); a.v = B(v); a.o = B(o); a.d_o = B(d_o); a.dq = B(dq); a.dk = B(dk); a.dv = B(dv);
+    a.q_tok_stride = tok_strides[0]; a.k_tok_stride = tok_strides[1]; a.v_tok_stride = tok_strides[2]; a.o_tok_stride = tok_strides[3];
+    a.do_tok_stride = tok_strides[4]; a.dq_tok_stride = tok_strides[5]; a.dk_tok_stride = tok_strides[6]; a.dv_tok_stride = tok_strides[7];
+    a.q_head_stride = head_strides[0]; a.k_head_stride = head_strides[1]; a.v_head_stride = head_strides[2]; a.o_head_stride = head_strides[3];
+    a.do_head_stride = head_strides[4]; a.dq_head_stride = head_strides[5]; a.dk_head_stride = head_strides[6]; a.dv_head_stride = head_strides[7];
+    for (int i = 0; i < 8; ++i) VILA_REQUIRE(tok_strides[i] % 8 == 0 && head_strides[i] % 8 == 0, "attn_bwd: strides must be multiples of 8 elements");
+    a.cu_seqlens = cu_seqlens; a.n_seq = n_seq; a.total_tokens = total_tokens; a.max_seqlen = max_seqlen;
+    a.n_q_heads = n_q_heads; a.n_kv_heads = n_kv_heads; a.head_dim = head_dim; a.causal = causal; a.scale = scale; a.lse = lse; a.delta = delta;
+    return launch_attn_bwd(a, S(stream));
+}
+extern "C" int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream) {
+    return launch_adamw(master, m, v, B(grad), B(param), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
+}
+extern "C" int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream) { return launch_sumsq(B(x), n, out, S(stream)); }

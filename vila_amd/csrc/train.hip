@@ -1,0 +1,423 @@
+// Backward / optimizer kernels of the SFT step.  The dense contractions of backward reuse
+// gemm_bf16_tn: dgrad  dX[M,K] = dY[M,N] . (W^T)[K,N]^T  and  wgrad  dW[N,K] = (dY^T)[N,M] . (X^T)[K,M]^T,  with the
+// transposed operands produced by transpose_kernel below (activations are a few MB; the weight transposes cost
+// ~2 x 16 GB of HBM traffic per step = ~5 ms, 2 % of the step).  Everything elementwise / reductions lives here.
+#include "kernels.h"
+#include "train.h"
+
+// ------------------------------------------------------------------------------------------------
+// bf16 2-D transpose through a padded LDS tile (64x64), 16-B global accesses on both sides when R,C % 8 == 0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C,
+                                                        int64_t ldi, int64_t ldo) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    // load: 64 rows x 8 chunks of 8
+    for (int i = tid; i < 512; i += 256) {
+        const int r = i >> 3, ch = i & 7;
+        const int gr = r0 + r, gc = c0 + ch * 8;
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (gr < R && gc < C) v = *(const u32x4*)(in + (int64_t)gr * ldi + gc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tile[r][ch * 8 + 2 * k] = (bf16_t)(v[k] & 0xffffu);
+            tile[r][ch * 8 + 2 * k + 1] = (bf16_t)(v[k] >> 16);
+        }
+    }
+    __syncthreads();
+    const int Rp = (R + 7) & ~7;                    // output rows are padded to a multiple of 8 with zeros (wgrad contraction dim)
+    for (int i = tid; i < 512; i += 256) {
+        const int c = i >> 3, ch = i & 7;          // output row = input column
+        const int gc = c0 + c, gr = r0 + ch * 8;
+        if (gc < C && gr < Rp) {
+            u32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (uint32_t)tile[ch * 8 + 2 * k][c] | ((uint32_t)tile[ch * 8 + 2 * k + 1][c] << 16);
+            *(u32x4*)(out + (int64_t)gc * ldo + gr) = v;
+        }
+    }
+}
+int launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, int64_t ldi, int64_t ldo, hipStream_t s) {
+    VILA_REQUIRE(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldo >= ((R + 7) & ~7), "transpose: C (%d), ld must be multiples of 8 and ldo >= round_up(R,8)", C);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, s, in, out, R, C, ldi, ldo);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise helpers (vectorised 16 B / lane, grid-stride)
+// ------------------------------------------------------------------------------------------------
+#define EW_GRID(total) ((int)(((total) + 255) / 256 < 8192 ? ((total) + 255) / 256 : 8192))
+#define EW_LOOP(total) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float dgelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float t = tanhf(k0 * (x + k1 * x * x * x));
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x * x);
+}
+__device__ __forceinline__ float dgelu_erf(float x) {
+    return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// y = act(z)  (forward of the un-fused training path; z kept for backward)
+template <int ACT>
+__global__ void act_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ y, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 v = *(const u32x4*)(z + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = lo_bf(v[k]), b = hi_bf(v[k]);
+            o[k] = ACT == 1 ? pack2bf(gelu_tanh_f(a), gelu_tanh_f(b)) : pack2bf(gelu_erf_f(a), gelu_erf_f(b));
+        }
+        *(u32x4*)(y + i * 8) = o;
+    }
+}
+// dz = dy * act'(z)
+template <int ACT>
+__global__ void act_bwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dz, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 v = *(const u32x4*)(z + i * 8);
+        const u32x4 g = *(const u32x4*)(dy + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = lo_bf(v[k]), b = hi_bf(v[k]);
+            const float da = ACT == 1 ? dgelu_tanh(a) : dgelu_erf(a), db = ACT == 1 ? dgelu_tanh(b) : dgelu_erf(b);
+            o[k] = pack2bf(lo_bf(g[k]) * da, hi_bf(g[k]) * db);
+        }
+        *(u32x4*)(dz + i * 8) = o;
+    }
+}
+int launch_act_fwd(const bf16_t* z, bf16_t* y, int64_t n, int act, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0 && (act == 1 || act == 2), "act_fwd: n %% 8 and act in {1,2}");
+    if (act == 1) hipLaunchKernelGGL(act_fwd_kernel<1>, dim3(EW_GRID(n / 8)), dim3(256), 0, s, z, y, n / 8);
+    else hipLaunchKernelGGL(act_fwd_kernel<2>, dim3(EW_GRID(n / 8)), dim3(256), 0, s, z, y, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+int launch_act_bwd(const bf16_t* z, const bf16_t* dy, bf16_t* dz, int64_t n, int act, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0 && (act == 1 || act == 2), "act_bwd: n %% 8 and act in {1,2}");
+    if (act == 1) hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(EW_GRID(n / 8)), dim3(256), 0, s, z, dy, dz, n / 8);
+    else hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(EW_GRID(n / 8)), dim3(256), 0, s, z, dy, dz, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// SwiGLU: a = bf16(silu(g)) * u (HF rounding);  backward: dg = da * u * silu'(g), du = da * silu(g)
+__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ a, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 gv = *(const u32x4*)(g + i * 8), uv = *(const u32x4*)(u + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack2bf(bfround(silu_f(lo_bf(gv[k]))) * lo_bf(uv[k]), bfround(silu_f(hi_bf(gv[k]))) * hi_bf(uv[k]));
+        *(u32x4*)(a + i * 8) = o;
+    }
+}
+__device__ __forceinline__ float dsilu(float x) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+__global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, const bf16_t* __restrict__ da,
+                                    bf16_t* __restrict__ dg, bf16_t* __restrict__ du, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 gv = *(const u32x4*)(g + i * 8), uv = *(const u32x4*)(u + i * 8), dv = *(const u32x4*)(da + i * 8);
+        u32x4 og, ou;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g0 = lo_bf(gv[k]), g1 = hi_bf(gv[k]), d0 = lo_bf(dv[k]), d1 = hi_bf(dv[k]);
+            og[k] = pack2bf(d0 * lo_bf(uv[k]) * dsilu(g0), d1 * hi_bf(uv[k]) * dsilu(g1));
+            ou[k] = pack2bf(d0 * silu_f(g0), d1 * silu_f(g1));
+        }
+        *(u32x4*)(dg + i * 8) = og;
+        *(u32x4*)(du + i * 8) = ou;
+    }
+}
+int launch_silu_mul_fwd(const bf16_t* g, const bf16_t* u, bf16_t* a, int64_t n, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0, "silu_mul: n %% 8");
+    hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(EW_GRID(n / 8)), dim3(256), 0, s, g, u, a, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+int launch_silu_mul_bwd(const bf16_t* g, const bf16_t* u, const bf16_t* da, bf16_t* dg, bf16_t* du, int64_t n, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0, "silu_mul_bwd: n %% 8");
+    hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(EW_GRID(n / 8)), dim3(256), 0, s, g, u, da, dg, du, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = a + b (bf16)
+__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 av = *(const u32x4*)(a + i * 8), bv = *(const u32x4*)(b + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(lo_bf(av[k]) + lo_bf(bv[k]), hi_bf(av[k]) + hi_bf(bv[k]));
+        *(u32x4*)(y + i * 8) = o;
+    }
+}
+int launch_add(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0, "add: n %% 8");
+    hipLaunchKernelGGL(add_kernel, dim3(EW_GRID(n / 8)), dim3(256), 0, s, a, b, y, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: out[c] (+)= sum_r x[r][c]  (bias / position-embedding gradients).  One block per 64 columns; each of the
+// 4 waves walks a quarter of the rows with lane = column; fp32 accumulate.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int R, int C, int64_t ld,
+                                                     int accumulate, int period) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int prow = blockIdx.y;                     // output row when period > 0: sums rows r with r % period == prow
+    float acc = 0.f;
+    if (c < C) {
+        if (period > 0) for (int r = prow + wave * period; r < R; r += 4 * period) acc += bf2f(x[(int64_t)r * ld + c]);
+        else for (int r = wave; r < R; r += 4) acc += bf2f(x[(int64_t)r * ld + c]);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        bf16_t* o = out + (int64_t)prow * C + c;
+        if (accumulate) v += bf2f(*o);
+        *o = f2bf(v);
+    }
+}
+int launch_colsum(const bf16_t* x, bf16_t* out, int R, int C, int64_t ld, int accumulate, int period, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), period > 0 ? period : 1), dim3(256), 0, s, x, out, R, C, ld, accumulate, period);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm backward.  One block per row for dx; dw/db through fp32 atomics into [cols] scratch that a second
+// tiny kernel converts (and accumulates) into the bf16 gradient tensors.
+//   LN : xhat = (x-mean)*rstd ; dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*w ; dw += dy*xhat ; db += dy
+//   RMS: xhat = x*rstd        ; dx = rstd*(g - xhat*mean(g*xhat))             ; dw += dy*xhat
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum4(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                       bf16_t* __restrict__ dx, float* __restrict__ dw32, float* __restrict__ db32,
+                                                       int cols, float eps) {
+    __shared__ float scratch[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)row * cols;
+    const bf16_t* gr = dy + (int64_t)row * cols;
+    bf16_t* dr = dx + (int64_t)row * cols;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = tid; c < cols; c += 256) { const float v = bf2f(xr[c]); s1 += v; s2 += v * v; }
+    s1 = block_sum4(s1, scratch);
+    s2 = block_sum4(s2, scratch);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s2 / cols + eps);
+    } else {
+        mean = s1 / cols;
+        float q = 0.f;
+        for (int c = tid; c < cols; c += 256) { const float d = bf2f(xr[c]) - mean; q += d * d; }
+        q = block_sum4(q, scratch);
+        rstd = rsqrtf(q / cols + eps);
+    }
+    float a = 0.f, b = 0.f;     // a = sum(g), b = sum(g*xhat)
+    for (int c = tid; c < cols; c += 256) {
+        const float xh = (bf2f(xr[c]) - mean) * rstd;
+        const float g = bf2f(gr[c]) * bf2f(w[c]);
+        a += g; b += g * xh;
+    }
+    a = block_sum4(a, scratch);
+    b = block_sum4(b, scratch);
+    const float ma = RMS ? 0.f : a / cols, mb = b / cols;
+    for (int c = tid; c < cols; c += 256) {
+        const float xh = (bf2f(xr[c]) - mean) * rstd;
+        const float dyv = bf2f(gr[c]);
+        const float g = dyv * bf2f(w[c]);
+        dr[c] = f2bf(rstd * (g - ma - xh * mb));
+        atomicAdd(dw32 + c, dyv * xh);
+        if (!RMS && db32 != nullptr) atomicAdd(db32 + c, dyv);
+    }
+}
+__global__ void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2bf(src[i] + (accumulate ? bf2f(dst[i]) : 0.f));
+}
+int launch_norm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, float* scratch /*2*cols fp32*/,
+                    int rows, int cols, float eps, int rms, int accumulate, hipStream_t s) {
+    VILA_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * cols * sizeof(float), s));
+    if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(rows), dim3(256), 0, s, x, w, dy, dx, scratch, (float*)nullptr, cols, eps);
+    else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(rows), dim3(256), 0, s, x, w, dy, dx, scratch, scratch + cols, cols, eps);
+    VILA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, scratch, dw, cols, accumulate);
+    VILA_LAUNCH_CHECK();
+    if (!rms && db != nullptr) {
+        hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, scratch + cols, db, cols, accumulate);
+        VILA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax cross-entropy over fp32 logits rows (HF ForCausalLMLoss, reduction sum / num_items): in-place gradient.
+//   loss += (lse - z[label]) * scale ;  dz = (softmax(z) - onehot(label)) * scale  written as bf16 into dlogits
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, bf16_t* __restrict__ dlogits,
+                                                 float* __restrict__ loss, int V, int64_t ldl, float scale) {
+    __shared__ float scratch[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* z = logits + (int64_t)row * ldl;
+    bf16_t* dz = dlogits + (int64_t)row * V;
+    const int64_t lab = labels[row];
+    float m = -INFINITY;
+    for (int c = tid; c < V; c += 256) m = fmaxf(m, z[c]);
+    m = wave_max(m);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float sum = 0.f;
+    for (int c = tid; c < V; c += 256) sum += __expf(z[c] - m);
+    sum = block_sum4(sum, scratch);
+    const float inv = 1.f / sum;
+    const bool valid = lab >= 0 && lab < V;
+    for (int c = tid; c < V; c += 256) {
+        float p = __expf(z[c] - m) * inv;
+        if (c == lab) p -= 1.f;
+        dz[c] = f2bf(valid ? p * scale : 0.f);
+    }
+    if (tid == 0 && valid) atomicAdd(loss, (m + logf(sum) - z[lab]) * scale);
+}
+int launch_ce(const float* logits, const int64_t* labels, bf16_t* dlogits, float* loss, int rows, int V, int64_t ldl, float scale, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, s, logits, labels, dlogits, loss, V, ldl, scale);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter-add rows into a bf16 table (embedding gradient): dst[rows[i]] += src[i], packed-bf16 CAS loop
+// ------------------------------------------------------------------------------------------------
+__global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ rows, int n, int H) {
+    const int w2 = H >> 1;
+    const int64_t total = (int64_t)n * w2;
+    EW_LOOP(total) {
+        const int r = (int)(i / w2), c = (int)(i % w2);
+        const uint32_t add = *(const uint32_t*)(src + (int64_t)r * H + 2 * c);
+        unsigned int* addr = (unsigned int*)(dst + (int64_t)rows[r] * H + 2 * c);
+        unsigned int old = *addr, assumed;
+        do {
+            assumed = old;
+            const uint32_t nv = pack2bf(lo_bf(assumed) + lo_bf(add), hi_bf(assumed) + hi_bf(add));
+            old = atomicCAS(addr, assumed, nv);
+        } while (old != assumed);
+    }
+}
+int launch_scatter_add_rows(const bf16_t* src, bf16_t* dst, const int32_t* rows, int n, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    VILA_REQUIRE(H % 2 == 0, "scatter_add_rows: H must be even");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(EW_GRID((int64_t)n * H / 2)), dim3(256), 0, s, src, dst, rows, n, H);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// depth-to-space = backward of flat_square k x k (padded cells receive no gradient)
+__global__ void d2s_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int g, int C, int k) {
+    const int gd = (g + k - 1) / k, c8 = C >> 3;
+    const int64_t total = (int64_t)B * g * g * c8;
+    EW_LOOP(total) {
+        int64_t r = i;
+        const int ch = (int)(r % c8); r /= c8;
+        const int sx = (int)(r % g); r /= g;
+        const int sy = (int)(r % g); r /= g;
+        const int b = (int)r;
+        const int ii = sy / k, a = sy % k, j = sx / k, bb = sx % k;
+        *(u32x4*)(dx + ((int64_t)b * g * g + sy * g + sx) * C + ch * 8) =
+            *(const u32x4*)(dy + (((int64_t)b * gd * gd + ii * gd + j) * k * k + a * k + bb) * C + ch * 8);
+    }
+}
+int launch_depth_to_space(const bf16_t* dy, bf16_t* dx, int B, int g, int C, int k, hipStream_t s) {
+    VILA_REQUIRE(C % 8 == 0, "depth_to_space: C %% 8");
+    hipLaunchKernelGGL(d2s_kernel, dim3(EW_GRID((int64_t)B * g * g * C / 8)), dim3(256), 0, s, dy, dx, B, g, C, k);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// RoPE backward on a fused dqkv buffer [S][q+2kv]: the rotation matrix transposed = same rotation with -sin (q and k heads)
+__global__ void rope_bwd_kernel(bf16_t* __restrict__ dqkv, const float* __restrict__ cs, const float* __restrict__ sn, int S, int nq, int nkv, int hd) {
+    const int half = hd >> 1, cpr = half >> 3, heads = nq + nkv;
+    const int64_t total = (int64_t)S * heads * cpr;
+    const int row = (nq + 2 * nkv) * hd;
+    EW_LOOP(total) {
+        int64_t r = i;
+        const int ch = (int)(r % cpr); r /= cpr;
+        const int hh = (int)(r % heads); r /= heads;
+        const int s = (int)r;
+        bf16_t* base = dqkv + (int64_t)s * row + hh * hd + ch * 8;
+        const u32x4 x1 = *(const u32x4*)base, x2 = *(const u32x4*)(base + half);
+        const float* c = cs + (int64_t)s * half + ch * 8;
+        const float* sv = sn + (int64_t)s * half + ch * 8;
+        u32x4 o1, o2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = lo_bf(x1[k]), a1 = hi_bf(x1[k]), b0 = lo_bf(x2[k]), b1 = hi_bf(x2[k]);
+            // forward: y1 = x1 c - x2 s ; y2 = x2 c + x1 s   =>   dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s
+            o1[k] = pack2bf(a0 * c[2 * k] + b0 * sv[2 * k], a1 * c[2 * k + 1] + b1 * sv[2 * k + 1]);
+            o2[k] = pack2bf(b0 * c[2 * k] - a0 * sv[2 * k], b1 * c[2 * k + 1] - a1 * sv[2 * k + 1]);
+        }
+        *(u32x4*)base = o1;
+        *(u32x4*)(base + half) = o2;
+    }
+}
+int launch_rope_bwd(bf16_t* dqkv, const float* cs, const float* sn, int S, int nq, int nkv, int hd, hipStream_t s) {
+    hipLaunchKernelGGL(rope_bwd_kernel, dim3(EW_GRID((int64_t)S * (nq + nkv) * hd / 16)), dim3(256), 0, s, dqkv, cs, sn, S, nq, nkv, hd);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics, adamw_torch in llava/train/args.py:223): fp32 master weight + m + v, bf16 grad in,
+// bf16 param out.  One flat launch over the whole model.
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v, const bf16_t* __restrict__ grad,
+                             bf16_t* __restrict__ param, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                             float grad_scale) {
+    EW_LOOP(n) {
+        const float g = bf2f(grad[i]) * grad_scale;
+        float p = master[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        p *= (1.f - lr * wd);
+        p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        m[i] = mi; v[i] = vi; master[i] = p;
+        param[i] = f2bf(p);
+    }
+}
+int launch_adamw(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
+                 float wd, int step, float grad_scale, hipStream_t s) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, master, m, v, grad, param, n, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+// sum of squares of a bf16 buffer into a fp32 scalar (global grad-norm for clipping)
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float scratch[4];
+    float acc = 0.f;
+    EW_LOOP(n) { const float v = bf2f(x[i]); acc += v * v; }
+    acc = block_sum4(acc, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+int launch_sumsq(const bf16_t* x, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(EW_GRID(n) > 2048 ? 2048 : EW_GRID(n)), dim3(256), 0, s, x, n, out);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}

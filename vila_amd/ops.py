@@ -132,3 +132,137 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, src_row: Optional[torch.Tens
     for t in (src_row, dst_row):
         assert t is None or (t.dtype == torch.int32 and t.is_cuda)
     check(_lib.load().vila_copy_rows(src.data_ptr(), dst.data_ptr(), _p(src_row), _p(dst_row), n, src.shape[-1], _stream()), "copy_rows")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SFT-step operators (backward + optimizer)
+# ----------------------------------------------------------------------------------------------------------------------
+def _L():
+    return _lib.load()
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] -> [C, round_up(R, 8)] (zero-padded): the K-contiguous operand form gemm() needs for dgrad / wgrad."""
+    _need(x, name="x"); assert x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    Rp = (R + 7) // 8 * 8
+    out = torch.empty((Cc, Rp), device=x.device, dtype=x.dtype)
+    check(_L().vila_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), Rp, _stream()), "transpose")
+    return out
+
+
+def act_fwd(z: torch.Tensor, act: int) -> torch.Tensor:
+    y = torch.empty_like(z)
+    check(_L().vila_act_fwd_bf16(z.data_ptr(), y.data_ptr(), z.numel(), act, _stream()), "act_fwd")
+    return y
+
+
+def act_bwd(z: torch.Tensor, dy: torch.Tensor, act: int) -> torch.Tensor:
+    dz = torch.empty_like(z)
+    check(_L().vila_act_bwd_bf16(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), z.numel(), act, _stream()), "act_bwd")
+    return dz
+
+
+def silu_mul(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    a = torch.empty_like(g)
+    check(_L().vila_silu_mul_fwd_bf16(g.data_ptr(), u.data_ptr(), a.data_ptr(), g.numel(), _stream()), "silu_mul")
+    return a
+
+
+def silu_mul_bwd(g, u, da):
+    dg, du = torch.empty_like(g), torch.empty_like(u)
+    check(_L().vila_silu_mul_bwd_bf16(g.data_ptr(), u.data_ptr(), da.data_ptr(), dg.data_ptr(), du.data_ptr(), g.numel(), _stream()), "silu_mul_bwd")
+    return dg, du
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    check(_L().vila_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False, period: int = 0) -> None:
+    assert x.dim() == 2 and x.stride(1) == 1 and out.is_contiguous()
+    check(_L().vila_colsum_bf16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), int(accumulate), period, _stream()), "colsum")
+
+
+def norm_bwd(x, w, dy, dw_out, db_out, eps: float, rms: bool, accumulate: bool = False) -> torch.Tensor:
+    x2, dy2 = x.reshape(-1, x.shape[-1]), dy.reshape(-1, x.shape[-1])
+    dx = torch.empty_like(x2)
+    scratch = torch.empty((2 * x2.shape[1],), device=x.device, dtype=torch.float32)
+    check(_L().vila_norm_bwd_bf16(x2.data_ptr(), w.data_ptr(), dy2.data_ptr(), dx.data_ptr(), dw_out.data_ptr(), _p(db_out),
+                                  scratch.data_ptr(), x2.shape[0], x2.shape[1], eps, int(rms), int(accumulate), _stream()), "norm_bwd")
+    return dx.view(x.shape)
+
+
+def ce_loss(logits: torch.Tensor, labels: torch.Tensor, loss_acc: torch.Tensor, scale: float) -> torch.Tensor:
+    """logits [n, V] fp32, labels [n] i64 -> dlogits [n, V] bf16; loss_acc (fp32 scalar on device) += sum CE * scale."""
+    _need(logits, dtype=torch.float32, name="logits")
+    n, V = logits.shape
+    d = torch.empty((n, V), device=logits.device, dtype=torch.bfloat16)
+    check(_L().vila_ce_loss_f32(logits.data_ptr(), labels.data_ptr(), d.data_ptr(), loss_acc.data_ptr(), n, V, logits.stride(0), scale, _stream()), "ce_loss")
+    return d
+
+
+def scatter_add_rows(src: torch.Tensor, dst: torch.Tensor, rows: torch.Tensor) -> None:
+    assert rows.dtype == torch.int32 and src.is_contiguous() and dst.is_contiguous()
+    check(_L().vila_scatter_add_rows_bf16(src.data_ptr(), dst.data_ptr(), rows.data_ptr(), rows.numel(), src.shape[-1], _stream()), "scatter_add_rows")
+
+
+def depth_to_space(dy: torch.Tensor, g: int, k: int) -> torch.Tensor:
+    B, _, CC = dy.shape
+    Cc = CC // (k * k)
+    dx = torch.empty((B, g * g, Cc), device=dy.device, dtype=dy.dtype)
+    check(_L().vila_depth_to_space_bf16(dy.contiguous().data_ptr(), dx.data_ptr(), B, g, Cc, k, _stream()), "depth_to_space")
+    return dx
+
+
+def im2col(px: torch.Tensor, patch: int, kp: int) -> torch.Tensor:
+    B, Cc, H, W = px.shape
+    out = torch.empty((B * (H // patch) * (W // patch), kp), device=px.device, dtype=px.dtype)
+    check(_L().vila_im2col_bf16(px.contiguous().data_ptr(), out.data_ptr(), B, Cc, H, W, patch, kp, _stream()), "im2col")
+    return out
+
+
+def rope_table(positions: torch.Tensor, head_dim: int, theta: float):
+    S = positions.numel()
+    cs = torch.empty((S, head_dim // 2), device=positions.device, dtype=torch.float32)
+    sn = torch.empty_like(cs)
+    check(_L().vila_rope_table_f32(positions.data_ptr(), cs.data_ptr(), sn.data_ptr(), S, head_dim, theta, _stream()), "rope_table")
+    return cs, sn
+
+
+def rope_fwd_(qkv: torch.Tensor, cs, sn, positions, nq: int, nkv: int, hd: int) -> None:
+    check(_L().vila_rope_fwd_bf16(qkv.data_ptr(), cs.data_ptr(), sn.data_ptr(), positions.data_ptr(), qkv.shape[0], nq, nkv, hd, _stream()), "rope_fwd")
+
+
+def rope_bwd_(dqkv: torch.Tensor, cs, sn, nq: int, nkv: int, hd: int) -> None:
+    check(_L().vila_rope_bwd_bf16(dqkv.data_ptr(), cs.data_ptr(), sn.data_ptr(), dqkv.shape[0], nq, nkv, hd, _stream()), "rope_bwd")
+
+
+def attn_bwd(q, k, v, o, do, lse, causal: bool, dq, dk, dv, scale: Optional[float] = None, cu_seqlens=None, max_seqlen=None, n_seq: int = 1):
+    """All of q,k,v,o,do,dq,dk,dv are [T, H, D] views (last dim contiguous).  lse [Hq, T] fp32 from attn_fwd(return_lse=True)."""
+    import ctypes as C
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    ts = (C.c_int64 * 8)(*[t.stride(0) for t in (q, k, v, o, do, dq, dk, dv)])
+    hs = (C.c_int32 * 8)(*[t.stride(1) for t in (q, k, v, o, do, dq, dk, dv)])
+    if cu_seqlens is not None:
+        n_seq = cu_seqlens.numel() - 1
+    else:
+        max_seqlen = T // n_seq
+    delta = torch.empty((Hq, T), device=q.device, dtype=torch.float32)
+    check(_L().vila_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                  ts, hs, _p(cu_seqlens), n_seq, T, int(max_seqlen), Hq, Hkv, D, int(causal),
+                                  float(scale if scale is not None else D ** -0.5), lse.data_ptr(), delta.data_ptr(), _stream()), "attn_bwd")
+
+
+def adamw_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0) -> None:
+    check(_L().vila_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), master.numel(), lr, beta1, beta2,
+                               eps, wd, step, grad_scale, _stream()), "adamw")
+
+
+def sumsq(x: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros((1,), device=x.device, dtype=torch.float32)
+    check(_L().vila_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sumsq")
+    return out

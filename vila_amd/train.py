@@ -1,0 +1,449 @@
+"""One SFT training step of NVILA on the HIP kernels.
+
+Replaces, for the step itself, what `Trainer.training_step` (patched at
+llava/train/transformer_normalize_monkey_patch.py:183-249) + autograd + DeepSpeed ZeRO-3 (`scripts/zero3.json`) do in the
+reference:  `LlavaLlamaModel.forward` (llava_llama.py:94-159: `_embed` -> `repack_multimodal_data` -> `llm(..., labels)`) ->
+loss = sum CE / GLOBAL num_items (`:261-268`) -> backward through LLM, mm_projector and ViT (all three trainable,
+scripts/NVILA-Lite/sft.sh:25-27) -> gradient exchange -> AdamW (adamw_torch, lr 2e-5, wd 0: sft.sh:41-42).
+
+MI355X-first choices:
+  * no activation checkpointing: at b=4 x 769 tokens the saved activations are ~16 GB of the 288 GB HBM, so the re-forward
+    (25 % extra FLOPs in the reference recipe, sft.sh:47) is simply not done;
+  * no ZeRO: every rank keeps the full bf16 params + fp32 master/m/v (8.06 B params -> 16 + 97 GB) and the only exchange is a
+    SUM all-reduce of the flat bf16 gradient buffer, bucketed per decoder/encoder layer and launched (async, RCCL's own stream)
+    the moment that layer's backward has been enqueued, so it overlaps the backward of the layers below;
+  * all parameters live in ONE flat bf16 buffer (module parameters are views, q/k/v fused), gradients in a second flat buffer
+    of the same layout: one AdamW launch for the whole model, all-reduce slices are contiguous.
+Backward is explicit (no autograd graph): every op is a C-ABI call on the current stream.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .configs import IGNORE_INDEX
+from .host import repack, splice_plan
+from .modules import _get
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# flat parameter / gradient storage
+# ----------------------------------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-points every parameter of (llm, vision_tower, mm_projector) into one flat bf16 buffer; same layout for grads."""
+
+    def __init__(self, model, with_optimizer_state: bool = True):
+        self.model = model
+        entries: List[Tuple[str, torch.nn.Parameter]] = []
+        for prefix, mod in (("llm.", model.llm), ("vision_tower.", model.vision_tower), ("mm_projector.", model.mm_projector)):
+            done = set()
+            groups = {g[0]: g for g in getattr(mod, "_fused_groups", [])}
+            member = {m for g in groups.values() for m in g}
+            for n, p in mod.named_parameters():
+                if n in done:
+                    continue
+                if n in groups:                      # keep q,k,v adjacent (fused kernels need one [q+2kv, hidden] buffer)
+                    for m in groups[n]:
+                        entries.append((prefix + m, _get(mod, m)))
+                        done.add(m)
+                elif n in member:
+                    continue
+                else:
+                    entries.append((prefix + n, p))
+                    done.add(n)
+        dev = model.device
+        off = 0
+        self.index: Dict[str, Tuple[int, int, torch.Size]] = {}
+        for n, p in entries:
+            self.index[n] = (off, p.numel(), p.shape)
+            off += (p.numel() + 7) // 8 * 8          # keep every tensor 16-B aligned
+        self.numel = off
+        self.params = torch.zeros(off, device=dev, dtype=torch.bfloat16)
+        self.grads = torch.zeros(off, device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            for n, p in entries:
+                o, k, shape = self.index[n]
+                view = self.params[o:o + k].view(shape)
+                view.copy_(p.data)
+                p.data = view
+        for mod in (model.llm, model.vision_tower, model.mm_projector):
+            mod._cstruct = None
+        self.master = self.m = self.v = None
+        if with_optimizer_state:
+            self.master = self.params.float()
+            self.m = torch.zeros_like(self.master)
+            self.v = torch.zeros_like(self.master)
+        self.step_count = 0
+
+    def grad(self, name: str) -> torch.Tensor:
+        o, k, shape = self.index[name]
+        return self.grads[o:o + k].view(shape)
+
+    def param(self, name: str) -> torch.Tensor:
+        o, k, shape = self.index[name]
+        return self.params[o:o + k].view(shape)
+
+    def span(self, prefix: str) -> Tuple[int, int]:
+        """[start, end) of the contiguous slice holding every tensor whose name starts with `prefix`."""
+        offs = [(o, o + (k + 7) // 8 * 8) for n, (o, k, _) in self.index.items() if n.startswith(prefix)]
+        return min(a for a, _ in offs), max(b for _, b in offs)
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        return {n: self.grad(n) for n in self.index}
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of slices of the flat gradient buffer, one bucket per layer, issued as soon as the layer's
+    backward has been enqueued (DDP-style overlap; RCCL runs on its own stream, ordered after the compute stream at call time).
+    With no process group (single GPU) it only records the order — which the CPU/gloo test checks."""
+
+    def __init__(self, flat: FlatParams, group=None):
+        self.flat = flat
+        self.group = group
+        self.handles = []
+        self.log: List[Tuple[str, int, int]] = []
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+
+    def ready(self, prefix: str) -> None:
+        a, b = self.flat.span(prefix)
+        self.log.append((prefix, a, b))
+        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+            self.handles.append(self.dist.all_reduce(self.flat.grads[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self) -> None:
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# linear layer helpers: y = x W^T (+b);  dx = dy W ; dW = dy^T x ; db = colsum(dy)
+# ----------------------------------------------------------------------------------------------------------------------
+def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor] = None,
+               need_dx: bool = True, dx_residual: Optional[torch.Tensor] = None, dy_t: Optional[torch.Tensor] = None):
+    """x2 [M,K], w [N,K], dy2 [M,N]  ->  writes gw [N,K] (and gb [N]); returns dx [M,K] (+ dx_residual)."""
+    dyt = dy_t if dy_t is not None else ops.transpose(dy2)           # [N, Mp]
+    xt = ops.transpose(x2)                                           # [K, Mp]
+    ops.gemm(dyt, xt, out=gw.view(w.shape[0], -1) if gw.dim() != 2 else gw)      # dW = dY^T X
+    if gb is not None:
+        ops.colsum(dy2, gb)
+    if not need_dx:
+        return None
+    wt = ops.transpose(w.view(w.shape[0], -1))                       # [K, N]
+    return ops.gemm(dy2, wt, residual=dx_residual)                   # dX = dY W (+ residual)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the trainer
+# ----------------------------------------------------------------------------------------------------------------------
+class SFTTrainer:
+    def __init__(self, model, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_grad_norm: Optional[float] = None, optimizer_state: bool = True, group=None):
+        self.model = model
+        self.cfg = model.cfg
+        self.flat = FlatParams(model, with_optimizer_state=optimizer_state)
+        self.reducer = GradReducer(self.flat, group)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.group = group
+
+    # ------------------------------------------------------------------ ViT ------------------------------------------------
+    def _vit_fwd(self, pixels: torch.Tensor):
+        v = self.cfg.vision
+        P = self.flat.param
+        pre = "vision_tower.vision_tower.vision_model."
+        B = pixels.shape[0]
+        N, D, hd = v.num_patches, v.hidden_size, v.head_dim
+        Kc = v.num_channels * v.patch_size * v.patch_size
+        Kp = (Kc + 7) // 8 * 8
+        patches = ops.im2col(pixels, v.patch_size, Kp)                                   # [B*N, Kp]
+        wpad = torch.zeros((D, Kp), device=pixels.device, dtype=torch.bfloat16)
+        wpad[:, :Kc] = P(pre + "embeddings.patch_embedding.weight").view(D, Kc)
+        pos = P(pre + "embeddings.position_embedding.weight")
+        x = torch.empty((B * N, D), device=pixels.device, dtype=torch.bfloat16)
+        for b in range(B):
+            ops.gemm(patches[b * N:(b + 1) * N], wpad, bias=P(pre + "embeddings.patch_embedding.bias"), residual=pos, out=x[b * N:(b + 1) * N])
+        saved = SimpleNamespace(patches=patches, layers=[], B=B)
+        for i in range(v.num_used_layers):
+            l = f"{pre}encoder.layers.{i}."
+            s = SimpleNamespace(x_in=x)
+            s.h1 = ops.layernorm(x, P(l + "layer_norm1.weight"), P(l + "layer_norm1.bias"), v.layer_norm_eps)
+            wqkv = self._fused(l + "self_attn.", "weight")
+            bqkv = self._fused(l + "self_attn.", "bias")
+            s.qkv = ops.gemm(s.h1, wqkv, bias=bqkv)
+            q3 = s.qkv.view(B * N, 3 * v.num_attention_heads, hd)
+            H = v.num_attention_heads
+            s.a, s.lse = ops.attn_fwd(q3[:, :H], q3[:, H:2 * H], q3[:, 2 * H:], False, n_seq=B, return_lse=True)
+            s.x_mid = ops.gemm(s.a.view(B * N, D), P(l + "self_attn.out_proj.weight"), bias=P(l + "self_attn.out_proj.bias"), residual=x)
+            s.h2 = ops.layernorm(s.x_mid, P(l + "layer_norm2.weight"), P(l + "layer_norm2.bias"), v.layer_norm_eps)
+            s.z1 = ops.gemm(s.h2, P(l + "mlp.fc1.weight"), bias=P(l + "mlp.fc1.bias"))
+            s.f = ops.act_fwd(s.z1, 1)
+            x = ops.gemm(s.f, P(l + "mlp.fc2.weight"), bias=P(l + "mlp.fc2.bias"), residual=s.x_mid)
+            saved.layers.append(s)
+        return x.view(B, N, D), saved
+
+    def _fused(self, prefix: str, kind: str) -> torch.Tensor:
+        """the fused [q+2kv, ...] view of q_proj/k_proj/v_proj (adjacent in the flat buffer)."""
+        o, k, shape = self.flat.index[prefix + "q_proj." + kind]
+        o2, k2, shape2 = self.flat.index[prefix + "v_proj." + kind]
+        rows = (o2 + k2 - o) // (shape[1] if len(shape) == 2 else 1)
+        t = self.flat.params[o:o2 + k2]
+        return t.view(rows, shape[1]) if len(shape) == 2 else t
+
+    def _fused_grad(self, prefix: str, kind: str) -> torch.Tensor:
+        o, k, shape = self.flat.index[prefix + "q_proj." + kind]
+        o2, k2, _ = self.flat.index[prefix + "v_proj." + kind]
+        t = self.flat.grads[o:o2 + k2]
+        return t.view(-1, shape[1]) if len(shape) == 2 else t
+
+    def _vit_bwd(self, dx: torch.Tensor, saved) -> None:
+        v = self.cfg.vision
+        P, G = self.flat.param, self.flat.grad
+        pre = "vision_tower.vision_tower.vision_model."
+        B, N, D, hd, H = saved.B, v.num_patches, v.hidden_size, v.head_dim, v.num_attention_heads
+        for i in reversed(range(v.num_used_layers)):
+            l = f"{pre}encoder.layers.{i}."
+            s = saved.layers[i]
+            df = linear_bwd(s.f, P(l + "mlp.fc2.weight"), dx, G(l + "mlp.fc2.weight"), G(l + "mlp.fc2.bias"))
+            dz1 = ops.act_bwd(s.z1, df, 1)
+            dh2 = linear_bwd(s.h2, P(l + "mlp.fc1.weight"), dz1, G(l + "mlp.fc1.weight"), G(l + "mlp.fc1.bias"))
+            dxm = ops.norm_bwd(s.x_mid, P(l + "layer_norm2.weight"), dh2, G(l + "layer_norm2.weight"), G(l + "layer_norm2.bias"), v.layer_norm_eps, False)
+            dx_mid = ops.add(dx, dxm)
+            da = linear_bwd(s.a.view(B * N, D), P(l + "self_attn.out_proj.weight"), dx_mid, G(l + "self_attn.out_proj.weight"), G(l + "self_attn.out_proj.bias"))
+            dqkv = torch.empty_like(s.qkv)
+            q3, d3 = s.qkv.view(B * N, 3 * H, hd), dqkv.view(B * N, 3 * H, hd)
+            ops.attn_bwd(q3[:, :H], q3[:, H:2 * H], q3[:, 2 * H:], s.a, da.view(B * N, H, hd), s.lse, False,
+                         d3[:, :H], d3[:, H:2 * H], d3[:, 2 * H:], n_seq=B)
+            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"))
+            dxi = ops.norm_bwd(s.x_in, P(l + "layer_norm1.weight"), dh1, G(l + "layer_norm1.weight"), G(l + "layer_norm1.bias"), v.layer_norm_eps, False)
+            dx = ops.add(dx_mid, dxi)
+            self.reducer.ready(l)
+        # patch embedding: weight (unpadded), bias, position embedding (sum over images)
+        Kc = v.num_channels * v.patch_size * v.patch_size
+        gw = torch.empty((D, saved.patches.shape[1]), device=dx.device, dtype=torch.bfloat16)
+        ops.gemm(ops.transpose(dx), ops.transpose(saved.patches), out=gw)
+        G(pre + "embeddings.patch_embedding.weight").view(D, Kc).copy_(gw[:, :Kc])
+        ops.colsum(dx, G(pre + "embeddings.patch_embedding.bias"))
+        ops.colsum(dx, G(pre + "embeddings.position_embedding.weight"), period=N)
+        # unused parameters (27th layer, post_layernorm) keep zero gradients (hidden_states[-2]: vision_encoder.py:44-52)
+        self.reducer.ready(pre + "embeddings.")
+
+    # ------------------------------------------------------------------ projector ----------------------------------------
+    def _proj_fwd(self, feats: torch.Tensor):
+        P = self.flat.param
+        t = self.cfg.mm_projector_type
+        k = self.cfg.downsample
+        pre = "mm_projector.layers."
+        s = SimpleNamespace(g=int(round(feats.shape[1] ** 0.5)), k=k)
+        s.y = ops.space_to_depth(feats, k)
+        B, T, C1 = s.y.shape
+        y2 = s.y.view(B * T, C1)
+        s.yn = ops.layernorm(y2, P(pre + "1.weight"), P(pre + "1.bias"), 1e-5)
+        s.z1 = ops.gemm(s.yn, P(pre + "2.weight"), bias=P(pre + "2.bias"))
+        s.h1 = ops.act_fwd(s.z1, 2)
+        if t == "mlp_downsample_3x3_fix":
+            s.h1n = ops.layernorm(s.h1, P(pre + "4.weight"), P(pre + "4.bias"), 1e-5)
+            s.z2 = ops.gemm(s.h1n, P(pre + "5.weight"), bias=P(pre + "5.bias"))
+            s.h2 = ops.act_fwd(s.z2, 2)
+            out = ops.gemm(s.h2, P(pre + "7.weight"), bias=P(pre + "7.bias"))
+        else:
+            out = ops.gemm(s.h1, P(pre + "4.weight"), bias=P(pre + "4.bias"))
+        return out.view(B, T, -1), s
+
+    def _proj_bwd(self, dout: torch.Tensor, s) -> torch.Tensor:
+        P, G = self.flat.param, self.flat.grad
+        pre = "mm_projector.layers."
+        B, T, _ = s.y.shape
+        d = dout.reshape(B * T, -1)
+        if self.cfg.mm_projector_type == "mlp_downsample_3x3_fix":
+            dh2 = linear_bwd(s.h2, P(pre + "7.weight"), d, G(pre + "7.weight"), G(pre + "7.bias"))
+            dz2 = ops.act_bwd(s.z2, dh2, 2)
+            dh1n = linear_bwd(s.h1n, P(pre + "5.weight"), dz2, G(pre + "5.weight"), G(pre + "5.bias"))
+            dh1 = ops.norm_bwd(s.h1, P(pre + "4.weight"), dh1n, G(pre + "4.weight"), G(pre + "4.bias"), 1e-5, False)
+        else:
+            dh1 = linear_bwd(s.h1, P(pre + "4.weight"), d, G(pre + "4.weight"), G(pre + "4.bias"))
+        dz1 = ops.act_bwd(s.z1, dh1, 2)
+        dyn = linear_bwd(s.yn, P(pre + "2.weight"), dz1, G(pre + "2.weight"), G(pre + "2.bias"))
+        dy = ops.norm_bwd(s.y.view(B * T, -1), P(pre + "1.weight"), dyn, G(pre + "1.weight"), G(pre + "1.bias"), 1e-5, False)
+        self.reducer.ready("mm_projector.")
+        return ops.depth_to_space(dy.view(B, T, -1), s.g, s.k)
+
+    # ------------------------------------------------------------------ LLM ----------------------------------------------
+    def _llm_fwd(self, x: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_seqlen: int):
+        c = self.cfg.llm
+        P = self.flat.param
+        T = x.shape[0]
+        nq, nkv, hd = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        cs, sn = ops.rope_table(pos, hd, c.rope_theta)
+        saved = SimpleNamespace(layers=[], cs=cs, sn=sn, cu=cu, max_seqlen=max_seqlen)
+        for i in range(c.num_hidden_layers):
+            l = f"llm.model.layers.{i}."
+            s = SimpleNamespace(x_in=x)
+            s.h1 = ops.rmsnorm(x, P(l + "input_layernorm.weight"), c.rms_norm_eps)
+            s.qkv = ops.gemm(s.h1, self._fused(l + "self_attn.", "weight"), bias=self._fused(l + "self_attn.", "bias"))
+            ops.rope_fwd_(s.qkv, cs, sn, pos, nq, nkv, hd)
+            q3 = s.qkv.view(T, nq + 2 * nkv, hd)
+            s.a, s.lse = ops.attn_fwd(q3[:, :nq], q3[:, nq:nq + nkv], q3[:, nq + nkv:], True, cu_seqlens=cu, max_seqlen=max_seqlen, return_lse=True)
+            s.x_mid = ops.gemm(s.a.view(T, nq * hd), P(l + "self_attn.o_proj.weight"), residual=x)
+            s.h2 = ops.rmsnorm(s.x_mid, P(l + "post_attention_layernorm.weight"), c.rms_norm_eps)
+            s.g = ops.gemm(s.h2, P(l + "mlp.gate_proj.weight"))
+            s.u = ops.gemm(s.h2, P(l + "mlp.up_proj.weight"))
+            s.act = ops.silu_mul(s.g, s.u)
+            x = ops.gemm(s.act, P(l + "mlp.down_proj.weight"), residual=s.x_mid)
+            saved.layers.append(s)
+        saved.x_out = x
+        saved.hn = ops.rmsnorm(x, P("llm.model.norm.weight"), c.rms_norm_eps)
+        return saved
+
+    def _llm_bwd(self, dx: torch.Tensor, saved) -> torch.Tensor:
+        c = self.cfg.llm
+        P, G = self.flat.param, self.flat.grad
+        T = dx.shape[0]
+        nq, nkv, hd = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        for i in reversed(range(c.num_hidden_layers)):
+            l = f"llm.model.layers.{i}."
+            s = saved.layers[i]
+            dact = linear_bwd(s.act, P(l + "mlp.down_proj.weight"), dx, G(l + "mlp.down_proj.weight"))
+            dg, du = ops.silu_mul_bwd(s.g, s.u, dact)
+            dh2 = linear_bwd(s.h2, P(l + "mlp.gate_proj.weight"), dg, G(l + "mlp.gate_proj.weight"))
+            dh2 = linear_bwd(s.h2, P(l + "mlp.up_proj.weight"), du, G(l + "mlp.up_proj.weight"), dx_residual=dh2)
+            dxm = ops.norm_bwd(s.x_mid, P(l + "post_attention_layernorm.weight"), dh2, G(l + "post_attention_layernorm.weight"), None, c.rms_norm_eps, True)
+            dx_mid = ops.add(dx, dxm)
+            da = linear_bwd(s.a.view(T, nq * hd), P(l + "self_attn.o_proj.weight"), dx_mid, G(l + "self_attn.o_proj.weight"))
+            dqkv = torch.empty_like(s.qkv)
+            q3, d3 = s.qkv.view(T, nq + 2 * nkv, hd), dqkv.view(T, nq + 2 * nkv, hd)
+            ops.attn_bwd(q3[:, :nq], q3[:, nq:nq + nkv], q3[:, nq + nkv:], s.a, da.view(T, nq, hd), s.lse, True,
+                         d3[:, :nq], d3[:, nq:nq + nkv], d3[:, nq + nkv:], cu_seqlens=saved.cu, max_seqlen=saved.max_seqlen)
+            ops.rope_bwd_(dqkv, saved.cs, saved.sn, nq, nkv, hd)
+            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"))
+            dxi = ops.norm_bwd(s.x_in, P(l + "input_layernorm.weight"), dh1, G(l + "input_layernorm.weight"), None, c.rms_norm_eps, True)
+            dx = ops.add(dx_mid, dxi)
+            self.reducer.ready(l)
+        return dx
+
+    # ------------------------------------------------------------------ the step -------------------------------------------
+    def forward_backward(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
+                         attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None) -> torch.Tensor:
+        """Forward + backward of the packed batch; gradients land in self.flat.grads (already all-reduced when DP > 1).
+        Returns the (local) loss = sum CE / num_items_in_batch as a device scalar."""
+        model, cfg, flat = self.model, self.cfg, self.flat
+        dev = model.device
+        P, G = flat.param, flat.grad
+        flat.grads.zero_()
+        self.reducer.log.clear()
+        c = cfg.llm
+        H = c.hidden_size
+        # ---- vision + projector (+ "\n" end token) ----
+        pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16) if len(images) else None
+        n_img = 0 if pixels is None else pixels.shape[0]
+        if n_img:
+            feats, vit_saved = self._vit_fwd(pixels)
+            proj, proj_saved = self._proj_fwd(feats)                                   # [n_img, T', H]
+            Tm = proj.shape[1]
+        else:
+            Tm = 0
+        table = P("llm.model.embed_tokens.weight")
+        # ---- splice + pack (llava_arch.py:412-490, 744-800) ----
+        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right")
+        rp = repack(plan.mask, plan.labels)
+        T = int(rp.rows.numel())
+        # packed row index of every padded-grid position
+        inv = torch.full((plan.B * plan.S,), -1, dtype=torch.int64, device=rp.rows.device)
+        inv[rp.rows] = torch.arange(T, device=rp.rows.device)
+        txt_dst = inv[plan.txt_dst.long()].to(torch.int32).to(dev)
+        x0 = torch.empty((T, H), device=dev, dtype=torch.bfloat16)
+        ops.copy_rows(table, x0, plan.txt_src.to(dev), txt_dst, int(txt_dst.numel()))
+        if n_img:
+            img_dst = inv[plan.img_dst.long()].view(n_img, Tm + 1).to(torch.int32).to(dev)
+            feat_dst = img_dst[:, :Tm].reshape(-1).contiguous()
+            nl_dst = img_dst[:, Tm].contiguous()
+            ops.copy_rows(proj.reshape(n_img * Tm, H), x0, None, feat_dst, n_img * Tm)
+            nl_src = torch.full((n_img,), cfg.newline_token_id, dtype=torch.int32, device=dev)
+            ops.copy_rows(table, x0, nl_src, nl_dst, n_img)
+        pos = rp.position_ids.to(dev)
+        cu = rp.cu_seqlens.to(dev)
+        lab = rp.labels.to(dev)
+        # ---- LLM ----
+        saved = self._llm_fwd(x0, pos, cu, rp.max_seqlen)
+        # ---- loss on the rows that have a target (HF ForCausalLMLoss: shift by one inside each packed row) ----
+        tgt = torch.full((T,), IGNORE_INDEX, dtype=torch.int64, device=dev)
+        tgt[:-1] = lab[1:]
+        valid = torch.nonzero(tgt != IGNORE_INDEX, as_tuple=False).flatten()
+        n_valid = int(valid.numel())
+        n_items = n_valid if num_items_in_batch is None else int(num_items_in_batch)
+        loss = torch.zeros((1,), device=dev, dtype=torch.float32)
+        dhn = torch.zeros((T, H), device=dev, dtype=torch.bfloat16)
+        head_name = "llm.model.embed_tokens.weight" if c.tie_word_embeddings else "llm.lm_head.weight"
+        head = P(head_name)
+        if n_valid:
+            rows32 = valid.to(torch.int32)
+            hv = torch.empty((n_valid, H), device=dev, dtype=torch.bfloat16)
+            ops.copy_rows(saved.hn, hv, rows32, None, n_valid)
+            logits = ops.gemm(hv, head, out_f32=True)                                    # [n_valid, V] fp32 only
+            dlog = ops.ce_loss(logits, tgt[valid].contiguous(), loss, 1.0 / max(n_items, 1))
+            del logits
+            dhv = linear_bwd(hv, head, dlog, G(head_name))
+            ops.copy_rows(dhv, dhn, None, rows32, n_valid)
+        if not c.tie_word_embeddings:
+            self.reducer.ready("llm.lm_head.")
+        dx = ops.norm_bwd(saved.x_out, P("llm.model.norm.weight"), dhn, G("llm.model.norm.weight"), None, c.rms_norm_eps, True)
+        self.reducer.ready("llm.model.norm.")
+        dx0 = self._llm_bwd(dx, saved)
+        # ---- embedding rows (text + "\n") and media rows ----
+        ge = G("llm.model.embed_tokens.weight")
+        dtxt = torch.empty((int(txt_dst.numel()), H), device=dev, dtype=torch.bfloat16)
+        ops.copy_rows(dx0, dtxt, txt_dst, None, int(txt_dst.numel()))
+        ops.scatter_add_rows(dtxt, ge, plan.txt_src.to(dev))
+        if n_img:
+            dnl = torch.empty((n_img, H), device=dev, dtype=torch.bfloat16)
+            ops.copy_rows(dx0, dnl, nl_dst, None, n_img)
+            ops.scatter_add_rows(dnl, ge, nl_src)
+        self.reducer.ready("llm.model.embed_tokens.")
+        if n_img:
+            dproj = torch.empty((n_img * Tm, H), device=dev, dtype=torch.bfloat16)
+            ops.copy_rows(dx0, dproj, feat_dst, None, n_img * Tm)
+            dfeats = self._proj_bwd(dproj.view(n_img, Tm, H), proj_saved)
+            self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
+        self.reducer.wait()
+        return loss[0]
+
+    def optimizer_step(self) -> None:
+        f = self.flat
+        f.step_count += 1
+        scale = 1.0
+        if self.max_grad_norm is not None:
+            norm = float(ops.sumsq(f.grads).sqrt())
+            scale = min(1.0, self.max_grad_norm / (norm + 1e-6))
+        ops.adamw_step(f.master, f.m, f.v, f.grads, f.params, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, scale)
+
+    def global_num_items(self, labels_packed_valid: int) -> int:
+        """Token count summed over ranks (transformer_normalize_monkey_patch.py:261-263)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            t = torch.tensor([labels_packed_valid], device=self.model.device, dtype=torch.int64)
+            dist.all_reduce(t, group=self.group)
+            return int(t.item())
+        return labels_packed_valid
+
+    def step(self, input_ids, images, labels, attention_mask=None) -> float:
+        n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
+        n_global = self.global_num_items(n_local)
+        loss = self.forward_backward(input_ids, images, labels, attention_mask, n_global)
+        self.optimizer_step()
+        return loss
+
+
+def count_targets(input_ids, labels, attention_mask, image_token_id: int) -> int:
+    """Number of label positions that survive the shift + first-label masking of the packed row (host integer work)."""
+    mask = attention_mask.bool() if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
+    n = 0
+    for k in range(input_ids.shape[0]):
+        ids_k, lab_k = input_ids[k][mask[k]], labels[k][mask[k]]
+        keep = (ids_k != image_token_id) & (lab_k != IGNORE_INDEX)
+        keep[0] = False                       # first token of a sample is never a target (llava_arch.py:760-762 + HF shift)
+        n += int(keep.sum())
+    return n
