@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-decode", action="store_true", help="experiment: launch the 171 kernels per token eagerly instead of replaying a hipGraph")
     ap.add_argument("--config", default="nvila_8b", choices=["nvila_8b", "reduced"])
+    ap.add_argument("--mode", default="decode", choices=["decode", "sft"],
+                    help="decode = BASELINE.json metric (default); sft = one data-parallel SFT step (BASELINE configs[2])")
+    ap.add_argument("--micro-batch", type=int, default=4)
     return ap.parse_args()
 
 
@@ -85,6 +88,54 @@ def cpu_baseline(cfg, n_prompt: int, threads: int):
             "prefill_s_sample": round(t_prefill, 3)}
 
 
+def sft_main(a, rank, local, world, dev, dist):
+    """BASELINE configs[2]: NVILA-8B SFT step, per-GPU micro-batch of b samples (1 x 448^2 image + 512 text tokens, S = 769,
+    packed), labels on the last 256 text positions, all 8.06 B params trainable, AdamW lr 2e-5; weak scaling over ranks."""
+    from vila_amd import configs, synthetic
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import build_model
+    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    model = build_model(cfg, seed=0, device=dev)
+    tr = SFTTrainer(model, lr=2e-5, weight_decay=0.0)
+    b = a.micro_batch
+    pixels = synthetic.make_pixels(cfg, b, rank, device=dev, dtype=torch.bfloat16)
+    ids = torch.stack([synthetic.make_prompt(cfg, a.prompt_tokens, 1, 10 * rank + i) for i in range(b)], 0)
+    labels = ids.clone()
+    labels[:, : 1 + a.prompt_tokens - 256] = -100
+    S = cfg.tokens_per_tile + 1 + a.prompt_tokens
+    images = [pixels[i] for i in range(b)]
+    for _ in range(a.warmup):
+        loss = tr.step(ids, images, labels)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(ids, images, labels)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        step_s = elapsed / a.steps
+        flops = 35.8e12 * b              # BASELINE.md §2: fwd+bwd per 769-token sample, no recompute
+        print(json.dumps({
+            "metric": "SFT step throughput, NVILA-8B, packed 1x448^2 image + 512-token samples", "value": round(world * b * S / step_s, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 master/AdamW state)",
+            "data": "synthetic", "loss": round(float(loss), 4),
+            "config": {"workload": f"{cfg.name} SFT step, micro-batch {b} x S={S} packed, all params trainable, AdamW", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(flops / step_s / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / step_s / 2.5e15, 4), "traffic": None,
+                         "note": "whole step incl. optimizer and transposes; 35.8 TFLOP per sample (SURVEY §8d)"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -100,6 +151,10 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
 
+    if a.mode == "sft":
+        if a.steps == 128 and a.warmup == 16:
+            a.steps, a.warmup = 3, 1
+        return sft_main(a, rank, local, world, dev, dist)
     from vila_amd import _lib, configs, ops, synthetic
     from vila_amd.vlm import build_model
     lib = _lib.load()
