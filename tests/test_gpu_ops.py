@@ -43,6 +43,28 @@ def test_gemm_plain_bias_residual(ops, M, N, K):
     assert rel_l2(out32, ref) < 2e-5, f"fp32-out rel={rel_l2(out32, ref):.3e}"
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 136), (769, 3584, 512), (1, 24, 40), (3076, 1088, 512), (513, 260, 72), (700, 520, 128)])
+def test_gemm_every_tile_shape(ops, tile, M, N, K):
+    """The three tile shapes (128x128, 128x64, 256x128) must agree with the fp32 reference on every epilogue."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    a = randn_bf16(M, K, seed=41)
+    w = randn_bf16(N, K, seed=42, scale=K ** -0.5)
+    w2 = randn_bf16(N, K, seed=43, scale=K ** -0.5)
+    bias, res = randn_bf16(N, seed=44), randn_bf16(M, N, seed=45)
+    ref = a.float() @ w.float().t()
+    lib.vila_gemm_force_tile(tile)
+    try:
+        assert rel_l2(ops.gemm(a, w, bias=bias, residual=res), ref + bias.float() + res.float()) < 4e-3
+        assert rel_l2(ops.gemm(a, w, out_f32=True), ref) < 2e-5
+        assert rel_l2(ops.gemm(a, w, bias=bias, epi=1), torch.nn.functional.gelu(ref + bias.float(), approximate="tanh")) < 5e-3
+        gu = torch.nn.functional.silu(ref) * (a.float() @ w2.float().t())
+        assert rel_l2(ops.gemm(a, w, w2=w2, epi=3), gu) < 5e-3
+    finally:
+        lib.vila_gemm_force_tile(0)
+
+
 def test_gemm_detects_transpose_and_identity(ops):
     """A = I with an asymmetric W must give exactly W^T rows (guide rule: symmetric inputs hide a swapped C layout)."""
     n = 256

@@ -25,6 +25,22 @@ def rnd(*s, scale=1.0):
     return (torch.randn(*s, device="cuda") * scale).to(torch.bfloat16)
 
 
+def bench_gemm_tiles():
+    from vila_amd import _lib
+    lib = _lib.load()
+    print("== GEMM tile shapes (TFLOP/s): auto | 128x128 | 128x64 | 256x128 | 256x256dma ==")
+    for M, N, K in [(769, 4608, 3584), (769, 3584, 3584), (769, 3584, 18944), (1024, 1152, 1152), (1024, 1152, 4304), (1024, 4304, 1152),
+                    (3076, 3584, 3584), (3076, 3584, 18944), (3584, 3584, 3080), (18944, 3584, 3080), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        res = []
+        for tile in (0, 1, 2, 3, 4):
+            lib.vila_gemm_force_tile(tile)
+            t = timeit(lambda: ops.gemm(a, w), iters=10)
+            res.append(2.0 * M * N * K / t / 1e12)
+        lib.vila_gemm_force_tile(0)
+        print(f"M={M:5d} N={N:6d} K={K:6d}: " + " | ".join(f"{r:7.1f}" for r in res))
+
+
 def bench_gemm():
     print("== GEMM bf16 (TFLOP/s) ==")
     for M, N, K, epi in [(769, 4608, 3584, 0), (769, 3584, 3584, 0), (769, 18944, 3584, 3), (769, 3584, 18944, 0),
@@ -63,6 +79,8 @@ def bench_attn():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
+    if what in ("tiles",):
+        bench_gemm_tiles()
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemv", "all"):

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "vila_graph_destroy": (c_int, [c_void_p]),
     "vila_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vila_gemm_force_tile": (None, [c_int]),
     "vila_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "vila_rmsnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "vila_space_to_depth_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

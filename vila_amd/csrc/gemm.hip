@@ -1,55 +1,72 @@
-// bf16 MFMA GEMM for the prefill / ViT / projector / lm_head contractions (SURVEY.md §8 rows a2,a3,a5,a10,a11).
+// bf16 MFMA GEMM for the prefill / ViT / projector / lm_head contractions and the dgrad / wgrad GEMMs of the SFT step
+// (SURVEY.md §8 rows a2,a3,a5,a10,a11,a13).
 //
 //   C[M,N] = epi(A[M,K] . W[N,K]^T + bias) (+ residual)        nn.Linear layout: W is [out,in] row-major,
 //   so BOTH operands are K-contiguous = the natural MFMA A/B fragment layout (8 consecutive k per lane).
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 fragments.
-// HBM -> registers -> LDS (XOR-swizzled 16-B slots, double buffered, one barrier per K-tile; loads for tile t+1
-// are issued before the MFMAs of tile t and written to LDS after them).  Epilogue goes through LDS so that the
+// One kernel template, three tile shapes (waves are WM x 2, each wave owns 64 x (16*NF) of C as 4 x NF
+// v_mfma_f32_16x16x32_bf16 fragments, K-tile 64):
+//     256 x 128  (8 waves)  M >= 1536: SFT-step shapes; halves the B-tile bytes per flop (the 128^2 tile is exactly
+//                           L1/LDS-bound on gfx950: 32 KB per K-tile at 64 B/clk == its 512 MFMA cycles)
+//     128 x 128  (4 waves)  default
+//     128 x  64  (4 waves)  small grids (S = 769 prefill with N <= 4608: 196 tiles of 128^2 cannot fill 256 CUs)
+// HBM -> registers -> LDS (XOR-swizzled 16-B slots, double buffered, one barrier per K-tile; loads for tile t+1 are
+// issued before the MFMAs of tile t and written to LDS after them).  The epilogue goes through LDS so that the
 // residual read and the C write are full-row coalesced (8 / 16 B per lane).
-// Roofline: MFMA-bound at M >= 256 (2*M*N*K flop vs (M+N)*K*2 + M*N*2 bytes).
+// Roofline: MFMA (2*M*N*K flop vs (M+N)*K*2 + M*N*2 bytes).
 #include "kernels.h"
 
-#define BM 128
 #define BK 64
 #define STG 68  // fp32 staging row stride (floats)
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) {
+template <int EPI, bool OUT_F32, int WM, int NF>
+__global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) {
+    constexpr int THREADS = WM * 128;
+    constexpr int BM = WM * 64;              // rows of C per block
+    constexpr int BNT = 32 * NF;             // B-tile rows held in LDS (2 waves x 16*NF)
+    constexpr int A_IT = BM * 8 / THREADS;   // 16-B chunks per thread and K-tile
+    constexpr int B_IT = (BNT * 8 + THREADS - 1) / THREADS;
+    constexpr int RSTEP = THREADS / 8;       // rows covered per staging pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* sA = (bf16_t*)smem;         // [2][128][64]
-    bf16_t* sB = sA + 2 * BM * BK;      // [2][128][64]
-    float* stage = (float*)smem;        // epilogue reuse: [4][64][STG]
+    bf16_t* sA = (bf16_t*)smem;              // [2][BM][64]
+    bf16_t* sB = sA + 2 * BM * BK;           // [2][BNT][64]
+    float* stage = (float*)smem;             // epilogue reuse: [waves][64][STG]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id % tiles_m, tn = id / tiles_m;
-    constexpr int BN_OUT = (EPI == EPI_GATEUP) ? 64 : 128;
+    constexpr int WN = 16 * NF;                                   // C columns per wave held in registers
+    constexpr int WN_OUT = (EPI == EPI_GATEUP) ? WN / 2 : WN;     // C columns per wave written
+    constexpr int BN_OUT = 2 * WN_OUT;
     const int m0 = tm * BM, n0 = tn * BN_OUT;
     const int M = p.M, N = p.N, K = p.K;
 
-    // ---- staging coordinates: thread owns 16-B chunk (row = r0 + 32 i, kc) of both tiles ----
+    // ---- staging coordinates: thread owns 16-B chunk (row = r0 + RSTEP*i, kc) ----
     const int kc = tid & 7, r0 = tid >> 3;
-    const int sw = kc ^ ((r0 >> 1) & 7);
-    const bf16_t* a_ptr[4];
-    const bf16_t* b_ptr[4];
+    const int sw = kc ^ ((r0 >> 1) & 7);     // RSTEP is a multiple of 16 => same swizzle for every pass
+    const bf16_t* a_ptr[A_IT];
+    const bf16_t* b_ptr[B_IT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = r0 + 32 * i;
-        int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    for (int i = 0; i < A_IT; ++i) {
+        int gm = m0 + r0 + RSTEP * i; gm = gm < M ? gm : M - 1;
         a_ptr[i] = p.A + (int64_t)gm * p.lda + kc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = r0 + RSTEP * i;      // B-tile row: wave column = row / WN, fragment j = (row % WN) / 16
         if constexpr (EPI == EPI_GATEUP) {
-            const int j = (row >> 4) & 3;
-            int gn = n0 + (row >> 6) * 32 + (j & 1) * 16 + (row & 15); gn = gn < N ? gn : N - 1;
-            b_ptr[i] = ((j >> 1) ? p.W2 : p.W) + (int64_t)gn * p.ldw + kc * 8;
+            const int j = (row % WN) >> 4;
+            int gn = n0 + (row / WN) * WN_OUT + (j % (NF / 2)) * 16 + (row & 15); gn = gn < N ? gn : N - 1;
+            b_ptr[i] = ((j >= NF / 2) ? p.W2 : p.W) + (int64_t)gn * p.ldw + kc * 8;
         } else {
             int gn = n0 + row; gn = gn < N ? gn : N - 1;
             b_ptr[i] = p.W + (int64_t)gn * p.ldw + kc * 8;
         }
     }
-    const int st_off = r0 * BK + sw * 8;  // + 32*i*BK per chunk
+    const int st_off = r0 * BK + sw * 8;
+    const bool b_active = (B_IT * RSTEP == BNT) || (r0 < BNT);   // 128x64 tile with 256 threads: only half the threads stage B
 
     // ---- fragment read offsets (elements) ----
     const int sw_r = (l15 >> 1) & 7;
@@ -58,31 +75,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) 
     for (int ks = 0; ks < 2; ++ks) {
         const int kcc = ks * 4 + lg;
         a_off[ks] = (wr * 64 + l15) * BK + ((kcc ^ sw_r) << 3);
-        b_off[ks] = (wc * 64 + l15) * BK + ((kcc ^ sw_r) << 3);
+        b_off[ks] = (wc * WN + l15) * BK + ((kcc ^ sw_r) << 3);
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NF];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = (K + BK - 1) / BK;
-    u32x4 ra[4], rb[4];
+    u32x4 ra[A_IT], rb[B_IT];
     auto gload = [&](int t) {
         const int k0 = t * BK;
         const bool ok = (k0 + kc * 8) < K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = ok ? *(const u32x4*)(a_ptr[i] + k0) : (u32x4){0u, 0u, 0u, 0u};
-            rb[i] = ok ? *(const u32x4*)(b_ptr[i] + k0) : (u32x4){0u, 0u, 0u, 0u};
-        }
+        for (int i = 0; i < A_IT; ++i) ra[i] = ok ? *(const u32x4*)(a_ptr[i] + k0) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[i] = (ok && b_active) ? *(const u32x4*)(b_ptr[i] + k0) : (u32x4){0u, 0u, 0u, 0u};
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(sA + buf * BM * BK + st_off + 32 * i * BK) = ra[i];
-            *(u32x4*)(sB + buf * BM * BK + st_off + 32 * i * BK) = rb[i];
+        for (int i = 0; i < A_IT; ++i) *(u32x4*)(sA + buf * BM * BK + st_off + RSTEP * i * BK) = ra[i];
+        if (b_active) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) *(u32x4*)(sB + buf * BNT * BK + st_off + RSTEP * i * BK) = rb[i];
         }
     };
 
@@ -94,18 +111,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) 
         const int buf = t & 1;
         if (t + 1 < nt) gload(t + 1);
         const bf16_t* cA = sA + buf * BM * BK;
-        const bf16_t* cB = sB + buf * BM * BK;
+        const bf16_t* cB = sB + buf * BNT * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[NF];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(cA + a_off[ks] + i * 16 * BK);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(cB + b_off[ks] + j * 16 * BK);
+            for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(cB + b_off[ks] + j * 16 * BK);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nt) lstore(buf ^ 1);
@@ -114,29 +131,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) 
 
     // ---- epilogue: bias / activation in registers -> per-wave fp32 staging -> coalesced residual add + store ----
     float* wst = stage + wave * 64 * STG;
-    constexpr int WN = (EPI == EPI_GATEUP) ? 32 : 64;  // output columns per wave
-    const int ncol0 = n0 + wc * WN;
+    const int ncol0 = n0 + wc * WN_OUT;
     if constexpr (EPI == EPI_GATEUP) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NF / 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float g = acc[i][j][r], u = acc[i][j + 2][r];
+                    const float g = acc[i][j][r], u = acc[i][j + NF / 2][r];
                     wst[(i * 16 + lg * 4 + r) * STG + j * 16 + l15] = silu_f(g) * u;
                 }
     } else {
-        float bv[4];
+        float bv[NF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NF; ++j) {
             const int col = ncol0 + j * 16 + l15;
             bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bv[j];
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int LPR = WN / 4;          // lanes per output row
+    constexpr int LPR = WN_OUT / 4;      // lanes per output row
     constexpr int RPI = 64 / LPR;        // rows per pass
     const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
 #pragma unroll
@@ -172,20 +188,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn(GemmArgs p, int tiles_m) 
     }
 }
 
-template <int EPI, bool OUT_F32>
-static int launch_t(const GemmArgs& a, hipStream_t s) {
-    const int tiles_m = cdiv(a.M, BM);
-    const int bn = (EPI == EPI_GATEUP) ? 64 : 128;
-    const int tiles_n = cdiv(a.N, bn);
-    const size_t lds = 4 * 64 * STG * sizeof(float);  // 69632 >= 2*2*128*64*2
+template <int EPI, bool OUT_F32, int WM, int NF>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = WM * 64, BNT = 32 * NF;
+    constexpr int BN_OUT = (EPI == EPI_GATEUP) ? BNT / 2 : BNT;
+    const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN_OUT);
+    const size_t lds_main = (size_t)2 * (BM + BNT) * BK * 2, lds_epi = (size_t)WM * 2 * 64 * STG * sizeof(float);
+    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn<EPI, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn<EPI, OUT_F32, WM, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_tn<EPI, OUT_F32>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
+    hipLaunchKernelGGL((gemm_bf16_tn<EPI, OUT_F32, WM, NF>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, s, a, tiles_m);
     VILA_LAUNCH_CHECK();
     return 0;
+}
+
+bool gemm256_supported(const GemmArgs& a);
+int launch_gemm256(const GemmArgs& a, hipStream_t s);
+static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel
+extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
+
+template <int EPI, bool OUT_F32>
+static int launch_t(const GemmArgs& a, hipStream_t s) {
+    int sel = g_force_tile;
+    if (sel == 4 || (sel == 0 && (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) >= 150)) {
+        if (gemm256_supported(a)) return launch_gemm256(a, s);
+        if (sel == 4) sel = 0;
+    }
+    if (sel == 0) {
+        const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
+        if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;
+        else sel = 1;
+    }
+    if (sel == 2 && EPI == EPI_GATEUP) sel = 1;
+    if (sel == 3) return launch_cfg<EPI, OUT_F32, 4, 4>(a, s);
+    if constexpr (EPI != EPI_GATEUP) {
+        if (sel == 2) return launch_cfg<EPI, OUT_F32, 2, 2>(a, s);
+    }
+    return launch_cfg<EPI, OUT_F32, 2, 4>(a, s);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {

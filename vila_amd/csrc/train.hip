@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         }
     }
     __syncthreads();
-    const int Rp = (R + 7) & ~7;                    // output rows are padded to a multiple of 8 with zeros (wgrad contraction dim)
+    const int Rp = (int)ldo;                         // output columns [R, ldo) are zero-filled (padding of the wgrad contraction dim)
     for (int i = tid; i < 512; i += 256) {
         const int c = i >> 3, ch = i & 7;          // output row = input column
         const int gc = c0 + c, gr = r0 + ch * 8;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 }
 int launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, int64_t ldi, int64_t ldo, hipStream_t s) {
     VILA_REQUIRE(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && ldo >= ((R + 7) & ~7), "transpose: C (%d), ld must be multiples of 8 and ldo >= round_up(R,8)", C);
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, s, in, out, R, C, ldi, ldo);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv((int)ldo, 64)), dim3(256), 0, s, in, out, R, C, ldi, ldo);
     VILA_LAUNCH_CHECK();
     return 0;
 }

@@ -32,7 +32,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual   (nn.Linear semantics; EPI_GATEUP: silu(a w^T) * (a w2^T))."""
     _need(a, name="a"); _need(w, name="w")
-    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    # w may carry extra zero-padded columns (transpose() pads the contraction dim to 64): K is a's width
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] <= w.shape[1]
     M, K = a.shape
     N = w.shape[0]
     if out is None:
@@ -142,10 +143,11 @@ def _L():
 
 
 def transpose(x: torch.Tensor) -> torch.Tensor:
-    """[R, C] -> [C, round_up(R, 8)] (zero-padded): the K-contiguous operand form gemm() needs for dgrad / wgrad."""
+    """[R, C] -> [C, round_up(R, 64)] (zero-padded): the K-contiguous operand form gemm() needs for dgrad / wgrad
+    (64 = the K-tile of the 256x256 kernel, so the padded token dimension never needs a K tail)."""
     _need(x, name="x"); assert x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
-    Rp = (R + 7) // 8 * 8
+    Rp = (R + 63) // 64 * 64
     out = torch.empty((Cc, Rp), device=x.device, dtype=x.dtype)
     check(_L().vila_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), Rp, _stream()), "transpose")
     return out
