@@ -180,8 +180,8 @@ int vila_act_bwd_bf16(const void* z, const void* dy, void* dz, int64_t n, int ac
 int vila_silu_mul_fwd_bf16(const void* gate, const void* up, void* act, int64_t n, vila_stream_t stream);
 int vila_silu_mul_bwd_bf16(const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, vila_stream_t stream);
 int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_t stream);
-/* out[c] (+)= sum_r x[r][c]; period > 0: out[p][c] = sum over rows r == p (mod period)  (position-embedding gradient) */
-int vila_colsum_bf16(const void* x, void* out, int rows, int cols, int64_t ld, int accumulate, int period, vila_stream_t stream);
+/* out[c] (+)= sum_r x[r][c] (scratch: cols fp32); period > 0: out[p][c] = sum over rows r == p (mod period) (position-embedding gradient) */
+int vila_colsum_bf16(const void* x, void* out, float* scratch, int rows, int cols, int64_t ld, int accumulate, int period, vila_stream_t stream);
 /* LayerNorm (rms=0) / RMSNorm (rms=1) backward; scratch = 2*cols fp32 */
 int vila_norm_bwd_bf16(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, float* scratch, int rows, int cols,
                        float eps, int rms, int accumulate, vila_stream_t stream);

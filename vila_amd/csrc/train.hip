@@ -166,28 +166,75 @@ int launch_add(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream
 // column sums: out[c] (+)= sum_r x[r][c]  (bias / position-embedding gradients).  One block per 64 columns; each of the
 // 4 waves walks a quarter of the rows with lane = column; fp32 accumulate.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int R, int C, int64_t ld,
-                                                     int accumulate, int period) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int prow = blockIdx.y;                     // output row when period > 0: sums rows r with r % period == prow
-    float acc = 0.f;
-    if (c < C) {
-        if (period > 0) for (int r = prow + wave * period; r < R; r += 4 * period) acc += bf2f(x[(int64_t)r * ld + c]);
-        else for (int r = wave; r < R; r += 4) acc += bf2f(x[(int64_t)r * ld + c]);
+// stage 1: block = 128 columns x (R / gridDim.y) rows; thread = (row lane, 8-column chunk), 16-B loads, fp32 partials reduced
+// through LDS, one fp32 atomic per column and block into `scratch` (zeroed by the launcher); stage 2 converts to bf16.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ scratch, int R, int C, int64_t ld) {
+    __shared__ float part[16][132];
+    const int tid = threadIdx.x, cg = tid & 15, rl = tid >> 4;
+    const int c0 = blockIdx.x * 128 + cg * 8;
+    const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+    const int rb = blockIdx.y * rows_per, re = (rb + rows_per < R) ? rb + rows_per : R;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (c0 < C) {
+        for (int r = rb + rl; r < re; r += 16) {
+            const u32x4 v = *(const u32x4*)(x + (int64_t)r * ld + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += lo_bf(v[k]); acc[2 * k + 1] += hi_bf(v[k]); }
+        }
     }
-    part[wave][lane] = acc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[rl][cg * 8 + k] = acc[k];
     __syncthreads();
-    if (wave == 0 && c < C) {
-        float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        bf16_t* o = out + (int64_t)prow * C + c;
-        if (accumulate) v += bf2f(*o);
-        *o = f2bf(v);
+    if (tid < 128) {
+        const int c = blockIdx.x * 128 + tid;
+        if (c < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += part[r][tid];
+            atomicAdd(scratch + c, v);
+        }
     }
 }
-int launch_colsum(const bf16_t* x, bf16_t* out, int R, int C, int64_t ld, int accumulate, int period, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), period > 0 ? period : 1), dim3(256), 0, s, x, out, R, C, ld, accumulate, period);
+// out[p][c] (+)= sum_b x[b*period + p][c]   (position-embedding gradient: sum over images)
+__global__ void periodic_sum_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int nrep, int64_t n8, int accumulate) {
+    EW_LOOP(n8) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int b = 0; b < nrep; ++b) {
+            const u32x4 v = *(const u32x4*)(x + ((int64_t)b * n8 + i) * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += lo_bf(v[k]); acc[2 * k + 1] += hi_bf(v[k]); }
+        }
+        u32x4 o;
+        if (accumulate) {
+            const u32x4 p = *(const u32x4*)(out + i * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += lo_bf(p[k]); acc[2 * k + 1] += hi_bf(p[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(acc[2 * k], acc[2 * k + 1]);
+        *(u32x4*)(out + i * 8) = o;
+    }
+}
+__global__ void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int n, int accumulate);
+int launch_colsum(const bf16_t* x, bf16_t* out, float* scratch, int R, int C, int64_t ld, int accumulate, int period, hipStream_t s) {
+    VILA_REQUIRE(C % 8 == 0 && ld % 8 == 0, "colsum: C (%d) and ld must be multiples of 8", C);
+    if (period > 0) {
+        VILA_REQUIRE(R % period == 0 && ld == C, "colsum: periodic mode needs R %% period == 0 and a dense input");
+        const int64_t n8 = (int64_t)period * C / 8;
+        hipLaunchKernelGGL(periodic_sum_kernel, dim3(EW_GRID(n8)), dim3(256), 0, s, x, out, R / period, n8, accumulate);
+        VILA_LAUNCH_CHECK();
+        return 0;
+    }
+    VILA_REQUIRE(scratch != nullptr, "colsum: fp32 scratch of C floats required");
+    VILA_HIP(hipMemsetAsync(scratch, 0, (size_t)C * sizeof(float), s));
+    int gy = cdiv(R, 128); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 128), gy), dim3(256), 0, s, x, scratch, R, C, ld);
+    VILA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, scratch, out, C, accumulate);
     VILA_LAUNCH_CHECK();
     return 0;
 }
@@ -209,9 +256,18 @@ __device__ __forceinline__ float block_sum4(float v, float* scratch) {
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ dy,
                                                        bf16_t* __restrict__ dx, float* __restrict__ dw32, float* __restrict__ db32,
-                                                       int cols, float eps) {
+                                                       int rows, int cols, float eps) {
     __shared__ float scratch[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    // NORM_ROWS rows per block: dw/db partials of this thread's columns are summed over them in registers (cols <= 16384)
+    constexpr int NORM_ROWS = 8, MAXJ = 128;
+    float dwacc[MAXJ / 8], dbacc[MAXJ / 8];        // up to 16 column slots per thread (cols <= 4096) stay in registers; wider rows use atomics per row
+    const bool reg_acc = cols <= 256 * (MAXJ / 8);
+#pragma unroll
+    for (int j = 0; j < MAXJ / 8; ++j) { dwacc[j] = 0.f; dbacc[j] = 0.f; }
+  for (int rowi = 0; rowi < NORM_ROWS; ++rowi) {
+    const int row = blockIdx.x * NORM_ROWS + rowi;
+    if (row >= rows) break;
     const bf16_t* xr = x + (int64_t)row * cols;
     const bf16_t* gr = dy + (int64_t)row * cols;
     bf16_t* dr = dx + (int64_t)row * cols;
@@ -238,13 +294,31 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
     a = block_sum4(a, scratch);
     b = block_sum4(b, scratch);
     const float ma = RMS ? 0.f : a / cols, mb = b / cols;
-    for (int c = tid; c < cols; c += 256) {
+    int j = 0;
+    for (int c = tid; c < cols; c += 256, ++j) {
         const float xh = (bf2f(xr[c]) - mean) * rstd;
         const float dyv = bf2f(gr[c]);
         const float g = dyv * bf2f(w[c]);
         dr[c] = f2bf(rstd * (g - ma - xh * mb));
-        atomicAdd(dw32 + c, dyv * xh);
-        if (!RMS && db32 != nullptr) atomicAdd(db32 + c, dyv);
+        if (reg_acc) {
+#pragma unroll
+            for (int jj = 0; jj < MAXJ / 8; ++jj) if (jj == j) { dwacc[jj] += dyv * xh; dbacc[jj] += dyv; }
+        } else {
+            atomicAdd(dw32 + c, dyv * xh);
+            if (!RMS && db32 != nullptr) atomicAdd(db32 + c, dyv);
+        }
+    }
+    __syncthreads();
+  }
+    if (reg_acc) {
+#pragma unroll
+        for (int jj = 0; jj < MAXJ / 8; ++jj) {
+            const int c = tid + 256 * jj;
+            if (c < cols) {
+                atomicAdd(dw32 + c, dwacc[jj]);
+                if (!RMS && db32 != nullptr) atomicAdd(db32 + c, dbacc[jj]);
+            }
+        }
     }
 }
 __global__ void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int n, int accumulate) {
@@ -254,8 +328,8 @@ __global__ void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __
 int launch_norm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, float* scratch /*2*cols fp32*/,
                     int rows, int cols, float eps, int rms, int accumulate, hipStream_t s) {
     VILA_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * cols * sizeof(float), s));
-    if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(rows), dim3(256), 0, s, x, w, dy, dx, scratch, (float*)nullptr, cols, eps);
-    else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(rows), dim3(256), 0, s, x, w, dy, dx, scratch, scratch + cols, cols, eps);
+    if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, (float*)nullptr, rows, cols, eps);
+    else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, scratch + cols, rows, cols, eps);
     VILA_LAUNCH_CHECK();
     hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, scratch, dw, cols, accumulate);
     VILA_LAUNCH_CHECK();

@@ -185,7 +185,8 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False, period: int = 0) -> None:
     assert x.dim() == 2 and x.stride(1) == 1 and out.is_contiguous()
-    check(_L().vila_colsum_bf16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), int(accumulate), period, _stream()), "colsum")
+    scratch = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32) if period == 0 else None
+    check(_L().vila_colsum_bf16(x.data_ptr(), out.data_ptr(), _p(scratch), x.shape[0], x.shape[1], x.stride(0), int(accumulate), period, _stream()), "colsum")
 
 
 def norm_bwd(x, w, dy, dw_out, db_out, eps: float, rms: bool, accumulate: bool = False) -> torch.Tensor:
