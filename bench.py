@@ -254,8 +254,17 @@ def main():
     kern_s = k0.elapsed_time(k1) * 1e-3 / n_launch           # includes the ~1.5 us launch boundary between kernels
     kern_bytes = 2 * c.intermediate_size * c.hidden_size * 2 + c.hidden_size * 2 * 2 + c.intermediate_size * 2
     achieved = kern_bytes / kern_s / 1e9
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
+    # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if a.config == "nvila_8b" and os.path.exists(tj):
+        with open(tj) as f:
+            tdata = json.load(f)
+        if tdata.get("algorithmic_bytes_per_launch") == kern_bytes:
+            traffic, traffic_src = tdata["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
     roofline = {"bound": "hbm", "kernel": "gemv_kernel<1> (RMSNorm + gate/up GEMV + SiLU*mul)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_us": round(kern_s * 1e6, 2),
                 "whole_step": {"bytes_per_token": step_bytes, "achieved": round(step_bytes / step_s / 1e9, 1),
                                "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),

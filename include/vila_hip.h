@@ -154,7 +154,11 @@ enum { VILA_EPI_NONE = 0, VILA_EPI_GELU_TANH = 1, VILA_EPI_GELU_ERF = 2, VILA_EP
 int vila_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
                    const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
                    vila_stream_t stream);
-/* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128 (process-wide) */
+/* same, with an fp32 workspace (>= splits*M*N*4 bytes): lets under-filled grids (small M x N, long K) run split-K */
+int vila_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
+                      const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
+                      void* ws, size_t ws_bytes, vila_stream_t stream);
+/* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */
 void vila_gemm_force_tile(int tile);
 int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream);
 int vila_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, float eps, vila_stream_t stream);

@@ -65,6 +65,27 @@ def test_gemm_every_tile_shape(ops, tile, M, N, K):
         lib.vila_gemm_force_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(769, 3584, 18944), (600, 520, 1024), (769, 4608, 3584)])
+def test_gemm_splitk_with_workspace(ops, M, N, K):
+    """Split-K over grid.y of the 256x256 LDS-DMA kernel (fp32 slabs + reduce with bias/residual)."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    a = randn_bf16(M, K, seed=51)
+    w = randn_bf16(N, K, seed=52, scale=K ** -0.5)
+    bias, res = randn_bf16(N, seed=53), randn_bf16(M, N, seed=54)
+    ws = torch.empty(8 * M * N, device="cuda", dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    lib.vila_gemm_force_tile(5)
+    try:
+        out = ops.gemm(a, w, bias=bias, residual=res, ws=ws)
+    finally:
+        lib.vila_gemm_force_tile(0)
+    assert rel_l2(out, ref) < 4e-3, f"rel={rel_l2(out, ref):.3e}"
+    x = res.clone()
+    ops.gemm(a, w, residual=x, out=x, ws=ws)      # in place on the residual stream, automatic choice
+    assert rel_l2(x, a.float() @ w.float().t() + res.float()) < 4e-3
+
+
 def test_gemm_detects_transpose_and_identity(ops):
     """A = I with an asymmetric W must give exactly W^T rows (guide rule: symmetric inputs hide a swapped C layout)."""
     n = 256

@@ -41,6 +41,24 @@ def bench_gemm_tiles():
         print(f"M={M:5d} N={N:6d} K={K:6d}: " + " | ".join(f"{r:7.1f}" for r in res))
 
 
+def bench_prefill_shapes():
+    from vila_amd import _lib
+    lib = _lib.load()
+    print("== S=769 prefill GEMMs (us): auto | forced 128-tile kernel | gemm256 (4) | split-K (5) ==")
+    M = 769
+    ws = torch.empty(8 * M * 4608, device="cuda", dtype=torch.float32)
+    for N, K, epi in [(4608, 3584, 0), (3584, 3584, 0), (18944, 3584, 3), (3584, 18944, 0)]:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        w2 = rnd(N, K, scale=K ** -0.5) if epi == 3 else None
+        res = []
+        for tile in (0, 1, 4, 5):
+            lib.vila_gemm_force_tile(tile)
+            t = timeit(lambda: ops.gemm(a, w, w2=w2, epi=epi, ws=ws), iters=20)
+            res.append(t * 1e6)
+        lib.vila_gemm_force_tile(0)
+        print(f"N={N:6d} K={K:6d} epi={epi}: " + " | ".join(f"{r:7.1f}" for r in res))
+
+
 def bench_gemm():
     print("== GEMM bf16 (TFLOP/s) ==")
     for M, N, K, epi in [(769, 4608, 3584, 0), (769, 3584, 3584, 0), (769, 18944, 3584, 3), (769, 3584, 18944, 0),
@@ -79,6 +97,8 @@ def bench_attn():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
+    if what in ("prefill",):
+        bench_prefill_shapes()
     if what in ("tiles",):
         bench_gemm_tiles()
     if what in ("gemm", "all"):

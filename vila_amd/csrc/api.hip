@@ -32,8 +32,10 @@ inline const bf16_t* B(const void* p) { return (const bf16_t*)p; }
 inline bf16_t* B(void* p) { return (bf16_t*)p; }
 
 int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const bf16_t* res, int64_t ldr,
-         void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0) {
+         void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0,
+         float* ws = nullptr, size_t ws_bytes = 0) {
     GemmArgs g;
+    g.ws = ws; g.ws_bytes = ws_bytes;
     g.A = A; g.lda = lda; g.W = B(W); g.ldw = ldw; g.W2 = B(W2); g.bias = B(bias); g.residual = res; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.M = M; g.N = N; g.K = K; g.epi = epi;
     return launch_gemm(g, s);
@@ -175,6 +177,7 @@ extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T)
     b += align_up((size_t)T * F * 2, 256);                     // act
     b += 2 * align_up((size_t)T * (s->head_dim / 2) * 4, 256); // rope cos/sin
     b += align_up((size_t)T * H * 2, 256);                     // gathered last rows / final norm
+    b += align_up((size_t)4 * T * H * 4, 256);                 // split-K fp32 slabs (o_proj / down_proj at small T)
     return b + 8192;
 }
 
@@ -197,6 +200,8 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     float* cs = a.take<float>((size_t)T * hd / 2);
     float* sn = a.take<float>((size_t)T * hd / 2);
     bf16_t* lastbuf = a.take<bf16_t>((size_t)T * H);
+    float* skws = a.take<float>((size_t)4 * T * H);
+    const size_t skws_bytes = (size_t)4 * T * H * 4;
     VILA_REQUIRE(a.ok(), "llm_prefill: workspace arena overflow");
     if (cache != nullptr) VILA_REQUIRE(max_seqlen <= cache->max_ctx, "llm_prefill: sequence (%d) longer than the KV cache (%d)", max_seqlen, cache->max_ctx);
 
@@ -232,10 +237,10 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
         at.scale = 1.0f / sqrtf((float)hd); at.lse = nullptr;
         VILA_REQUIRE(QS == H, "llm: q_heads*head_dim (%d) must equal hidden (%d) for the in-place attention buffer", QS, H);
         VILA_TRY(launch_attn_fwd(at, s));
-        VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s));                   // x += o_proj(attn)
+        VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes));   // x += o_proj(attn)
         VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
         VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, T, F, H, EPI_GATEUP, s, L.w_up));  // silu(gate)*up
-        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, T, H, F, EPI_NONE, s));                // x += down(...)
+        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, T, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes));  // x += down(...)
         if (taps) VILA_HIP(hipMemcpyAsync(taps + (size_t)(l + 1) * T * H, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
     }
 
@@ -365,6 +370,11 @@ extern "C" int vila_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                               const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
                               vila_stream_t stream) {
     return gemm(B(A), lda, W, ldw, bias, B(residual), ldr, C, ldc, M, N, K, epi, S(stream), W2, out_f32);
+}
+extern "C" int vila_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
+                                 const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
+                                 void* ws, size_t ws_bytes, vila_stream_t stream) {
+    return gemm(B(A), lda, W, ldw, bias, B(residual), ldr, C, ldc, M, N, K, epi, S(stream), W2, out_f32, (float*)ws, ws_bytes);
 }
 extern "C" int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream) {
     return launch_layernorm(B(x), B(w), B(b), B(y), rows, cols, eps, S(stream));

@@ -207,16 +207,29 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 bool gemm256_supported(const GemmArgs& a);
 int launch_gemm256(const GemmArgs& a, hipStream_t s);
+int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
 static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 
 template <int EPI, bool OUT_F32>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
     int sel = g_force_tile;
-    if (sel == 4 || (sel == 0 && (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) >= 150)) {
+    const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, (EPI == EPI_GATEUP) ? 128 : 256);
+    if (sel == 4 || (sel == 0 && tiles256 >= 150)) {
         if (gemm256_supported(a)) return launch_gemm256(a, s);
         if (sel == 4) sel = 0;
     }
+    // under-filled grid of 256^2 tiles (S = 769 prefill: 56 tiles for N = 3584): slice K over grid.y when a workspace is given
+    if ((sel == 0 || sel == 5) && EPI == EPI_NONE && !OUT_F32 && a.ws != nullptr && a.M >= 512 && gemm256_supported(a)) {
+        const int kt = a.K / 64;
+        int splits = 0;      // largest power of two that keeps every slice resident at once (1 block of 512 threads per CU)
+        for (int c = 2; c <= 8; c *= 2)
+            if (kt % c == 0 && kt / c >= 8 && tiles256 * c <= 256 && (size_t)c * a.M * a.N * 4 <= a.ws_bytes) splits = c;
+        // measured at M = 769 (tools/microbench.py prefill): N=3584,K=18944 233 -> 122 us; N=3584,K=3584 51 -> 41 us;
+        // N=4608 (72 tiles) only breaks even, so require at least 4 slices
+        if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);
+    }
+    if (sel == 5) sel = 0;
     if (sel == 0) {
         const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
         if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;

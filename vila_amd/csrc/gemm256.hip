@@ -1,4 +1,5 @@
-// 256x256x64 bf16 MFMA GEMM for the large-M contractions (SFT step: T = 3076 packed tokens; wgrad / dgrad; long prefill).
+// 256x256x64 bf16 MFMA GEMM for the large contractions (SFT step: T = 3076 packed tokens; wgrad / dgrad; gate/up and
+// down projections of the prefill).
 //
 // Why a second kernel: on gfx950 the 128x128 tile moves 32 KB per K-tile through the 64 B/clk vector-memory path and the
 // LDS write port for only 512 MFMA cycles per SIMD — it is L1/LDS-bound by construction.  The 256x256 tile halves the bytes
@@ -12,6 +13,9 @@
 //   barriers, so one wave's LDS reads overlap the other's MFMAs.
 //   LDS image is lane-linear for the DMA; the 16-B slot swizzle (slot ^= (row>>1)&7, conflict-free for ds_read_b128 and the
 //   same involution as gemm.hip) is applied on the per-lane SOURCE address and on the fragment reads (guide rule 21).
+// Variants: fused gate/up epilogue (each wave's 64 B rows = 32 gate + 32 up rows of the same output columns -> silu(g)*u),
+// and split-K (grid.y slices of K write fp32 slabs that splitk_reduce_kernel sums with bias / residual) for the
+// M = 769 x N = 3584 prefill shapes whose 56 tiles cannot fill 256 CUs.
 // Requires K % 64 == 0 (callers pad the contraction dim); M / N tails by row clamping + masked stores.
 #include "kernels.h"
 
@@ -21,42 +25,52 @@
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <bool OUT_F32, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m) {
+// MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators)
+template <int MODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
     constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
+    constexpr bool GU = (MODE == 2);
+    constexpr int BN_OUT = GU ? 128 : 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id % tiles_m, tn = id / tiles_m;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int M = p.M, N = p.N, K = p.K;
+    const int m0 = tm * 256, n0 = tn * BN_OUT;
+    const int M = p.M, N = p.N;
 
     // ---- DMA source offsets: thread's chunk c = tid + 512*i of a half-tile: row = c >> 3, LDS slot = c & 7 ----
     const int srow = tid >> 3;                         // + 64 i
     const int kch = (tid & 7) ^ ((srow >> 1) & 7);     // global k-chunk that lands in this lane's LDS slot
     uint32_t aoff[2][2], boff[2][2];                   // [half][round] element offsets of the row starts
+    bool b_up[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int gm = m0 + h * 128 + srow + 64 * i; gm = gm < M ? gm : M - 1;
-            int gn = n0 + h * 128 + srow + 64 * i; gn = gn < N ? gn : N - 1;
             aoff[h][i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
+            const int rb = h * 128 + srow + 64 * i;    // row of the 256-row B tile; wave column = rb >> 6
+            int gn;
+            if (GU) { gn = n0 + (rb >> 6) * 32 + (rb & 31); b_up[h][i] = (rb & 32) != 0; }
+            else { gn = n0 + rb; b_up[h][i] = false; }
+            gn = gn < N ? gn : N - 1;
             boff[h][i] = (uint32_t)gn * (uint32_t)p.ldw + kch * 8;
         }
     const int lds_lane_base = __builtin_amdgcn_readfirstlane(wave * 1024);   // wave-uniform: 64 lanes x 16 B per DMA
+    const int kt0 = (MODE == 3) ? blockIdx.y * k_tiles_per_split : 0;
     auto issue_tile = [&](int t, int buf) {
-        const int k0 = t * T256_BK;
+        const int k0 = (kt0 + t) * T256_BK;
         char* base = smem + buf * BUF_BYTES + lds_lane_base;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[h][i] + k0), (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void*)(p.W + boff[h][i] + k0), (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
+                const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc + boff[h][i] + k0), (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
             }
     };
 
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = K / T256_BK;
+    const int nt = (MODE == 3) ? k_tiles_per_split : p.K / T256_BK;
     issue_tile(0, 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -137,46 +151,61 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     }
     __syncthreads();   // all LDS reads of the last tile done before the staging area is reused
 
-    // ---- epilogue: 4 passes of 32 rows through per-wave fp32 staging; bias / GELU / residual; coalesced stores ----
+    // ---- epilogue: 4 passes of 32 rows through per-wave fp32 staging; coalesced stores ----
     float* wst = (float*)smem + wave * 32 * T256_STG;
-    const int ncol0 = n0 + wc * 64;
-    float bv[4];
+    constexpr int WN_OUT = GU ? 32 : 64;
+    constexpr int NJ = GU ? 2 : 4;
+    const int ncol0 = n0 + wc * WN_OUT;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 2 && MODE != 3) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = ncol0 + j * 16 + l15;
-        bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const int col = ncol0 + j * 16 + l15;
+            bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
+        }
     }
-    const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
+    constexpr int LPR = WN_OUT / 4, RPI = 64 / LPR;
+    const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
+    float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[2 * q + ii][j][r] + bv[j];
-                    if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
-                    if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                    float v;
+                    if (GU) {
+                        v = silu_f(acc[2 * q + ii][j][r]) * acc[2 * q + ii][j + 2][r];
+                    } else {
+                        v = acc[2 * q + ii][j][r] + bv[j];
+                        if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
+                        if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                    }
                     wst[(ii * 16 + lg * 4 + r) * T256_STG + j * 16 + l15] = v;
                 }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rr = it * 4 + rr0;
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + rr0;
             const int gm = m0 + wr * 128 + q * 32 + rr, gc = ncol0 + c4;
             if (gm < M && gc < N) {
                 f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
-                if (p.residual != nullptr) {
-                    const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
-                    v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
-                }
-                if constexpr (OUT_F32) {
-                    *(f32x4*)((float*)p.C + (int64_t)gm * p.ldc + gc) = v;
+                if (MODE == 3) {
+                    *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
                 } else {
-                    u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-                    *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+                    if (p.residual != nullptr) {
+                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
+                        v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+                    }
+                    if constexpr (MODE == 1) {
+                        *(f32x4*)((float*)p.C + (int64_t)gm * p.ldc + gc) = v;
+                    } else {
+                        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+                        *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+                    }
                 }
             }
         }
@@ -185,31 +214,73 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     }
 }
 
-template <bool OUT_F32, int EPI>
-static int launch256_t(const GemmArgs& a, hipStream_t s) {
-    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, 256);
+// out[m][n] = bf16(sum_s slab[s][m][n] + bias[n] + residual[m][n])
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t slab_stride, const bf16_t* __restrict__ bias,
+                                     const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int M, int N) {
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), c = (int)(i % n4) * 4;
+        f32x4 v = *(const f32x4*)(slab + (int64_t)m * N + c);
+        for (int s = 1; s < splits; ++s) {
+            const f32x4 w = *(const f32x4*)(slab + s * slab_stride + (int64_t)m * N + c);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        if (bias != nullptr) {
+            const u32x2 b = *(const u32x2*)(bias + c);
+            v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
+        }
+        if (residual != nullptr) {
+            const u32x2 r = *(const u32x2*)(residual + (int64_t)m * ldr + c);
+            v[0] += lo_bf(r[0]); v[1] += hi_bf(r[0]); v[2] += lo_bf(r[1]); v[3] += hi_bf(r[1]);
+        }
+        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(out + (int64_t)m * ldc + c) = o;
+    }
+}
+
+template <int MODE, int EPI>
+static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1) {
+    const int bn = (MODE == 2) ? 128 : 256;
+    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, bn);
     const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<OUT_F32, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<OUT_F32, EPI>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m);
+    const int kt = a.K / T256_BK;
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI>), dim3(tiles_m * tiles_n, splits), dim3(512), lds, s, a, tiles_m, kt / splits);
     VILA_LAUNCH_CHECK();
     return 0;
 }
 
 bool gemm256_supported(const GemmArgs& a) {
-    return a.epi != EPI_GATEUP && a.K % T256_BK == 0 && a.K >= 2 * T256_BK &&
-           (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
+    return a.K % T256_BK == 0 && a.K >= 2 * T256_BK && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
-    if (a.out_f32) return launch256_t<true, EPI_NONE>(a, s);
+    if (a.epi == EPI_GATEUP) return launch256_t<2, EPI_NONE>(a, s);
+    if (a.out_f32) return launch256_t<1, EPI_NONE>(a, s);
     switch (a.epi) {
-        case EPI_NONE: return launch256_t<false, EPI_NONE>(a, s);
-        case EPI_GELU_TANH: return launch256_t<false, EPI_GELU_TANH>(a, s);
-        case EPI_GELU_ERF: return launch256_t<false, EPI_GELU_ERF>(a, s);
+        case EPI_NONE: return launch256_t<0, EPI_NONE>(a, s);
+        case EPI_GELU_TANH: return launch256_t<0, EPI_GELU_TANH>(a, s);
+        case EPI_GELU_ERF: return launch256_t<0, EPI_GELU_ERF>(a, s);
     }
     VILA_FAIL(-1, "gemm256: unsupported epilogue %d", a.epi);
+}
+
+// split-K: C = sum over `splits` K-slices; `slab` = splits * M * N fp32 workspace owned by the caller
+int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s) {
+    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && (a.K / T256_BK) % splits == 0 && a.N % 4 == 0, "gemm256 split-K: K tiles (%d) must divide by %d",
+                 a.K / T256_BK, splits);
+    GemmArgs b = a;
+    b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
+    VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits)));
+    const int64_t total = (int64_t)a.M * (a.N / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
+                       (bf16_t*)a.C, a.ldc, a.M, a.N);
+    VILA_LAUNCH_CHECK();
+    return 0;
 }

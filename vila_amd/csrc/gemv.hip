@@ -207,14 +207,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     const bf16_t* rows[R];
     Batch<R, U> b0;
     const bool has = g < n_groups;
-    if (has) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
+    // issue the first weight batch before staging x only for short rows (K <= 4096: the staging latency is comparable to the
+    // stream); for K = 18944 the x staging is long and queuing the weight loads in front of it measured 13 % slower
+    const bool early = has && (p.K <= 4096);
+    if (early) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
     if constexpr (MODE == 2) {
         const int n_active = (*p.pos_ptr + DEC_KS) / DEC_KS;     // ceil((pos+1)/KS)
         stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
     } else {
         stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     }
-    if (has) {
+    if (early) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -260,8 +263,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 // fused RMSNorm + QKV projection + bias + RoPE + KV-cache append for one new token.
-// Group = 4 rows: q/k heads -> rows {d, d+1, d+hd/2, d+hd/2+1} of one head (the two rotate-half pairs),
-// v heads -> 4 consecutive rows.  cos/sin of the token's position come from the per-token table written by
+// Group = 2 rows per wave: q/k heads -> the rotate-half pair {d, d+hd/2} of one head, v heads -> 2 consecutive rows.  cos/sin of the token's position come from the per-token table written by
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
 template <int U>
@@ -271,43 +273,34 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = p.hd, half = hd >> 1;
-    const int gph = hd >> 2;                                   // groups per head
+    const int gph = half;                                      // groups (row pairs) per head
     const int n_groups = (p.nq + 2 * p.nkv) * gph;
     const int nch = p.K >> 3;
     const int stride = gridDim.x * 4;
     int g = blockIdx.x * 4 + wave;
 
-    int rows_i[4];
-    const bf16_t* rows[4];
+    int rows_i[2];
+    const bf16_t* rows[2];
     auto rows_of = [&](int gg) {
         const int head = gg / gph, gi = gg % gph;
-        if (head >= p.nq + p.nkv) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rows_i[r] = head * hd + gi * 4 + r;
-        } else {
-            const int d = gi * 2;
-            rows_i[0] = head * hd + d; rows_i[1] = head * hd + d + 1;
-            rows_i[2] = head * hd + d + half; rows_i[3] = head * hd + d + half + 1;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rows[r] = p.Wqkv + (int64_t)rows_i[r] * p.K;
+        if (head >= p.nq + p.nkv) { rows_i[0] = head * hd + gi * 2; rows_i[1] = rows_i[0] + 1; }   // v: two consecutive rows
+        else { rows_i[0] = head * hd + gi; rows_i[1] = rows_i[0] + half; }                        // q/k: the rotate-half pair (d, d + hd/2)
+        rows[0] = p.Wqkv + (int64_t)rows_i[0] * p.K;
+        rows[1] = p.Wqkv + (int64_t)rows_i[1] * p.K;
     };
-    auto finish = [&](int gg, float (&acc)[4]) {
-        if (lane >= 4) return;
+    auto finish = [&](int gg, float (&acc)[2]) {
+        if (lane >= 2) return;
         const int head = gg / gph, gi = gg % gph;
         const bool is_v = head >= p.nq + p.nkv;
         const int pos = *p.pos_ptr;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = bfround(acc[r] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[r]]) : 0.f));
-        float out = v[lane & 3];
+        const float lo = bfround(acc[0] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[0]]) : 0.f));
+        const float hi = bfround(acc[1] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[1]]) : 0.f));
+        float out = lane ? hi : lo;
         if (!is_v) {
-            const int e = lane & 1, hi_half = lane >> 1, d = gi * 2 + e;
-            const float c = p.rope_cs[d], sn = p.rope_cs[half + d];
-            const float lo = v[e], hi = v[2 + e];
-            out = hi_half ? bfround(bfround(hi * c) + bfround(lo * sn)) : bfround(bfround(lo * c) + bfround(-hi * sn));
+            const float c = p.rope_cs[gi], sn = p.rope_cs[half + gi];
+            out = lane ? bfround(bfround(hi * c) + bfround(lo * sn)) : bfround(bfround(lo * c) + bfround(-hi * sn));
         }
-        const int row = rows_i[lane & 3];
+        const int row = rows_i[lane];
         if (head < p.nq) {
             p.q_out[row] = f2bf(out);
         } else if (pos < p.max_ctx) {
@@ -317,30 +310,32 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         }
     };
 
-    Batch<4, U> b0;
+    Batch<2, U> b0;
     const bool has = g < n_groups;
-    if (has) { rows_of(g); load_batch<4, U>(rows, 0, lane, nch, b0); }
+    if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); }
     stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        fma_batch<4, U>(b0, sx, 0, lane, nch, acc);
-        wave_rows_dot<4, U>(rows, sx, p.K, lane, acc, 64 * U);
+        float acc[2] = {0.f, 0.f};
+        fma_batch<2, U>(b0, sx, 0, lane, nch, acc);
+        wave_rows_dot<2, U>(rows, sx, p.K, lane, acc, 64 * U);
         finish(g, acc);
         g += stride;
     }
     for (; g < n_groups; g += stride) {
         rows_of(g);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        wave_rows_dot<4, U>(rows, sx, p.K, lane, acc, 0);
+        float acc[2] = {0.f, 0.f};
+        wave_rows_dot<2, U>(rows, sx, p.K, lane, acc, 0);
         finish(g, acc);
     }
 }
 
 int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.K % 8 == 0 && a.hd % 4 == 0 && a.rope_cs != nullptr, "qkv_decode: K=%d hd=%d", a.K, a.hd);
-    const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 4);
+    const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 2);
     const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
-    hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(cdiv(n_groups, 4)), dim3(256), lds, s, a);   // U=7 measured slower (2 waves/SIMD)
+    // one rotate-half pair per wave; K <= 3584: the whole row pair (14 x 16 B per lane) is in flight in ONE round trip
+    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(cdiv(n_groups, 4)), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(cdiv(n_groups, 4)), dim3(256), lds, s, a);
     VILA_LAUNCH_CHECK();
     return 0;
 }

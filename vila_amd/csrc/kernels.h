@@ -14,6 +14,7 @@ struct GemmArgs {
     const bf16_t* residual = nullptr; int64_t ldr = 0;
     void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
     int M = 0, N = 0, K = 0; int epi = EPI_NONE;
+    float* ws = nullptr; size_t ws_bytes = 0;   // optional fp32 workspace: enables split-K for under-filled grids
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 

@@ -29,7 +29,7 @@ def _need(t: torch.Tensor, dtype=torch.bfloat16, name: str = "tensor") -> None:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          epi: int = EPI_NONE, w2: Optional[torch.Tensor] = None, out_f32: bool = False,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual   (nn.Linear semantics; EPI_GATEUP: silu(a w^T) * (a w2^T))."""
     _need(a, name="a"); _need(w, name="w")
     # w may carry extra zero-padded columns (transpose() pads the contraction dim to 64): K is a's width
@@ -40,6 +40,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     if residual is not None:
         _need(residual, name="residual"); assert residual.shape == (M, N) and residual.stride(1) == 1
+    if ws is not None:   # fp32 workspace: allows split-K on under-filled grids
+        check(_lib.load().vila_gemm_bf16_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(w2), _p(bias), _p(residual),
+                                            residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                            1 if out_f32 else 0, M, N, K, epi, ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
+              "vila_gemm_bf16_ws")
+        return out
     check(_lib.load().vila_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(w2), _p(bias), _p(residual),
                                      residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
                                      1 if out_f32 else 0, M, N, K, epi, _stream()), "vila_gemm_bf16")
