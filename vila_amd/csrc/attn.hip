@@ -265,9 +265,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
-template <int HD, bool CAUSAL>
-static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
-    constexpr int QF = 2;
+template <int HD, bool CAUSAL, int QF>
+static int launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
     const size_t lds = (size_t)2 * 64 * (HDP + 8) * 2 + (size_t)2 * DN * 16 * 72 * 2;
     static bool attr_set = false;
@@ -279,6 +278,15 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_fwd_kernel<HD, QF, CAUSAL>), grid, dim3(256), lds, s, a);
     VILA_LAUNCH_CHECK();
     return 0;
+}
+
+// 32 query rows per wave (QF = 2) halves the LDS traffic per MFMA; with few blocks (one 448^2 tile = 8 x 16, S = 769 prefill
+// = 7 x 28) 16 rows per wave (QF = 1) doubles the grid and fills the 256 CUs
+template <int HD, bool CAUSAL>
+static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    const int64_t blocks2 = (int64_t)cdiv(a.max_seqlen, 128) * a.n_q_heads * a.n_seq;
+    if (blocks2 < 256) return launch_attn_q<HD, CAUSAL, 1>(a, s);
+    return launch_attn_q<HD, CAUSAL, 2>(a, s);
 }
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
