@@ -14,6 +14,8 @@
 #include "kernels.h"
 
 #define NEG_BIG (-1.0e30f)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
 template <int HD, int QF, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
@@ -22,7 +24,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DN = (HD + 15) / 16;      // 16-row output fragments of O^T
     constexpr int CH = HD / 8;              // 16-B chunks per K/V row
     constexpr int KSTR = HDP + 8;           // sK row stride (elements): +16 B pad => conflict-free ds_read_b128
-    constexpr int VSTR = 72;                // sVt row stride (elements): 64 keys + 16 B pad
     constexpr int KT = 64;
     constexpr int BQ = 4 * QF * 16;
     constexpr int K_ITERS = (KT * CH + 255) / 256;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sK = (bf16_t*)smem;                       // [2][64][KSTR]
-    bf16_t* sV = sK + 2 * KT * KSTR;                  // [2][DN*16][VSTR]
+    bf16_t* sV = sK + 2 * KT * KSTR;                  // [2][64][KSTR]  row-major like K; V^T fragments come out of ds_read_b64_tr_b16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -43,14 +44,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     // zero the pad columns/rows once (they are never overwritten): K cols [HD,HDP), V^T rows [HD, DN*16)
     if constexpr (HDP > HD) {
-        for (int i = tid; i < 2 * KT * (HDP - HD); i += 256) {
+        for (int i = tid; i < 4 * KT * (HDP - HD); i += 256) {     // 2 K buffers + 2 V buffers are contiguous rows
             const int row = i / (HDP - HD), c = i % (HDP - HD);
             sK[row * KSTR + HD + c] = 0;
         }
-    }
-    if constexpr (DN * 16 > HD) {
-        for (int b = 0; b < 2; ++b)
-            for (int i = tid; i < (DN * 16 - HD) * VSTR; i += 256) sV[b * DN * 16 * VSTR + HD * VSTR + i] = 0;
     }
 
     // ---- Q fragments (B operand of S^T): lane holds Q[q0 + qf*16 + l15][kk*32 + lg*8 .. +8] ----
@@ -88,47 +85,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     // staging registers
     u32x4 rk[K_ITERS];
-    u32x4 rv[4];
-    const int v_dc = tid >> 4, v_kg = tid & 15;     // V: d-chunk, key group (4 keys)
+    u32x4 rv[K_ITERS];
     auto gload = [&](int t) {
         const int key0 = t * KT;
 #pragma unroll
         for (int i = 0; i < K_ITERS; ++i) {
             const int cidx = tid + 256 * i;
             const int key = cidx / CH, ch = cidx % CH;
-            rk[i] = (u32x4){0u, 0u, 0u, 0u};
-            if (cidx < KT * CH && key0 + key < seqlen) rk[i] = *(const u32x4*)(kbase + (int64_t)(key0 + key) * p.k_tok_stride + ch * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = key0 + v_kg * 4 + i;
-            rv[i] = (u32x4){0u, 0u, 0u, 0u};
-            if (v_dc < CH && key < seqlen) rv[i] = *(const u32x4*)(vbase + (int64_t)key * p.v_tok_stride + v_dc * 8);
+            rk[i] = (u32x4){0u, 0u, 0u, 0u}; rv[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (cidx < KT * CH && key0 + key < seqlen) {
+                rk[i] = *(const u32x4*)(kbase + (int64_t)(key0 + key) * p.k_tok_stride + ch * 8);
+                rv[i] = *(const u32x4*)(vbase + (int64_t)(key0 + key) * p.v_tok_stride + ch * 8);
+            }
         }
     };
     auto lstore = [&](int buf) {
         bf16_t* dK = sK + buf * KT * KSTR;
+        bf16_t* dVv = sV + buf * KT * KSTR;
 #pragma unroll
         for (int i = 0; i < K_ITERS; ++i) {
             const int cidx = tid + 256 * i;
             const int key = cidx / CH, ch = cidx % CH;
-            if (cidx < KT * CH) *(u32x4*)(dK + key * KSTR + ch * 8) = rk[i];
-        }
-        if (v_dc < CH) {
-            bf16_t* dV = sV + buf * DN * 16 * VSTR + (v_dc * 8) * VSTR + v_kg * 4;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int w = e >> 1;
-                u32x2 o;
-                if (e & 1) {
-                    o[0] = (rv[0][w] >> 16) | (rv[1][w] & 0xffff0000u);
-                    o[1] = (rv[2][w] >> 16) | (rv[3][w] & 0xffff0000u);
-                } else {
-                    o[0] = (rv[0][w] & 0xffffu) | (rv[1][w] << 16);
-                    o[1] = (rv[2][w] & 0xffffu) | (rv[3][w] << 16);
-                }
-                *(u32x2*)(dV + e * VSTR) = o;
-            }
+            if (cidx < KT * CH) { *(u32x4*)(dK + key * KSTR + ch * 8) = rk[i]; *(u32x4*)(dVv + key * KSTR + ch * 8) = rv[i]; }
         }
     };
 
@@ -141,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const int buf = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
         const bf16_t* cK = sK + buf * KT * KSTR;
-        const bf16_t* cV = sV + buf * DN * 16 * VSTR;
+        const bf16_t* cV = sV + buf * KT * KSTR;
         const int key0 = t * KT;
 
         // ---- S^T = K Q^T ----
@@ -190,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = exp2f((m_run[f] - m_new) * c);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[f] - m_new) * c);   // raw v_exp_f32: arguments are <= 0, no range fix-up needed
             const float mc = m_new * c;
             m_run[f] = m_new;
             float ps = 0.f;
@@ -199,15 +177,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(sacc[jn][f][r] * c - mc);
+                    const float e = __builtin_amdgcn_exp2f(sacc[jn][f][r] * c - mc);
                     pv[jn][r] = e;
                     ps += e;
                 }
             l_run[f] = l_run[f] * alpha + ps;
+            if (!__all(alpha == 1.f)) {          // the running max moved for some row of this wave: rescale O (wave-uniform branch)
 #pragma unroll
-            for (int dn = 0; dn < DN; ++dn)
+                for (int dn = 0; dn < DN; ++dn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[dn][f][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) oacc[dn][f][r] *= alpha;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w;
@@ -224,11 +204,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int dn = 0; dn < DN; ++dn) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16_t* vp = cV + (dn * 16 + l15) * VSTR + ks * 32 + lg * 4;
-                const u32x2 lo = *(const u32x2*)(vp);
-                const u32x2 hi = *(const u32x2*)(vp + 16);
-                const u32x4 w = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
+                // V^T fragment via the LDS transpose read: lane i of a 16-lane group points at V[key0 + (i>>2)][d0 + 4*(i&3)] and
+                // receives V[key0 + 0..3][d0 + i] (semantics pinned by tools/tr16_probe.hip); key0 = ks*32 + lg*4 (+16 for slots 4..7)
+                const bf16_t* vp = cV + (ks * 32 + lg * 4 + (l15 >> 2)) * KSTR + dn * 16 + (l15 & 3) * 4;
+                const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)vp);
+                const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vp + 16 * KSTR));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int f = 0; f < QF; ++f)
                     oacc[dn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][ks], oacc[dn][f], 0, 0, 0);
@@ -268,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 template <int HD, bool CAUSAL, int QF>
 static int launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
-    const size_t lds = (size_t)2 * 64 * (HDP + 8) * 2 + (size_t)2 * DN * 16 * 72 * 2;
+    const size_t lds = (size_t)4 * 64 * (HDP + 8) * 2;   // K and V tiles, double buffered
     static bool attr_set = false;
     if (!attr_set) {
         VILA_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, QF, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

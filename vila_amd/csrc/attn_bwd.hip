@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const int kpos = key0 + jn * 16 + lg * 4 + r;
                     const bool ok = (kpos < seqlen) && (!CAUSAL || kpos <= qrow) && qok;
-                    const float pr = ok ? exp2f(sacc[jn][r] * c - lse2) : 0.f;
+                    const float pr = ok ? __builtin_amdgcn_exp2f(sacc[jn][r] * c - lse2) : 0.f;
                     ds[jn][r] = pr * (pacc[jn][r] - dl) * p.scale;
                 }
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
                     l2 = p.lse[(int64_t)hq * p.total_tokens + tok0 + q] * LOG2E;
                     dl = p.delta[(int64_t)hq * p.total_tokens + tok0 + q];
                 }
-                pr[r] = ok ? exp2f(sacc[f][r] * c - l2) : 0.f;
+                pr[r] = ok ? __builtin_amdgcn_exp2f(sacc[f][r] * c - l2) : 0.f;
                 ds[r] = pr[r] * (pacc[f][r] - dl) * p.scale;
             }
             pw[2 * f] = pack2bf(pr[0], pr[1]); pw[2 * f + 1] = pack2bf(pr[2], pr[3]);
