@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", default="decode", choices=["decode", "sft", "video"],
                     help="decode = BASELINE.json metric (default); sft = one data-parallel SFT step (BASELINE configs[2])")
     ap.add_argument("--micro-batch", type=int, default=4)
+    ap.add_argument("--dynamic-s2", action="store_true", help="full NVILA-8B recipe: 14 tiles (448/896/1344) -> 2304 image tokens (SURVEY 8f row 1)")
     return ap.parse_args()
 
 
@@ -202,11 +203,15 @@ def main():
     from vila_amd.vlm import build_model
     lib = _lib.load()
     cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    n_tiles, media_cfg = 1, {}
+    if a.dynamic_s2:
+        cfg = configs.nvila_8b_s2()
+        n_tiles, media_cfg = 14, {"image": {"block_sizes": [(3, 3)]}}
     model = build_model(cfg, seed=0, device=dev)
     llm = model.llm
-    pixels = synthetic.make_pixels(cfg, 1, 0, device=dev, dtype=torch.bfloat16)
+    pixels = synthetic.make_pixels(cfg, n_tiles, 0, device=dev, dtype=torch.bfloat16)
     ids = synthetic.make_prompt(cfg, a.prompt_tokens, 1, 0)[None].to(dev)
-    S = cfg.tokens_per_tile + 1 + a.prompt_tokens
+    S = (cfg.tokens_per_tile * 9 if a.dynamic_s2 else cfg.tokens_per_tile) + 1 + a.prompt_tokens
     max_new = a.steps + a.warmup + 2
     cache = llm.new_cache(((S + max_new + 255) // 256) * 256)
 
@@ -214,7 +219,7 @@ def main():
     def ttft_once():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e, _, m = model._embed(ids, {"image": [pixels[0]]})
+        e, _, m = model._embed(ids, {"image": [pixels[i] for i in range(n_tiles)]}, media_cfg)
         pos = torch.arange(S, device=dev, dtype=torch.int32)
         r = llm.prefill_packed(e[0], pos, None, S, cache=cache, last_rows=torch.tensor([S - 1], device=dev, dtype=torch.int32))
         first = int(ops.argmax(r.last_logits[0]))

@@ -209,6 +209,17 @@ int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* p
                     float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);
 int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * dynamic_s2 multi-scale path — replaces merge_features_for_dynamic_s2 + split_chessboard +
+ * rearrange of LlavaMetaModel.encode_images (llava/model/llava_arch.py:298-379):
+ *   feats [n_tiles, g*g, C] (tower output for every tile of every image, scales in ascending order per image)
+ *   desc  device [n_blocks][6] = {first tile of the image, bh, bw, block row i, block col j, single (block_sizes None)}
+ *   out   [n_blocks, g*g, n_scales*C] = the projector input.  splits[k] = scales[k] / scales[0] for k < n_scales-1 [host].
+ * ------------------------------------------------------------------------------------------------------------ */
+int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,
+                       const int32_t* splits, vila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

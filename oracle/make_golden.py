@@ -90,7 +90,7 @@ def run_vision(cfg, w, pixels):
 def run_projector(cfg, w, feats):
     bp = ref_projector()
     pc = bp.MultimodalProjectorConfig(cfg.mm_projector_type)
-    ns = types.SimpleNamespace(mm_hidden_size=cfg.vision.hidden_size, hidden_size=cfg.llm.hidden_size)
+    ns = types.SimpleNamespace(mm_hidden_size=cfg.mm_hidden_size, hidden_size=cfg.llm.hidden_size)
     model = bp.MultimodalProjector(pc, ns).eval()
     pre = "mm_projector."
     sd = {k[len(pre):]: t for k, t in w.items() if k.startswith(pre)}

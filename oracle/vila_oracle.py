@@ -398,3 +398,84 @@ def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_ite
         return causal_lm_loss(logits, pl, num_items_in_batch)
     logits, _ = qwen2_forward(e, w, cfg.llm, attention_mask=m)
     return causal_lm_loss(logits, l, num_items_in_batch)
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY §8(f) row 1 — dynamic_s2 multi-scale path (the full NVILA-8B recipe, scripts/NVILA/stage*_9tile.sh:19-22:
+# --dynamic_s2 True --s2_scales 448,896,1344 --s2_resize_output_to_scale_idx -1)
+#   merge_chessboard / split_chessboard            llava/model/llava_arch.py:255-296
+#   merge_features_for_dynamic_s2                  llava/model/llava_arch.py:298-364
+#   encode_images, dynamic_s2 branch               llava/model/llava_arch.py:369-390
+#   VisionTowerDynamicS2 (hidden = C * n_scales)   llava/model/multimodal_encoder/vision_encoder.py:251-276
+# ----------------------------------------------------------------------------------------------
+def merge_chessboard(x: torch.Tensor, num_split_h: int, num_split_w: int) -> torch.Tensor:
+    """x: [B, N, C] (or [B, C, h, w]) holding num_split_h*num_split_w sub-squares along the batch dim -> [b, C, H, W]."""
+    B = x.shape[0]
+    if x.dim() == 3:
+        N = x.shape[1]
+        g = int(N ** 0.5)
+        x = x.reshape(B, g, g, x.shape[2]).permute(0, 3, 1, 2)
+    assert B % (num_split_h * num_split_w) == 0
+    b = B // (num_split_h * num_split_w)
+    rows = [torch.cat([x[(i * num_split_w + j) * b:(i * num_split_w + j + 1) * b] for j in range(num_split_w)], dim=-1)
+            for i in range(num_split_h)]
+    return torch.cat(rows, dim=-2)
+
+
+def split_chessboard(x: torch.Tensor, num_split_h: int, num_split_w: int) -> torch.Tensor:
+    B, C, H, W = x.shape
+    assert H % num_split_h == 0 and W % num_split_w == 0
+    h, w = H // num_split_h, W // num_split_w
+    return torch.cat([x[:, :, i * h:(i + 1) * h, j * w:(j + 1) * w] for i in range(num_split_h) for j in range(num_split_w)], dim=0)
+
+
+def merge_features_for_dynamic_s2(image_features: torch.Tensor, block_sizes, scales, resize_output_to_scale_idx: int = -1):
+    feats_each, new_block_sizes = [], []
+    cnt = 0
+    for bs in block_sizes:
+        if bs is None:
+            cur = image_features[cnt:cnt + 1]
+            g = int(cur.shape[1] ** 0.5)
+            cur = cur.reshape(1, g, g, -1).permute(0, 3, 1, 2).repeat(1, len(scales), 1, 1)
+            feats_each.append(cur)
+            new_block_sizes.append((1, 1))
+            cnt += 1
+            continue
+        per_scale = []
+        for scale in scales[:-1]:
+            n = (scale // scales[0]) ** 2
+            per_scale.append(merge_chessboard(image_features[cnt:cnt + n], scale // scales[0], scale // scales[0]))
+            cnt += n
+        n_last = bs[0] * bs[1]
+        per_scale.append(merge_chessboard(image_features[cnt:cnt + n_last], bs[0], bs[1]))
+        cnt += n_last
+        out_size = per_scale[resize_output_to_scale_idx].shape[-2:]
+        cur = torch.cat([F.interpolate(f.to(torch.float32), size=out_size, mode="area").to(f.dtype) for f in per_scale], dim=1)
+        feats_each.append(cur)
+        if resize_output_to_scale_idx in (len(scales) - 1, -1):
+            new_block_sizes.append(tuple(bs))
+        else:
+            s = scales[resize_output_to_scale_idx] // scales[0]
+            new_block_sizes.append((s, s))
+    assert cnt == len(image_features), f"The number of blocks ({cnt}) does not match length of image_features ({len(image_features)})!"
+    return feats_each, new_block_sizes
+
+
+def s2_merge_to_projector_input(image_features, block_sizes, scales, resize_idx: int = -1):
+    """-> (proj_in [sum blocks, N, C*n_scales], new_block_sizes): everything between the tower and the projector."""
+    feats_each, nbs = merge_features_for_dynamic_s2(image_features, block_sizes, scales, resize_idx)
+    blocks = [split_chessboard(x, b[0], b[1]) for x, b in zip(feats_each, nbs)]
+    x = torch.cat([t.flatten(2).transpose(1, 2) for t in blocks], dim=0)        # "b c h w -> b (h w) c"
+    return x, nbs
+
+
+def encode_images_dynamic_s2(pixels_tiles, block_sizes, w, cfg) -> List[torch.Tensor]:
+    """dynamic_s2 branch of encode_images: list of per-image [N_tokens, hidden] tensors."""
+    feats = vision_tower_forward(pixels_tiles, w, cfg.vision)
+    x, nbs = s2_merge_to_projector_input(feats, block_sizes, cfg.s2_scales, cfg.s2_resize_output_to_scale_idx)
+    y = projector_forward(x, w, cfg.mm_projector_type)
+    outs = []
+    for part, b in zip(y.split([b[0] * b[1] for b in nbs], dim=0), nbs):
+        m = merge_chessboard(part, b[0], b[1])                                   # [1, C, H, W]
+        outs.append(m[0].flatten(1).transpose(0, 1))                             # "1 c h w -> (h w) c"
+    return outs

@@ -1,0 +1,91 @@
+"""dynamic_s2 multi-scale path.  Fixture tests/golden/dynamic_s2.npz comes from EXECUTING the reference's
+merge_chessboard / split_chessboard / merge_features_for_dynamic_s2 (oracle/make_golden_s2.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vila_oracle as O
+from tests.gpu_util import rel_l2
+from vila_amd import configs, host, synthetic
+
+BLOCKS = [(2, 3), None]
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "dynamic_s2.npz"))
+
+
+def test_oracle_s2_matches_reference_bit_exact(fx):
+    cfg = configs.tiny_s2()
+    x, nbs = O.s2_merge_to_projector_input(torch.from_numpy(fx["tower_out"]), BLOCKS, cfg.s2_scales, -1)
+    assert torch.equal(x, torch.from_numpy(fx["proj_in"])) and [list(b) for b in nbs] == fx["new_block_sizes"].tolist()
+    xi, _ = O.s2_merge_to_projector_input(torch.from_numpy(fx["int_tiles"]), [(3, 3), None], (8, 16, 24), -1)
+    assert torch.equal(xi, torch.from_numpy(fx["int_proj_in"]))
+
+
+def test_host_plan_reproduces_reference_token_order(fx):
+    cfg = configs.tiny_s2()
+    plan = host.s2_plan(BLOCKS, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+    assert plan.n_tiles == 12 and plan.n_blocks == 7 and plan.splits == [1, 2]
+    w = synthetic.make_weights(cfg, int(fx["seed"]))
+    y = O.projector_forward(torch.from_numpy(fx["proj_in"]), w, cfg.mm_projector_type)
+    flat = y.reshape(-1, y.shape[-1])
+    for i, perm in enumerate(plan.perms):
+        ref = torch.from_numpy(fx[f"tokens_{i}"])
+        assert rel_l2(flat[perm.long()], ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_s2_merge_kernel_bit_exact_on_integers(fx):
+    from vila_amd import ops
+    t = torch.from_numpy(fx["int_tiles"])                       # [15, 16, 2] -> pad channels to 8 for the 16-B kernel path
+    t8 = torch.cat([t, torch.zeros(15, 16, 6)], -1).to(torch.bfloat16).cuda()
+    plan = host.s2_plan([(3, 3), None], [8, 16, 24], 4, 2)
+    out = ops.s2_merge(t8, plan.desc.cuda(), 3, plan.splits)    # [10, 16, 24]
+    ref = torch.from_numpy(fx["int_proj_in"])                   # [10, 16, 6] = 3 scales x 2 channels
+    got = torch.cat([out[..., 0:2], out[..., 8:10], out[..., 16:18]], -1).float().cpu()
+    # integers and halves/quarters of small integers are exact in bf16
+    assert torch.equal(got, ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.gpu
+def test_s2_encode_images_vs_golden_and_oracle(fx):
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny_s2()
+    seed = int(fx["seed"])
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, seed).items()}
+    model = build_model(cfg, weights=w)
+    from vila_amd import ops
+    feats = torch.from_numpy(fx["tower_out"]).to(torch.bfloat16)
+    plan = host.s2_plan(BLOCKS, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+    x = ops.s2_merge(feats.cuda(), plan.desc.cuda(), 3, plan.splits)
+    xr, _ = O.s2_merge_to_projector_input(feats.float(), BLOCKS, cfg.s2_scales, -1)
+    assert rel_l2(x, xr) < 2e-3                                  # same bf16 inputs, fp32 window means, one bf16 rounding
+    px = synthetic.make_pixels(cfg, 12, seed).to(torch.bfloat16)
+    outs = model.encode_images(px.cuda(), block_sizes=list(BLOCKS))
+    refs = O.encode_images_dynamic_s2(px.float(), BLOCKS, w, cfg)
+    assert len(outs) == 2
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert o.shape == r.shape == fx[f"tokens_{i}"].shape
+        assert rel_l2(o, r) < 2e-2, f"image {i} vs oracle {rel_l2(o, r):.3e}"
+        assert rel_l2(o, torch.from_numpy(fx[f"tokens_{i}"])) < 3e-2
+    with pytest.raises(AssertionError, match="does not match length of image_features"):
+        model.encode_images(px[:11].cuda(), block_sizes=list(BLOCKS))
+
+
+@pytest.mark.gpu
+def test_s2_generate_end_to_end():
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny_s2()
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, 12).items()}
+    model = build_model(cfg, weights=w)
+    px = synthetic.make_pixels(cfg, 14, 12).to(torch.bfloat16)     # square image: 1 + 4 + 9 tiles
+    ids = synthetic.make_prompt(cfg, 6, 1, 12)[None]
+    media_cfg = {"image": {"block_sizes": [(3, 3)]}}
+    # the image encoder stacks `images`; for dynamic_s2 the 14 tiles of ONE image arrive as one [14,3,H,W] entry list
+    feats = model.encode_images(px.cuda(), block_sizes=[(3, 3)])
+    ref = O.encode_images_dynamic_s2(px.float(), [(3, 3)], w, cfg)[0]
+    assert feats.shape == (1, 36, cfg.llm.hidden_size) and rel_l2(feats[0], ref) < 2e-2

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
     "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "vila_s2_merge_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

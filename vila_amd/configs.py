@@ -83,6 +83,15 @@ class VilaConfig:
     init_std: float = 0.02
     lm_head_std: float = 0.05
     name: str = "nvila-8b"
+    # dynamic_s2 multi-scale recipe (scripts/NVILA/stage1_9tile.sh:19-22); off = the README benchmark setting (README.md:87)
+    dynamic_s2: bool = False
+    s2_scales: tuple = (448, 896, 1344)
+    s2_resize_output_to_scale_idx: int = -1
+
+    @property
+    def mm_hidden_size(self) -> int:
+        """VisionTowerDynamicS2.hidden_size = C * len(scales) (vision_encoder.py:274-276)."""
+        return self.vision.hidden_size * (len(self.s2_scales) if self.dynamic_s2 else 1)
 
     @property
     def downsample(self) -> int:
@@ -131,6 +140,23 @@ def tiny(proj: str = "mlp_downsample", layers_v: int = 3, layers_l: int = 2, tie
         lm_head_std=0.08,
         name=f"tiny-{proj}",
     )
+
+
+def tiny_s2(layers_v: int = 3, layers_l: int = 2) -> VilaConfig:
+    """tiny config with the dynamic_s2 recipe: scales (56, 112, 168) = 1x, 2x, 3x of the 56-px tile."""
+    cfg = tiny("mlp_downsample", layers_v, layers_l)
+    cfg.dynamic_s2 = True
+    cfg.s2_scales = (56, 112, 168)
+    cfg.name = "tiny-dynamic-s2"
+    return cfg
+
+
+def nvila_8b_s2() -> VilaConfig:
+    """The full NVILA-8B recipe: dynamic_s2, mm_hidden 3456, 14 tiles -> 2304 tokens for a square image."""
+    cfg = nvila_8b()
+    cfg.dynamic_s2 = True
+    cfg.name = "nvila-8b-dynamic-s2"
+    return cfg
 
 
 def reduced_8b(layers_v: int = 2, layers_l: int = 2, vocab: int = 152064) -> VilaConfig:

@@ -477,3 +477,11 @@ extern "C" int vila_adamw_step(float* master, float* m, float* v, const void* gr
     return launch_adamw(master, m, v, B(grad), B(param), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
 }
 extern "C" int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream) { return launch_sumsq(B(x), n, out, S(stream)); }
+
+// dynamic_s2: merge_chessboard + area interpolation + concat + split_chessboard in one gather
+extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,
+                                  const int32_t* splits /*[host] n_scales-1*/, vila_stream_t stream) {
+    int sp[4] = {1, 1, 1, 1};
+    for (int k = 0; k < n_scales - 1 && k < 4; ++k) sp[k] = splits[k];
+    return launch_s2_merge(B(feats), B(out), desc, n_blocks, grid, channels, n_scales, sp, S(stream));
+}

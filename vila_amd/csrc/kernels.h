@@ -35,6 +35,9 @@ int launch_rope_kv(bf16_t* qkv, const float* cs, const float* sn, const int32_t*
 int launch_embed_gather(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int H, int64_t vocab, hipStream_t s);
 int launch_copy_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_row, const int32_t* dst_row, int n, int H, hipStream_t s);
 int launch_argmax(const float* logits, int V, int64_t* out, float* tmpv, int* tmpi, hipStream_t s);
+// dynamic_s2 merge (s2.hip): tower output -> projector input, desc = device [n_blocks][6] {tile_base, bh, bw, i, j, single}
+int launch_s2_merge(const bf16_t* feats, bf16_t* out, const int32_t* desc, int n_blocks, int g, int C, int n_scales, const int* splits,
+                    hipStream_t s);
 
 // ---- attention (attn.hip) ----
 struct AttnArgs {

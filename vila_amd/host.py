@@ -73,3 +73,35 @@ def repack(attention_mask: torch.Tensor, labels: torch.Tensor) -> SimpleNamespac
     lab[cu[:-1].long()[seqlens > 0]] = IGNORE_INDEX
     return SimpleNamespace(rows=rows, position_ids=pos, labels=lab, cu_seqlens=cu, seqlens=seqlens,
                            max_seqlen=int(seqlens.max()) if B else 0, seq_of_tok=seq_id.to(torch.int32))
+
+
+def s2_plan(block_sizes, scales, grid: int, downsample: int):
+    """Host plan of the dynamic_s2 branch of encode_images (llava/model/llava_arch.py:298-390) for
+    s2_resize_output_to_scale_idx = -1 (the NVILA recipe, scripts/NVILA/stage1_9tile.sh:22):
+      desc      [n_blocks, 6] i32  {first tile of the image, bh, bw, block row, block col, single}  for vila_s2_merge_bf16
+      n_tiles   total tiles the tower must have produced (checked like the reference's assert, :360-362)
+      perm      per image: for every output token (h w order over the merged (g' bh) x (g' bw) grid, :386-389) its row in the
+                projector output [n_blocks * g'^2]   (merge_chessboard + "1 c h w -> (h w) c" as one row gather)
+    """
+    splits = [s // scales[0] for s in scales[:-1]]
+    n_pre = sum(s * s for s in splits)
+    gd = (grid + downsample - 1) // downsample
+    desc, perms, base, blk = [], [], 0, 0
+    for bs in block_sizes:
+        if bs is None:
+            desc.append([base, 1, 1, 0, 0, 1])
+            perms.append(torch.arange(blk * gd * gd, (blk + 1) * gd * gd, dtype=torch.int32))
+            base += 1
+            blk += 1
+            continue
+        bh, bw = int(bs[0]), int(bs[1])
+        for i in range(bh):
+            for j in range(bw):
+                desc.append([base, bh, bw, i, j, 0])
+        Y = torch.arange(gd * bh)[:, None]
+        X = torch.arange(gd * bw)[None, :]
+        src = (blk + (Y // gd) * bw + (X // gd)) * gd * gd + (Y % gd) * gd + (X % gd)
+        perms.append(src.reshape(-1).to(torch.int32))
+        base += n_pre + bh * bw
+        blk += bh * bw
+    return SimpleNamespace(desc=torch.tensor(desc, dtype=torch.int32), n_tiles=base, n_blocks=blk, perms=perms, splits=splits)

@@ -207,7 +207,7 @@ class HipMultimodalProjector(_HipModule):
             L = self.layers
             w = _lib.VilaProjWeights()
             w.kind = _PROJ_KIND[self.cfg.mm_projector_type]
-            w.in_dim, w.out_dim = self.cfg.vision.hidden_size, self.cfg.llm.hidden_size
+            w.in_dim, w.out_dim = self.cfg.mm_hidden_size, self.cfg.llm.hidden_size   # dynamic_s2: C * n_scales
             g = lambda i, n: getattr(getattr(L, str(i)), n).data_ptr()
             w.ln1_w, w.ln1_b, w.fc1_w, w.fc1_b = g(1, "weight"), g(1, "bias"), g(2, "weight"), g(2, "bias")
             if w.kind == 2:

@@ -275,3 +275,17 @@ def sumsq(x: torch.Tensor) -> torch.Tensor:
     out = torch.zeros((1,), device=x.device, dtype=torch.float32)
     check(_L().vila_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sumsq")
     return out
+
+
+def s2_merge(feats: torch.Tensor, desc: torch.Tensor, n_scales: int, splits) -> torch.Tensor:
+    """dynamic_s2: tower output [n_tiles, N, C] + block descriptors [n_blocks, 6] i32 -> projector input [n_blocks, N, n_scales*C]."""
+    import ctypes as C
+    _need(feats, name="feats")
+    assert desc.dtype == torch.int32 and desc.is_cuda and desc.dim() == 2 and desc.shape[1] == 6
+    n_tiles, N, Cc = feats.shape
+    g = int(round(N ** 0.5))
+    out = torch.empty((desc.shape[0], N, n_scales * Cc), device=feats.device, dtype=feats.dtype)
+    sp = (C.c_int32 * max(len(splits), 1))(*splits) if len(splits) else (C.c_int32 * 1)(1)
+    check(_L().vila_s2_merge_bf16(feats.contiguous().data_ptr(), out.data_ptr(), desc.contiguous().data_ptr(), desc.shape[0], g, Cc, n_scales, sp,
+                                  _stream()), "s2_merge")
+    return out

@@ -42,7 +42,7 @@ def vision_specs(cfg: VilaConfig) -> List[Spec]:
 
 def projector_specs(cfg: VilaConfig) -> List[Spec]:
     """Layer indices follow the nn.Sequential positions of base_projector.py:145-174."""
-    c, h = cfg.vision.hidden_size, cfg.llm.hidden_size
+    c, h = cfg.mm_hidden_size, cfg.llm.hidden_size
     p = "mm_projector.layers."
     t = cfg.mm_projector_type
     if t in ("mlp_downsample", "mlp_downsample_2x2_fix"):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .configs import IGNORE_INDEX, VilaConfig
-from .host import splice_plan
+from .host import s2_plan, splice_plan
 from .modules import HipMultimodalProjector, HipQwen2ForCausalLM, HipSiglipVisionTower
 
 
@@ -99,10 +99,31 @@ class HipLlavaLlamaModel(nn.Module):
         self.mm_projector.load_weights(w, "mm_projector.")
 
     # llava_arch.py:366-394 (plain branch; dynamic_s2 is SURVEY §8f "next")
-    def encode_images(self, images: torch.Tensor, block_sizes=None) -> torch.Tensor:
-        if getattr(self.cfg, "dynamic_s2", False):
-            raise NotImplementedError("dynamic_s2 is not implemented (SURVEY.md §8f item 1)")
-        return self.get_mm_projector()(self.get_vision_tower()(images))
+    def encode_images(self, images: torch.Tensor, block_sizes=None):
+        if not getattr(self.cfg, "dynamic_s2", False):
+            return self.get_mm_projector()(self.get_vision_tower()(images))
+        # dynamic_s2 (llava_arch.py:369-390): tower on every tile of every scale, one merge kernel, projector on the
+        # C*n_scales-wide blocks, chessboard re-merge of the projected blocks as a row gather
+        cfg = self.cfg
+        if cfg.s2_resize_output_to_scale_idx not in (-1, len(cfg.s2_scales) - 1):
+            raise NotImplementedError("dynamic_s2: only s2_resize_output_to_scale_idx = -1 (the NVILA recipe) is implemented")
+        if block_sizes is None:
+            block_sizes = [None] * len(images)
+        plan = s2_plan(block_sizes, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+        feats = self.get_vision_tower()(images)
+        if plan.n_tiles != feats.shape[0]:
+            raise AssertionError(f"The number of blocks ({plan.n_tiles}) does not match length of image_features ({feats.shape[0]})!")
+        x = ops.s2_merge(feats.to(self.dtype), plan.desc.to(feats.device), len(cfg.s2_scales), plan.splits)
+        y = self.get_mm_projector()(x)                                  # [n_blocks, g'^2, H]
+        flat = y.reshape(-1, y.shape[-1])
+        outs = []
+        for perm in plan.perms:
+            o = torch.empty((perm.numel(), flat.shape[1]), device=flat.device, dtype=flat.dtype)
+            ops.copy_rows(flat, o, perm.to(flat.device), None, int(perm.numel()))
+            outs.append(o)
+        if all(o.shape[0] == outs[0].shape[0] for o in outs):
+            return torch.stack(outs, 0)
+        return outs
 
     # llava_arch.py:412-490 + 528-555
     def _embed(self, input_ids: torch.Tensor, media: Dict[str, List[torch.Tensor]], media_config: Optional[Dict[str, Dict[str, Any]]] = None,
