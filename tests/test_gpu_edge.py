@@ -88,6 +88,24 @@ def test_long_context_decode_crosses_many_splits(tiny):
     assert torch.equal(a, b)
 
 
+def test_split_kv_decode_path_for_large_caches(tiny):
+    """Caches larger than 2048 positions use the split-KV + merge kernels instead of the single-launch per-head kernel:
+    both must reproduce the prefill logits."""
+    cfg, w, model = tiny
+    llm = model.llm
+    g = torch.Generator().manual_seed(8)
+    S, n = 150, 6
+    e = (torch.randn(1, S, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    forced = torch.randint(0, 900, (n,), generator=g)
+    full = torch.cat([e[0], llm.embed_tokens(forced[: n - 1].cuda())], 0)
+    T = full.shape[0]
+    ref = llm.prefill_packed(full, torch.arange(T, dtype=torch.int32, device="cuda"), None, T, want_all_logits=True).all_logits[S - 1:]
+    for max_ctx in (256, 2304):
+        cache = llm.new_cache(max_ctx)
+        _, lg = llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, forced_ids=forced, use_graph=False, cache=cache)
+        assert rel_l2(lg, ref) < 1.5e-2, f"max_ctx={max_ctx} rel={rel_l2(lg, ref):.3e}"
+
+
 def test_generate_stops_after_eos(tiny):
     cfg, w, model = tiny
     ids = synthetic.make_prompt(cfg, 8, 0, 9)[None]

@@ -467,10 +467,117 @@ __global__ __launch_bounds__(128) void attn_decode_merge(AttnDecodeArgs p) {
     p.o[h * 128 + d] = f2bf(o / L);
 }
 
+// ------------------------------------------------------------------------------------------------
+// single-launch decode attention for short contexts (cache capacity <= 2048): one block of 16 waves per QUERY head walks the
+// whole context (wave w takes 16-key chunks w, w+16, ...), online softmax per wave, cross-wave merge in LDS.  No split-KV
+// partials and no merge launch: 2 launches -> 1 per layer (each launch costs ~3-4 us of floor inside the decode graph); the
+// price is that the G = 7 query heads of a kv head each read that head's K/V (served by L2 / MALL, 2.5 % of a token's bytes).
+//   scores: lane = (key = lane/4, d quarter = lane%4): 32 FMAs + 2 cross-lane adds;  P.V: lane = (4-key subgroup, 8-wide d chunk)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
+    __shared__ float sq[128];
+    __shared__ float so[16][128];
+    __shared__ float sml[16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, kvh = h / (p.nq / p.nkv);
+    const int nkeys = *p.pos_ptr + 1;
+    const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
+    const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
+    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
+    __syncthreads();
+    const int kq = lane >> 2, qd = lane & 3;        // scores: key within the chunk, d quarter
+    const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup, d chunk
+    float qr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+
+    u32x4 kc[4], vc[4], kn_[4], vn_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
+    auto load_chunk = [&](int k0, u32x4 (&kk)[4], u32x4 (&vv)[4]) {
+        const int key = k0 + kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kk[j] = (key < nkeys) ? *(const u32x4*)(kb + (int64_t)key * 128 + qd * 32 + j * 8) : (u32x4){0u, 0u, 0u, 0u};
+            const int vk = k0 + sg * 4 + j;
+            vv[j] = (vk < nkeys) ? *(const u32x4*)(vb + (int64_t)vk * 128 + dc * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    int k0 = wave * 16;
+    if (k0 < nkeys) load_chunk(k0, kc, vc);
+    for (; k0 < nkeys; k0 += 256) {
+        const int kn = k0 + 256;
+        if (kn < nkeys) load_chunk(kn, kn_, vn_);            // prefetch the wave's next chunk under this chunk's math
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a = fmaf(lo_bf(kc[j][e]), qr[j * 8 + 2 * e], a);
+                a = fmaf(hi_bf(kc[j][e]), qr[j * 8 + 2 * e + 1], a);
+            }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        const float s = (k0 + kq < nkeys) ? a : -INFINITY;
+        float cm = s;
+        cm = fmaxf(cm, __shfl_xor(cm, 4, 64)); cm = fmaxf(cm, __shfl_xor(cm, 8, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float m_new = fmaxf(m, cm);
+        const float alpha = __expf(m - m_new);
+        const float pr = __expf(s - m_new);
+        float ps = pr;
+        ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pj = __shfl(pr, (sg * 4 + j) * 4, 64);   // probability of key k0 + sg*4 + j (held by lanes 4*key .. 4*key+3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] = fmaf(pj, lo_bf(vc[j][e]), o[2 * e]);
+                o[2 * e + 1] = fmaf(pj, hi_bf(vc[j][e]), o[2 * e + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kc[j] = kn_[j]; vc[j] = vn_[j]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) so[wave][dc * 8 + e] = o[e];
+    }
+    if (lane == 0) { sml[wave][0] = m; sml[wave][1] = l; }
+    __syncthreads();
+    if (tid < 128) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) M = fmaxf(M, sml[w][0]);
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float wgt = __expf(sml[w][0] - M);
+            L += wgt * sml[w][1];
+            acc += wgt * so[w][tid];
+        }
+        p.o[h * 128 + tid] = f2bf(acc / L);
+    }
+}
+
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.hd == 128, "attn_decode: head_dim must be 128 (got %d)", a.hd);
     VILA_REQUIRE(a.nq % a.nkv == 0 && a.nq / a.nkv <= DEC_MAXG, "attn_decode: GQA group %d/%d unsupported (max %d)", a.nq, a.nkv, DEC_MAXG);
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
+    if (a.o != nullptr && a.max_ctx <= 2048 && !a.force_split) {
+        hipLaunchKernelGGL(attn_decode_head, dim3(a.nq), dim3(1024), 0, s, a);
+        VILA_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)(DEC_MAXG * 128 + DEC_MAXG * DEC_KS + 16 * DEC_MAXG * 128) * 4;
     static bool attr_set = false;
     if (!attr_set) {

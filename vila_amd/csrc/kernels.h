@@ -83,6 +83,7 @@ struct AttnDecodeArgs {
     float* part_o; float* part_ml;   // workspace: [n_splits][nq][hd], [n_splits][nq][2]
     const int32_t* pos_ptr;          // context length BEFORE this token; keys 0..pos inclusive are attended
     int nq, nkv, hd, max_ctx, n_splits; float scale;
+    int force_split;                 // 1: always use the split-KV + merge pair (default: single-launch per-head kernel when max_ctx <= 2048)
 };
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
