@@ -1,0 +1,70 @@
+"""Checkpoint I/O in the reference's three-folder layout (llava_arch.py:158-204): CPU-only (tensor plumbing, no kernels)."""
+import json
+import os
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import save_file
+
+from vila_amd import checkpoint, configs
+from vila_amd.vlm import HipLlavaLlamaModel
+
+
+def _rand_model(cfg, seed):
+    m = HipLlavaLlamaModel(cfg, device="cpu")
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).to(p.dtype))
+    return m
+
+
+def test_save_layout_and_roundtrip(tmp_path):
+    cfg = configs.tiny("mlp_downsample_3x3_fix", tied=True)
+    m = _rand_model(cfg, 1)
+    d = str(tmp_path / "ckpt")
+    checkpoint.save_pretrained(m, d, max_shard_bytes=1 << 20)          # small shards: exercises the index.json path
+    assert sorted(os.listdir(d)) == ["config.json", "llm", "mm_projector", "vision_tower"]
+    assert os.path.exists(os.path.join(d, "llm", "model.safetensors.index.json"))
+    pj_keys = {k for k, _ in checkpoint._folder_tensors(os.path.join(d, "mm_projector"))}
+    assert pj_keys == {f"layers.{i}.{k}" for i in (1, 2, 4, 5, 7) for k in ("weight", "bias")}
+    keys = {k for k, _ in checkpoint._folder_tensors(os.path.join(d, "vision_tower"))}
+    assert "vision_model.embeddings.patch_embedding.weight" in keys and all(k.startswith("vision_model.") for k in keys)
+    idx = json.load(open(os.path.join(d, "llm", "model.safetensors.index.json")))
+    assert "model.layers.0.self_attn.q_proj.weight" in idx["weight_map"] and "lm_head.weight" not in idx["weight_map"]   # tied head
+    top = json.load(open(os.path.join(d, "config.json")))
+    assert top["architectures"] == ["LlavaLlamaModel"] and top["llm_cfg"]["model_type"] == "qwen2"
+    m2 = checkpoint.load_pretrained(d, device="cpu")
+    assert m2.cfg.mm_projector_type == cfg.mm_projector_type and m2.cfg.llm.tie_word_embeddings
+    sd1, sd2 = m.state_dict(), m2.state_dict()
+    assert set(sd1) == set(sd2)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    # q/k/v stayed views of one fused buffer after loading
+    a = getattr(m2.llm.model.layers, "0").self_attn
+    assert a.k_proj.weight.data_ptr() == a.q_proj.weight.data_ptr() + a.q_proj.weight.numel() * 2
+
+
+def test_reference_checkpoint_extras_are_ignored_and_missing_detected(tmp_path):
+    cfg = configs.tiny("mlp_downsample")
+    m = _rand_model(cfg, 2)
+    d = str(tmp_path / "ckpt")
+    checkpoint.save_pretrained(m, d)
+    # a real SigLIP checkpoint also carries the pooling head: must be ignored, not fatal
+    vt = os.path.join(d, "vision_tower", "model.safetensors")
+    tensors = {}
+    with safe_open(vt, framework="pt") as f:
+        for k in f.keys():
+            tensors[k] = f.get_tensor(k)
+    tensors["vision_model.head.probe"] = torch.zeros(1, 1, 144)
+    save_file(tensors, vt)
+    m2 = HipLlavaLlamaModel(cfg, device="cpu")
+    rep = checkpoint.load_weights_into(m2, d)
+    assert rep["ignored"] == ["vision_tower/vision_model.head.probe"] and not rep["missing"]
+    del tensors["vision_model.embeddings.patch_embedding.bias"]
+    save_file(tensors, vt)
+    try:
+        checkpoint.load_weights_into(HipLlavaLlamaModel(cfg, device="cpu"), d)
+        raise AssertionError("missing parameter not detected")
+    except KeyError as e:
+        assert "patch_embedding.bias" in str(e)

@@ -1,0 +1,152 @@
+"""Checkpoint I/O in the reference's three-folder layout (SURVEY.md §5 "Checkpoint / resume", §8f row 4).
+
+`LlavaMetaModel.save_pretrained` (llava/model/llava_arch.py:158-204) splits ONE state_dict by key prefix into
+    <dir>/llm/            keys `model.embed_tokens.weight`, `model.layers.N....`, `lm_head.weight`        (HF Qwen2 layout)
+    <dir>/vision_tower/   keys `vision_model....`   (prefix `vision_tower.vision_tower.` stripped, :177-179)
+    <dir>/mm_projector/   keys `layers.1.weight` ...
+plus a top-level config.json whose `llm_cfg / vision_tower_cfg / mm_projector_cfg` point at the sub-folders
+(llava/model/utils/utils.py:25-55).  Weights are HF safetensors (`model.safetensors` or shards + `model.safetensors.index.json`).
+The HIP modules keep exactly these key names, so loading is a name-for-name copy straight into the (fused / flat) parameter
+storage; unknown keys of real checkpoints (`vision_model.head.*`: the pooling head VILA never calls) are ignored.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Iterable, Optional
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import save_file
+
+from .configs import LlmConfig, VilaConfig, VisionConfig
+
+_PARTS = (("llm", "llm", ""), ("vision_tower", "vision_tower", "vision_tower."), ("mm_projector", "mm_projector", ""))
+
+
+def _shards(items: Iterable, max_bytes: int):
+    cur, size = {}, 0
+    for k, t in items:
+        n = t.numel() * t.element_size()
+        if cur and size + n > max_bytes:
+            yield cur
+            cur, size = {}, 0
+        cur[k] = t
+        size += n
+    if cur:
+        yield cur
+
+
+def _save_folder(folder: str, sd: Dict[str, torch.Tensor], cfg_json: dict, max_shard_bytes: int) -> None:
+    os.makedirs(folder, exist_ok=True)
+    # tied / view tensors must be materialised separately for safetensors
+    items = [(k, v.detach().to("cpu").contiguous().clone()) for k, v in sd.items()]
+    shards = list(_shards(items, max_shard_bytes))
+    if len(shards) == 1:
+        save_file(shards[0], os.path.join(folder, "model.safetensors"), metadata={"format": "pt"})
+    else:
+        wmap, total = {}, 0
+        for i, sh in enumerate(shards):
+            name = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(sh, os.path.join(folder, name), metadata={"format": "pt"})
+            for k, t in sh.items():
+                wmap[k] = name
+                total += t.numel() * t.element_size()
+        with open(os.path.join(folder, "model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": wmap}, f, indent=1)
+    with open(os.path.join(folder, "config.json"), "w") as f:
+        json.dump(cfg_json, f, indent=1)
+
+
+def _folder_tensors(folder: str):
+    idx = os.path.join(folder, "model.safetensors.index.json")
+    files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["model.safetensors"]
+    for fn in files:
+        with safe_open(os.path.join(folder, fn), framework="pt", device="cpu") as f:
+            for k in f.keys():
+                yield k, f.get_tensor(k)
+
+
+def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> None:
+    """Write the model in the reference's layout (llava_arch.py:158-204)."""
+    cfg: VilaConfig = model.cfg
+    c, v = cfg.llm, cfg.vision
+    llm_cfg = {"model_type": "qwen2", "architectures": ["Qwen2ForCausalLM"], "hidden_size": c.hidden_size, "intermediate_size": c.intermediate_size,
+               "num_hidden_layers": c.num_hidden_layers, "num_attention_heads": c.num_attention_heads, "num_key_value_heads": c.num_key_value_heads,
+               "vocab_size": c.vocab_size, "rms_norm_eps": c.rms_norm_eps, "rope_theta": c.rope_theta, "tie_word_embeddings": c.tie_word_embeddings,
+               "eos_token_id": c.eos_token_id, "torch_dtype": "bfloat16", "hidden_act": "silu"}
+    vt_cfg = {"model_type": "siglip_vision_model", "hidden_size": v.hidden_size, "intermediate_size": v.intermediate_size,
+              "num_hidden_layers": v.num_hidden_layers, "num_attention_heads": v.num_attention_heads, "image_size": v.image_size,
+              "patch_size": v.patch_size, "num_channels": v.num_channels, "layer_norm_eps": v.layer_norm_eps, "hidden_act": "gelu_pytorch_tanh"}
+    pj_cfg = {"model_type": "v2l_projector", "mm_projector_type": cfg.mm_projector_type}
+    for (attr, folder, strip), sub_cfg in zip(_PARTS, (llm_cfg, vt_cfg, pj_cfg)):
+        sd = getattr(model, attr).state_dict()
+        sd = {(k[len(strip):] if strip and k.startswith(strip) else k): t for k, t in sd.items()}
+        if attr == "llm" and c.tie_word_embeddings:
+            sd.pop("lm_head.weight", None)
+        _save_folder(os.path.join(output_dir, folder), sd, sub_cfg, max_shard_bytes)
+    top = {"model_type": "llava_llama", "architectures": ["LlavaLlamaModel"], "llm_cfg": llm_cfg, "vision_tower_cfg": vt_cfg,
+           "mm_projector_cfg": pj_cfg, "mm_projector_type": cfg.mm_projector_type, "mm_vision_select_layer": v.select_layer,
+           "mm_vision_select_feature": "cls_patch", "dynamic_s2": cfg.dynamic_s2, "s2_scales": ",".join(str(s) for s in cfg.s2_scales),
+           "s2_resize_output_to_scale_idx": cfg.s2_resize_output_to_scale_idx, "hidden_size": c.hidden_size,
+           "mm_hidden_size": cfg.mm_hidden_size, "image_token_id": cfg.image_token_id, "newline_token_id": cfg.newline_token_id,
+           "_name_or_path": output_dir}
+    with open(os.path.join(output_dir, "config.json"), "w") as f:
+        json.dump(top, f, indent=1)
+
+
+def config_from_pretrained(model_dir: str) -> VilaConfig:
+    top = json.load(open(os.path.join(model_dir, "config.json")))
+
+    def sub(key, folder):
+        cfg = top.get(key)
+        if isinstance(cfg, dict):
+            return cfg
+        path = cfg if isinstance(cfg, str) else os.path.join(model_dir, folder)
+        return json.load(open(os.path.join(path, "config.json")))
+    l, v = sub("llm_cfg", "llm"), sub("vision_tower_cfg", "vision_tower")
+    llm = LlmConfig(hidden_size=l["hidden_size"], intermediate_size=l["intermediate_size"], num_hidden_layers=l["num_hidden_layers"],
+                    num_attention_heads=l["num_attention_heads"], num_key_value_heads=l["num_key_value_heads"],
+                    head_dim=l.get("head_dim", l["hidden_size"] // l["num_attention_heads"]), vocab_size=l["vocab_size"],
+                    rms_norm_eps=l.get("rms_norm_eps", 1e-6), rope_theta=l.get("rope_theta", 1e6),
+                    tie_word_embeddings=l.get("tie_word_embeddings", False), eos_token_id=l.get("eos_token_id", 151645))
+    vis = VisionConfig(hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"], num_hidden_layers=v["num_hidden_layers"],
+                       num_attention_heads=v["num_attention_heads"], image_size=v["image_size"], patch_size=v["patch_size"],
+                       num_channels=v.get("num_channels", 3), layer_norm_eps=v.get("layer_norm_eps", 1e-6),
+                       select_layer=top.get("mm_vision_select_layer", -2))
+    scales = top.get("s2_scales", "448,896,1344")
+    return VilaConfig(vision=vis, llm=llm, mm_projector_type=top.get("mm_projector_type", "mlp_downsample"),
+                      image_token_id=top.get("image_token_id", 151649), newline_token_id=top.get("newline_token_id", 198),
+                      dynamic_s2=bool(top.get("dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
+                      s2_resize_output_to_scale_idx=top.get("s2_resize_output_to_scale_idx", -1), name=os.path.basename(model_dir.rstrip("/")))
+
+
+def load_weights_into(model, model_dir: str, strict: bool = True) -> Dict[str, list]:
+    """Name-for-name copy of the three folders into the (already constructed) HIP modules."""
+    report = {"missing": [], "ignored": []}
+    for attr, folder, strip in _PARTS:
+        mod = getattr(model, attr)
+        params = dict(mod.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for k, t in _folder_tensors(os.path.join(model_dir, folder)):
+                name = strip + k
+                if name in params:
+                    params[name].copy_(t.to(params[name].dtype))
+                    seen.add(name)
+                else:
+                    report["ignored"].append(f"{folder}/{k}")          # e.g. vision_model.head.* (pooling head, unused by VILA)
+        tied = attr == "llm" and model.cfg.llm.tie_word_embeddings
+        report["missing"] += [f"{folder}/{n}" for n in params if n not in seen and not (tied and n == "lm_head.weight")]
+    if strict and report["missing"]:
+        raise KeyError(f"checkpoint {model_dir} lacks parameters: {report['missing'][:8]}{' ...' if len(report['missing']) > 8 else ''}")
+    return report
+
+
+def load_pretrained(model_dir: str, device="cuda", dtype=torch.bfloat16):
+    """`llava.load(model_path)` for the HIP model: config from config.json, weights from the three sub-folders."""
+    from .vlm import HipLlavaLlamaModel
+    cfg = config_from_pretrained(model_dir)
+    model = HipLlavaLlamaModel(cfg, device, dtype)
+    load_weights_into(model, model_dir)
+    return model
