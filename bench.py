@@ -41,15 +41,20 @@ def parse():
     ap.add_argument("--mode", default="decode", choices=["decode", "sft", "video"],
                     help="decode = BASELINE.json metric (default); sft = one data-parallel SFT step (BASELINE configs[2])")
     ap.add_argument("--micro-batch", type=int, default=4)
+    ap.add_argument("--w4", action="store_true", help="W4A16 decode (int4 group-128 decoder projections; BASELINE configs[4], SURVEY 8f row 3)")
     ap.add_argument("--dynamic-s2", action="store_true", help="full NVILA-8B recipe: 14 tiles (448/896/1344) -> 2304 image tokens (SURVEY 8f row 1)")
     return ap.parse_args()
 
 
-def decode_bytes_per_token(cfg, ctx: int) -> int:
-    """Algorithmic HBM bytes per decoded token: every layer + lm_head weight once (bf16) + the KV cache."""
+def decode_bytes_per_token(cfg, ctx: int, w4: bool = False) -> int:
+    """Algorithmic HBM bytes per decoded token: every layer + lm_head weight once (bf16) + the KV cache.
+    W4A16: layer weights cost 0.5 B + 4 B per 128-group (scale|zero) = 0.53125 B each; lm_head stays bf16."""
     c = cfg.llm
     per_layer = (c.q_size + 2 * c.kv_size) * c.hidden_size + c.q_size * c.hidden_size + 3 * c.hidden_size * c.intermediate_size
-    w = (per_layer * c.num_hidden_layers + c.vocab_size * c.hidden_size) * 2
+    if w4:
+        w = per_layer * c.num_hidden_layers * 17 // 32 + c.vocab_size * c.hidden_size * 2
+    else:
+        w = (per_layer * c.num_hidden_layers + c.vocab_size * c.hidden_size) * 2
     kv = 2 * c.kv_size * 2 * c.num_hidden_layers * ctx
     return w + kv
 
@@ -232,6 +237,8 @@ def main():
         tt.append(t)
     ttft = statistics.median(tt)
 
+    if a.w4:
+        w4 = llm.quantize_w4()     # decode now streams int4 weights; the prefill above used bf16
     # ---- decode: capture one step in a hipGraph, replay ----
     st = llm._decode_session(cache, max_new)
     stream = st.stream
@@ -273,7 +280,7 @@ def main():
     n_generated = int(st.n_out.item())
     assert n_generated == a.warmup + a.steps, (n_generated, a.warmup, a.steps)
     ctx_mid = S + a.warmup + a.steps // 2
-    step_bytes = decode_bytes_per_token(cfg, ctx_mid)
+    step_bytes = decode_bytes_per_token(cfg, ctx_mid, a.w4)
     step_s = elapsed / a.steps
 
     # ---- roofline of the dominant kernel: gemv_kernel<1> (fused RMSNorm + gate/up GEMV + SiLU*mul = 54% of the decode
@@ -286,6 +293,13 @@ def main():
     reps = 4
 
     def gateup_all():
+        if a.w4:
+            for i in range(len(layers)):
+                L = w4.layers[i]
+                _lib.check(lib.vila_gemv_w4_bf16(x.data_ptr(), layers[i].post_attention_layernorm.weight.data_ptr(), c.rms_norm_eps,
+                                                 L.gate_q, L.gate_sz, L.up_q, L.up_sz, None, None, act.data_ptr(),
+                                                 c.intermediate_size, c.hidden_size, 1, stream.cuda_stream), "gemv_w4")
+            return
         for l in layers:
             _lib.check(lib.vila_gemv_bf16(x.data_ptr(), l.post_attention_layernorm.weight.data_ptr(), c.rms_norm_eps,
                                           l.mlp.gate_proj.weight.data_ptr(), l.mlp.up_proj.weight.data_ptr(), None, None,
@@ -301,17 +315,19 @@ def main():
     n_launch = reps * len(layers)
     kern_s = k0.elapsed_time(k1) * 1e-3 / n_launch           # includes the ~1.5 us launch boundary between kernels
     kern_bytes = 2 * c.intermediate_size * c.hidden_size * 2 + c.hidden_size * 2 * 2 + c.intermediate_size * 2
+    if a.w4:
+        kern_bytes = 2 * c.intermediate_size * c.hidden_size * 17 // 32 + c.hidden_size * 2 * 2 + c.intermediate_size * 2
     achieved = kern_bytes / kern_s / 1e9
     # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
     # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic, traffic_src = None, None
     tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if a.config == "nvila_8b" and os.path.exists(tj):
+    if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
         with open(tj) as f:
             tdata = json.load(f)
         if tdata.get("algorithmic_bytes_per_launch") == kern_bytes:
             traffic, traffic_src = tdata["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<1> (RMSNorm + gate/up GEMV + SiLU*mul)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": ("gemv_w4_kernel<1>" if a.w4 else "gemv_kernel<1>") + " (RMSNorm + gate/up GEMV + SiLU*mul)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_us": round(kern_s * 1e6, 2),
                 "whole_step": {"bytes_per_token": step_bytes, "achieved": round(step_bytes / step_s / 1e9, 1),
@@ -332,10 +348,10 @@ def main():
         "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / A100_DECODE_TOKS, 3) if a.config == "nvila_8b" else None,
         "vs_baseline_note": "value / 82.1 tok/s (NVILA-8B FP16 on ONE A100, TinyChat backend, README.md:65) — other hardware and fp16; no MI355X number is published",
-        "dtype": "bf16", "data": "synthetic (seeded random weights at NVILA-8B shapes; U(-1,1) pixels; random prompt ids)",
+        "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16", "data": "synthetic (seeded random weights at NVILA-8B shapes; U(-1,1) pixels; random prompt ids)",
         "ttft_ms": round(ttft * 1e3, 3),
         "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
-        "config": {"workload": f"{cfg.name} bf16, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
+        "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
                                f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                    "decode": "hipGraph replay of 171 launches/token (6 per layer + embed/lm_head/argmax/advance)"},
         "roofline": roofline,

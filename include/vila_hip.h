@@ -220,6 +220,23 @@ int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
 int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,
                        const int32_t* splits, vila_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * W4A16 decode (BASELINE configs[4]).  The reference's W4A16 backend is the external TinyChat
+ * (README.md:87), with no code in-tree: the packed format is defined in vila_amd/csrc/gemv_w4.hip and produced by
+ * vila_amd/quant.py; parity is against a CPU dequantise-then-fp32 oracle of the same quantised weights.
+ *   Wq  [N][K/8] u32 (nibble j<4 = element 2j, nibble j+4 = element 2j+1),  Wsz [N][K/128] u32 {bf16 scale, bf16 128+zero}
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void *qkv_q, *qkv_sz, *o_q, *o_sz, *gate_q, *gate_sz, *up_q, *up_sz, *down_q, *down_sz;
+} VilaLlmLayerW4;
+/* mode 0: y = W x (+bias)(+residual); mode 1: y = silu(Wg x) * (Wu x) (W2 = up); optional fused RMSNorm on x */
+int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz, const void* Wq2, const void* Wsz2,
+                      const void* bias, const void* residual, void* y, int N, int K, int mode, vila_stream_t stream);
+/* same contract as vila_llm_decode_step; `w` still supplies embed, norms, q/k/v biases and the bf16 lm_head */
+int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLayerW4* qlayers /*[host]*/, const VilaKvCache* cache,
+                            const VilaDecodeState* st, void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ class VilaLlmWeights(C.Structure):
                 ("norm_w", c_void_p), ("lm_head", c_void_p)]
 
 
+class VilaLlmLayerW4(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("qkv_q", "qkv_sz", "o_q", "o_sz", "gate_q", "gate_sz", "up_q", "up_sz", "down_q", "down_sz")]
+
+
 class VilaKvCache(C.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int), ("n_slots", c_int)]
 
@@ -112,6 +116,10 @@ PROTOTYPES = {
     "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
     "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "vila_gemv_w4_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_void_p]),
+    "vila_llm_decode_step_w4": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),
+                                        C.POINTER(VilaDecodeState), c_void_p, c_size_t, c_void_p]),
     "vila_s2_merge_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
 }
 

@@ -4,6 +4,7 @@
 #include "../../include/vila_hip.h"
 #include "kernels.h"
 #include "train.h"
+#include "w4.h"
 
 static thread_local char g_err[512] = "";
 void vila_set_error(const char* fmt, ...) {
@@ -484,4 +485,71 @@ extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* d
     int sp[4] = {1, 1, 1, 1};
     for (int k = 0; k < n_scales - 1 && k < 4; ++k) sp[k] = splits[k];
     return launch_s2_merge(B(feats), B(out), desc, n_blocks, grid, channels, n_scales, sp, S(stream));
+}
+
+// =================================================================================================
+// W4A16 decode: int4 group-128 weights for the five decoder-layer projections, bf16 everything else
+// =================================================================================================
+extern "C" int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz, const void* Wq2, const void* Wsz2,
+                                 const void* bias, const void* residual, void* y, int N, int K, int mode, vila_stream_t stream) {
+    GemvW4Args g{};
+    g.x = B(x); g.norm_w = B(norm_w); g.eps = eps; g.Wq = (const uint32_t*)Wq; g.Wsz = (const uint32_t*)Wsz; g.Wq2 = (const uint32_t*)Wq2;
+    g.Wsz2 = (const uint32_t*)Wsz2; g.bias = B(bias); g.residual = B(residual); g.y = B(y); g.N = N; g.K = K; g.mode = mode;
+    VILA_REQUIRE(mode == 0 || mode == 1, "vila_gemv_w4_bf16: mode must be 0 or 1");
+    return launch_gemv_w4(g, S(stream));
+}
+
+extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLayerW4* ql, const VilaKvCache* cache, const VilaDecodeState* st,
+                                       void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    const VilaLlmShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    VILA_REQUIRE(cache != nullptr && st != nullptr && ql != nullptr, "llm_decode_w4: cache/state/weights is NULL");
+    VILA_REQUIRE(workspace_bytes >= vila_llm_decode_workspace_bytes(&sh, cache->max_ctx), "llm_decode_w4: workspace too small");
+    const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd;
+    const int ns = dec_splits(cache->max_ctx);
+    Arena a(workspace, workspace_bytes);
+    bf16_t* x = a.take<bf16_t>(H);
+    bf16_t* x2 = a.take<bf16_t>(H);
+    bf16_t* q = a.take<bf16_t>(QS);
+    bf16_t* act = a.take<bf16_t>(F);
+    float* part_o = a.take<float>((size_t)ns * QS);
+    float* part_ml = a.take<float>((size_t)ns * sh.q_heads * 2);
+    float* tv = a.take<float>(256);
+    int* ti = a.take<int>(256);
+    float* rope_cs = a.take<float>(hd);
+    bf16_t* ao = a.take<bf16_t>(QS);
+    VILA_REQUIRE(a.ok(), "llm_decode_w4: workspace arena overflow");
+    VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
+    bf16_t* cur = x; bf16_t* nxt = x2;
+    for (int l = 0; l < sh.n_layers; ++l) {
+        const VilaLlmLayer& L = w->layers[l];
+        const VilaLlmLayerW4& Q = ql[l];
+        const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
+        bf16_t* kc = B(cache->k) + l * per_layer; bf16_t* vc = B(cache->v) + l * per_layer;
+        GemvW4Args qa{};
+        qa.x = cur; qa.norm_w = B(L.ln1_w); qa.eps = sh.rms_eps; qa.Wq = (const uint32_t*)Q.qkv_q; qa.Wsz = (const uint32_t*)Q.qkv_sz;
+        qa.bias = B(L.bq); qa.K = H; qa.N = QS + 2 * sh.kv_heads * hd; qa.mode = 3; qa.q_out = q; qa.kcache = kc; qa.vcache = vc; qa.pos_ptr = st->pos;
+        qa.rope_cs = rope_cs; qa.nq = sh.q_heads; qa.nkv = sh.kv_heads; qa.hd = hd; qa.max_ctx = cache->max_ctx;
+        VILA_TRY(launch_gemv_w4(qa, s));
+        AttnDecodeArgs ad{};
+        ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
+        ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
+        VILA_TRY(launch_attn_decode(ad, s));
+        GemvW4Args o{};
+        o.x = ao; o.Wq = (const uint32_t*)Q.o_q; o.Wsz = (const uint32_t*)Q.o_sz; o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
+        VILA_TRY(launch_gemv_w4(o, s));
+        GemvW4Args gu{};
+        gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.Wq = (const uint32_t*)Q.gate_q; gu.Wsz = (const uint32_t*)Q.gate_sz;
+        gu.Wq2 = (const uint32_t*)Q.up_q; gu.Wsz2 = (const uint32_t*)Q.up_sz; gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
+        VILA_TRY(launch_gemv_w4(gu, s));
+        GemvW4Args dn{};
+        dn.x = act; dn.Wq = (const uint32_t*)Q.down_q; dn.Wsz = (const uint32_t*)Q.down_sz; dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0;
+        VILA_TRY(launch_gemv_w4(dn, s));
+    }
+    GemvArgs lm{};
+    lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
+    VILA_TRY(launch_gemv(lm, s));       // lm_head stays bf16 (as AWQ / TinyChat keep it fp16)
+    VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
+    VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
+    return 0;
 }

@@ -1,0 +1,13 @@
+// W4A16 decode GEMV arguments (gemv_w4.hip).
+#pragma once
+#include "common.h"
+
+struct GemvW4Args {
+    const bf16_t* x; const bf16_t* norm_w; float eps;
+    const uint32_t* Wq; const uint32_t* Wsz;       // [N][K/8] packed nibbles, [N][K/128] {scale, 128+zero} bf16 pairs
+    const uint32_t* Wq2; const uint32_t* Wsz2;     // gate/up mode: the up matrix
+    const bf16_t* bias; const bf16_t* residual; bf16_t* y;
+    int N, K, mode;                                // 0 plain, 1 gate/up, 3 fused QKV + RoPE + KV append
+    bf16_t* q_out; bf16_t* kcache; bf16_t* vcache; const int32_t* pos_ptr; const float* rope_cs; int nq, nkv, hd, max_ctx;
+};
+int launch_gemv_w4(const GemvW4Args& a, hipStream_t s);

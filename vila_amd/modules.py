@@ -380,8 +380,21 @@ class HipQwen2ForCausalLM(_HipModule):
         self._decode = st
         return st
 
+    def quantize_w4(self):
+        """Build int4 (group-128) copies of the five decoder projections: decode then runs the W4A16 GEMVs
+        (vila_llm_decode_step_w4); prefill keeps using the bf16 weights."""
+        from .quant import W4Weights
+        self._w4 = W4Weights(self)
+        self._decode = None
+        return self._w4
+
     def decode_step(self, cache, st) -> None:
         lib = _lib.load()
+        w4 = getattr(self, "_w4", None)
+        if w4 is not None:
+            check(lib.vila_llm_decode_step_w4(C.byref(self._struct()), w4.ptr, C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(),
+                                              st.ws.numel(), ops._stream()), "vila_llm_decode_step_w4")
+            return
         check(lib.vila_llm_decode_step(C.byref(self._struct()), C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
                                        ops._stream()), "vila_llm_decode_step")
 
