@@ -238,7 +238,7 @@ def main():
     ttft = statistics.median(tt)
 
     if a.w4:
-        w4 = llm.quantize_w4()     # decode now streams int4 weights; the prefill above used bf16
+        w4 = llm.quantize_w4(keep_logical=False)     # decode now streams int4 weights; the prefill above used bf16
     # ---- decode: capture one step in a hipGraph, replay ----
     st = llm._decode_session(cache, max_new)
     stream = st.stream
@@ -297,7 +297,7 @@ def main():
             for i in range(len(layers)):
                 L = w4.layers[i]
                 _lib.check(lib.vila_gemv_w4_bf16(x.data_ptr(), layers[i].post_attention_layernorm.weight.data_ptr(), c.rms_norm_eps,
-                                                 L.gate_q, L.gate_sz, L.up_q, L.up_sz, None, None, act.data_ptr(),
+                                                 L.gateup_q, L.gateup_sz, None, None, act.data_ptr(),
                                                  c.intermediate_size, c.hidden_size, 1, stream.cuda_stream), "gemv_w4")
             return
         for l in layers:

@@ -225,13 +225,19 @@ int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_
  * W4A16 decode (BASELINE configs[4]).  The reference's W4A16 backend is the external TinyChat
  * (README.md:87), with no code in-tree: the packed format is defined in vila_amd/csrc/gemv_w4.hip and produced by
  * vila_amd/quant.py; parity is against a CPU dequantise-then-fp32 oracle of the same quantised weights.
- *   Wq  [N][K/8] u32 (nibble j<4 = element 2j, nibble j+4 = element 2j+1),  Wsz [N][K/128] u32 {bf16 scale, bf16 128+zero}
+ *   w = (q - zero) * scale, uint4 q, groups of 128 along K.  Tile-major HBM layout (16-row tiles, one 1-KB wave load per group):
+ *   Wq  [N/16][K/128][64 lanes][4] u32   lane = 16*g + n holds k = 128*group + 32*g + (0..31) of row n; per u32 nibble p<4 = element 2p,
+ *                                        nibble p+4 = element 2p+1
+ *   Wsz [N/16][K/128][16] u32            {bf16 scale, bf16 128 + zero}
+ *   Row order inside a matrix: o/down as the bf16 weight; gate/up interleaved (row 2i = gate i, 2i+1 = up i); q and k heads of
+ *   the fused qkv interleaved so RoPE partners are neighbours (row 2i = element i, 2i+1 = element i + head_dim/2), v heads as is.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
-    const void *qkv_q, *qkv_sz, *o_q, *o_sz, *gate_q, *gate_sz, *up_q, *up_sz, *down_q, *down_sz;
+    const void *qkv_q, *qkv_sz, *o_q, *o_sz, *gateup_q, *gateup_sz, *down_q, *down_sz;
 } VilaLlmLayerW4;
-/* mode 0: y = W x (+bias)(+residual); mode 1: y = silu(Wg x) * (Wu x) (W2 = up); optional fused RMSNorm on x */
-int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz, const void* Wq2, const void* Wsz2,
+/* N outputs.  mode 0: y = W x (+bias)(+residual); mode 1: W holds 2N interleaved gate/up rows, y = silu(Wg x) * (Wu x);
+ * optional fused RMSNorm on x.  K % 128 != 0 -> -1 */
+int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz,
                       const void* bias, const void* residual, void* y, int N, int K, int mode, vila_stream_t stream);
 /* same contract as vila_llm_decode_step; `w` still supplies embed, norms, q/k/v biases and the bf16 lm_head */
 int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLayerW4* qlayers /*[host]*/, const VilaKvCache* cache,

@@ -30,11 +30,16 @@ def _exact_w4(shape, seed, log2_scale=(-7, -6, -5)):
 
 
 def test_quantizer_roundtrip_and_packing():
-    from vila_amd.quant import dequantize_w4, quantize_w4
+    from vila_amd.quant import dequantize_w4, quantize_w4, tile_w4
     w = _exact_w4((64, 512), 0)
     q, sz = quantize_w4(w.cuda())
     assert q.shape == (64, 64) and sz.shape == (64, 4) and q.dtype == torch.int32
     assert torch.equal(dequantize_w4(q, sz).cpu(), w)
+    qt, szt = tile_w4(q[:37], sz[:37])                   # rows padded to 48 = 3 tiles
+    assert qt.numel() == 48 * 64 and szt.numel() == 48 * 4
+    # lane 16*g + n of (tile 1, group 2) holds words [8*2*... ] of row 16 + n: k = 256 + 32*g .. + 32
+    assert torch.equal(qt.view(3, 4, 4, 16, 4)[1, 2, 3, 5], q[21, 2 * 16 + 3 * 4: 2 * 16 + 3 * 4 + 4])
+    assert torch.equal(szt.view(3, 4, 16)[1, 2, 5], sz[21, 2])
     # generic weights: error bounded by half a quantisation step (+ bf16 rounding of the scale)
     g = torch.Generator().manual_seed(1)
     w = (torch.randn(32, 256, generator=g) * 0.05)
@@ -44,24 +49,24 @@ def test_quantizer_roundtrip_and_packing():
     assert ((d - w).view(32, 2, 128).abs().amax(-1) <= 0.52 * step + 1e-6).all()
 
 
-@pytest.mark.parametrize("N,K", [(3584, 3584), (3584, 18944), (37, 128), (2, 256), (4608, 3584)])
+@pytest.mark.parametrize("N,K", [(3584, 3584), (3584, 18944), (37, 128), (2, 256), (4608, 3584), (512, 1152), (48, 8192)])
 @pytest.mark.parametrize("fused", ["plain", "norm_bias_residual"])
 def test_gemv_w4_vs_dequantised_fp32(N, K, fused):
     from vila_amd import ops
-    from vila_amd.quant import dequantize_w4, quantize_w4
+    from vila_amd.quant import W4Matrix
     g = torch.Generator().manual_seed(N * 7 + K)
     w = torch.randn(N, K, generator=g) * 0.03
     x = torch.randn(K, generator=g).to(torch.bfloat16)
-    q, sz = quantize_w4(w.cuda())
-    wd = dequantize_w4(q, sz).cpu()
+    mat = W4Matrix.pack(w.cuda())
+    wd = mat.dequantized().cpu()
     if fused == "plain":
-        y = ops.gemv_w4(x.cuda(), q, sz)
+        y = ops.gemv_w4(x.cuda(), mat)
         ref = wd @ x.float()
     else:
         nw = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16)
         b = torch.randn(N, generator=g).to(torch.bfloat16)
         r = torch.randn(N, generator=g).to(torch.bfloat16)
-        y = ops.gemv_w4(x.cuda(), q, sz, norm_w=nw.cuda(), eps=1e-6, bias=b.cuda(), residual=r.cuda())
+        y = ops.gemv_w4(x.cuda(), mat, norm_w=nw.cuda(), eps=1e-6, bias=b.cuda(), residual=r.cuda())
         xn = O.rms_norm(x.float()[None], nw.float(), 1e-6)[0].to(torch.bfloat16).float()
         ref = wd @ xn + b.float() + r.float()
     assert rel_l2(y, ref) < 1e-2, f"rel={rel_l2(y, ref):.3e}"
@@ -70,23 +75,42 @@ def test_gemv_w4_vs_dequantised_fp32(N, K, fused):
 @pytest.mark.parametrize("N,K", [(18944, 3584), (1152, 512), (5, 128)])
 def test_gemv_w4_gate_up(N, K):
     from vila_amd import ops
-    from vila_amd.quant import dequantize_w4, quantize_w4
+    from vila_amd.quant import W4Matrix
     g = torch.Generator().manual_seed(N + K)
     wg, wu = torch.randn(N, K, generator=g) * 0.03, torch.randn(N, K, generator=g) * 0.03
     x = torch.randn(K, generator=g).to(torch.bfloat16)
     nw = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16)
-    (qg, sg), (qu, su) = quantize_w4(wg.cuda()), quantize_w4(wu.cuda())
-    y = ops.gemv_w4(x.cuda(), qg, sg, norm_w=nw.cuda(), eps=1e-6, wq2=qu, wsz2=su)
+    mat = W4Matrix.pack(wg.cuda(), wu.cuda())
+    y = ops.gemv_w4(x.cuda(), mat, norm_w=nw.cuda(), eps=1e-6)
+    assert y.shape == (N,)
+    dg, du = mat.dequantized()
     xn = O.rms_norm(x.float()[None], nw.float(), 1e-6)[0].to(torch.bfloat16).float()
-    ref = torch.nn.functional.silu(dequantize_w4(qg, sg).cpu() @ xn) * (dequantize_w4(qu, su).cpu() @ xn)
+    ref = torch.nn.functional.silu(dg.cpu() @ xn) * (du.cpu() @ xn)
     assert rel_l2(y, ref) < 1.5e-2, f"rel={rel_l2(y, ref):.3e}"
+
+
+def test_gemv_w4_large_offsets_cancel():
+    """The kernel computes sum x*(128+q) on the matrix cores and removes the 128- and zero-offsets per group afterwards: an
+    activation with a large mean makes that cancellation as hard as it gets."""
+    from vila_amd import ops
+    from vila_amd.quant import W4Matrix
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(256, 1024, generator=g) * 0.02
+    x = (3.0 + torch.randn(1024, generator=g)).to(torch.bfloat16)
+    mat = W4Matrix.pack(w.cuda())
+    y = ops.gemv_w4(x.cuda(), mat)
+    ref = mat.dequantized().cpu() @ x.float()
+    assert rel_l2(y, ref) < 1e-2, f"rel={rel_l2(y, ref):.3e}"
 
 
 def test_gemv_w4_rejects_bad_k():
     from vila_amd import ops
+    from vila_amd.quant import W4Matrix
+    mat = W4Matrix.pack(torch.zeros((4, 256), device="cuda"))
+    mat.K = 192
     x = torch.zeros(192, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(ValueError, match="multiple of the 128"):
-        ops.gemv_w4(x, torch.zeros((4, 24), device="cuda", dtype=torch.int32), torch.zeros((4, 2), device="cuda", dtype=torch.int32))
+        ops.gemv_w4(x, mat)
 
 
 def _w4_model(cfg, seed, log2_scale):

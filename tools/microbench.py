@@ -83,6 +83,28 @@ def bench_gemv():
         print(f"N={N:6d} K={K:6d} mode={mode}: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s")
 
 
+def bench_w4():
+    """W4A16 GEMVs; rotates over enough weight copies (> 600 MB) that the 256 MB Infinity Cache cannot serve re-reads."""
+    from vila_amd.quant import W4Matrix
+    print("== GEMV W4A16 (GB/s of packed weight bytes: 0.53125 B/weight) ==")
+    for N, K, mode in [(4608, 3584, 0), (3584, 3584, 0), (18944, 3584, 1), (3584, 18944, 0)]:
+        by = N * K * (2 if mode else 1) * 17 // 32
+        ncopy = max(2, int(6e8 // by))
+        mats = []
+        for i in range(ncopy):
+            w = rnd(N, K, scale=K ** -0.5)
+            mats.append(W4Matrix.pack(w, rnd(N, K, scale=K ** -0.5) if mode else None, keep_logical=False))
+        x, g = rnd(K), rnd(K)
+        state = {"i": 0}
+
+        def run():
+            state["i"] = (state["i"] + 1) % ncopy
+            ops.gemv_w4(x, mats[state["i"]], norm_w=g if K == 3584 else None, eps=1e-6)
+        t = timeit(run, iters=4 * ncopy, warm=ncopy)
+        print(f"N={N:6d} K={K:6d} mode={mode} copies={ncopy}: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s")
+        del mats
+
+
 def bench_attn():
     print("== attention fwd (TFLOP/s, 4*T*T*D*H (x0.5 causal)) ==")
     for T, Hq, Hkv, D, causal, nseq in [(1024, 16, 16, 72, False, 1), (8192, 16, 16, 72, False, 8), (769, 28, 4, 128, True, 1),
@@ -105,5 +127,7 @@ if __name__ == "__main__":
         bench_gemm()
     if what in ("gemv", "all"):
         bench_gemv()
+    if what in ("w4",):
+        bench_w4()
     if what in ("attn", "all"):
         bench_attn()

@@ -47,7 +47,7 @@ class VilaLlmWeights(C.Structure):
 
 
 class VilaLlmLayerW4(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("qkv_q", "qkv_sz", "o_q", "o_sz", "gate_q", "gate_sz", "up_q", "up_sz", "down_q", "down_sz")]
+    _fields_ = [(n, c_void_p) for n in ("qkv_q", "qkv_sz", "o_q", "o_sz", "gateup_q", "gateup_sz", "down_q", "down_sz")]
 
 
 class VilaKvCache(C.Structure):
@@ -116,7 +116,7 @@ PROTOTYPES = {
     "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
     "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
-    "vila_gemv_w4_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "vila_gemv_w4_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_void_p]),
     "vila_llm_decode_step_w4": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),
                                         C.POINTER(VilaDecodeState), c_void_p, c_size_t, c_void_p]),

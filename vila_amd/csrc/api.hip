@@ -490,12 +490,13 @@ extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* d
 // =================================================================================================
 // W4A16 decode: int4 group-128 weights for the five decoder-layer projections, bf16 everything else
 // =================================================================================================
-extern "C" int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz, const void* Wq2, const void* Wsz2,
+extern "C" int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* Wq, const void* Wsz,
                                  const void* bias, const void* residual, void* y, int N, int K, int mode, vila_stream_t stream) {
     GemvW4Args g{};
-    g.x = B(x); g.norm_w = B(norm_w); g.eps = eps; g.Wq = (const uint32_t*)Wq; g.Wsz = (const uint32_t*)Wsz; g.Wq2 = (const uint32_t*)Wq2;
-    g.Wsz2 = (const uint32_t*)Wsz2; g.bias = B(bias); g.residual = B(residual); g.y = B(y); g.N = N; g.K = K; g.mode = mode;
+    g.x = B(x); g.norm_w = B(norm_w); g.eps = eps; g.Wq = (const uint32_t*)Wq; g.Wsz = (const uint32_t*)Wsz;
+    g.bias = B(bias); g.residual = B(residual); g.y = B(y); g.N = N; g.K = K; g.mode = mode;
     VILA_REQUIRE(mode == 0 || mode == 1, "vila_gemv_w4_bf16: mode must be 0 or 1");
+    VILA_REQUIRE(x != nullptr && Wq != nullptr && Wsz != nullptr && y != nullptr, "vila_gemv_w4_bf16: NULL pointer");
     return launch_gemv_w4(g, S(stream));
 }
 
@@ -539,8 +540,8 @@ extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLay
         o.x = ao; o.Wq = (const uint32_t*)Q.o_q; o.Wsz = (const uint32_t*)Q.o_sz; o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
         VILA_TRY(launch_gemv_w4(o, s));
         GemvW4Args gu{};
-        gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.Wq = (const uint32_t*)Q.gate_q; gu.Wsz = (const uint32_t*)Q.gate_sz;
-        gu.Wq2 = (const uint32_t*)Q.up_q; gu.Wsz2 = (const uint32_t*)Q.up_sz; gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
+        gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.Wq = (const uint32_t*)Q.gateup_q; gu.Wsz = (const uint32_t*)Q.gateup_sz;
+        gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
         VILA_TRY(launch_gemv_w4(gu, s));
         GemvW4Args dn{};
         dn.x = act; dn.Wq = (const uint32_t*)Q.down_q; dn.Wsz = (const uint32_t*)Q.down_sz; dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0;

@@ -4,10 +4,9 @@
 
 struct GemvW4Args {
     const bf16_t* x; const bf16_t* norm_w; float eps;
-    const uint32_t* Wq; const uint32_t* Wsz;       // [N][K/8] packed nibbles, [N][K/128] {scale, 128+zero} bf16 pairs
-    const uint32_t* Wq2; const uint32_t* Wsz2;     // gate/up mode: the up matrix
+    const uint32_t* Wq; const uint32_t* Wsz;       // tile-major packed nibbles / {scale, zero} bf16 pairs (layout: gemv_w4.hip header)
     const bf16_t* bias; const bf16_t* residual; bf16_t* y;
-    int N, K, mode;                                // 0 plain, 1 gate/up, 3 fused QKV + RoPE + KV append
+    int N, K, mode;                                // N = outputs. 0 plain, 1 gate/up (2N interleaved rows), 3 fused QKV + RoPE + KV append
     bf16_t* q_out; bf16_t* kcache; bf16_t* vcache; const int32_t* pos_ptr; const float* rope_cs; int nq, nkv, hd, max_ctx;
 };
 int launch_gemv_w4(const GemvW4Args& a, hipStream_t s);

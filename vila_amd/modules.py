@@ -380,11 +380,11 @@ class HipQwen2ForCausalLM(_HipModule):
         self._decode = st
         return st
 
-    def quantize_w4(self):
+    def quantize_w4(self, keep_logical: bool = True):
         """Build int4 (group-128) copies of the five decoder projections: decode then runs the W4A16 GEMVs
         (vila_llm_decode_step_w4); prefill keeps using the bf16 weights."""
         from .quant import W4Weights
-        self._w4 = W4Weights(self)
+        self._w4 = W4Weights(self, keep_logical)
         self._decode = None
         return self._w4
 

@@ -117,15 +117,13 @@ def gemv(x: torch.Tensor, w: torch.Tensor, norm_w: Optional[torch.Tensor] = None
     return y
 
 
-def gemv_w4(x: torch.Tensor, wq: torch.Tensor, wsz: torch.Tensor, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0,
-            wq2: Optional[torch.Tensor] = None, wsz2: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+def gemv_w4(x: torch.Tensor, mat, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0, bias: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """W4A16 GEMV on weights packed by vila_amd.quant.quantize_w4 (Wq [N,K/8] int32, Wsz [N,K/128] int32)."""
-    _need(x, name="x"); _need(wq, dtype=torch.int32, name="wq"); _need(wsz, dtype=torch.int32, name="wsz")
-    N, K = wq.shape[0], wq.shape[1] * 8
-    y = torch.empty((N,), device=x.device, dtype=torch.bfloat16)
-    check(_lib.load().vila_gemv_w4_bf16(x.data_ptr(), _p(norm_w), eps, wq.data_ptr(), wsz.data_ptr(), _p(wq2), _p(wsz2), _p(bias),
-                                        _p(residual), y.data_ptr(), N, K, 1 if wq2 is not None else 0, _stream()), "gemv_w4")
+    """W4A16 GEMV on a vila_amd.quant.W4Matrix (tile-major int4, group 128); gate/up matrices give silu(Wg x) * (Wu x)."""
+    _need(x, name="x"); _need(mat.q, dtype=torch.int32, name="mat.q"); _need(mat.sz, dtype=torch.int32, name="mat.sz")
+    y = torch.empty((mat.N,), device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().vila_gemv_w4_bf16(x.data_ptr(), _p(norm_w), eps, mat.q.data_ptr(), mat.sz.data_ptr(), _p(bias), _p(residual),
+                                        y.data_ptr(), mat.N, mat.K, mat.mode, _stream()), "gemv_w4")
     return y
 
 
