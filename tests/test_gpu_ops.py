@@ -43,7 +43,7 @@ def test_gemm_plain_bias_residual(ops, M, N, K):
     assert rel_l2(out32, ref) < 2e-5, f"fp32-out rel={rel_l2(out32, ref):.3e}"
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 136), (769, 3584, 512), (1, 24, 40), (3076, 1088, 512), (513, 260, 72), (700, 520, 128)])
 def test_gemm_every_tile_shape(ops, tile, M, N, K):
     """The three tile shapes (128x128, 128x64, 256x128) must agree with the fp32 reference on every epilogue."""
@@ -65,7 +65,7 @@ def test_gemm_every_tile_shape(ops, tile, M, N, K):
         lib.vila_gemm_force_tile(0)
 
 
-@pytest.mark.parametrize("M,N,K", [(769, 3584, 18944), (600, 520, 1024), (769, 4608, 3584)])
+@pytest.mark.parametrize("M,N,K", [(769, 3584, 18944), (600, 520, 1024), (769, 4608, 3584), (1024, 1152, 4304), (515, 300, 1096)])
 def test_gemm_splitk_with_workspace(ops, M, N, K):
     """Split-K over grid.y of the 256x256 LDS-DMA kernel (fp32 slabs + reduce with bias/residual)."""
     from vila_amd import _lib

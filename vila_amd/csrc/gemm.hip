@@ -208,7 +208,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 bool gemm256_supported(const GemmArgs& a);
 int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
-static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel
+bool gemm_ring_supported(const GemmArgs& a);
+int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
+static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 
 template <int EPI, bool OUT_F32>
@@ -221,15 +223,27 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     }
     // under-filled grid of 256^2 tiles (S = 769 prefill: 56 tiles for N = 3584): slice K over grid.y when a workspace is given
     if ((sel == 0 || sel == 5) && EPI == EPI_NONE && !OUT_F32 && a.ws != nullptr && a.M >= 512 && gemm256_supported(a)) {
-        const int kt = a.K / 64;
+        const int kt = cdiv(a.K, 64);
         int splits = 0;      // largest power of two that keeps every slice resident at once (1 block of 512 threads per CU)
         for (int c = 2; c <= 8; c *= 2)
             if (kt % c == 0 && kt / c >= 8 && tiles256 * c <= 256 && (size_t)c * a.M * a.N * 4 <= a.ws_bytes) splits = c;
+        // K < 8192 (o_proj at S = 769): the DMA ring below does it in one launch at 557 TF/s vs 482 incl. the reduce
+        if (kt < 128 && sel == 0) splits = 0;
         // measured at M = 769 (tools/microbench.py prefill): N=3584,K=18944 233 -> 122 us; N=3584,K=3584 51 -> 41 us;
         // N=4608 (72 tiles) only breaks even, so require at least 4 slices
         if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);
     }
     if (sel == 5) sel = 0;
+    // short / under-filled problems: the 4-deep DMA ring (gemm_ring.hip) instead of the one-tile-ahead register staging
+    if (EPI != EPI_GATEUP && !OUT_F32 && gemm_ring_supported(a)) {
+        const int64_t tiles_ring = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64);
+        // measured (tools/microbench.py tiles): with two 3-stage blocks per CU the ring wins whenever its grid fits ~one round of
+        // 512 resident blocks — S=769 q/k/v 473 -> 675 TF/s, o_proj 397 -> 557, ViT fc2 168 -> 297 — and loses to the 128x128 /
+        // 256x256 tiles beyond that (LDS-read-bound at ~470 TF/s sustained)
+        if (sel == 7 || (sel == 0 && tiles_ring <= 560)) return launch_gemm_ring(a, 3, s);
+        if (sel == 6) return launch_gemm_ring(a, 4, s);
+    }
+    if (sel == 6 || sel == 7) sel = 0;
     if (sel == 0) {
         const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
         if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;

@@ -16,7 +16,10 @@
 // Variants: fused gate/up epilogue (each wave's 64 B rows = 32 gate + 32 up rows of the same output columns -> silu(g)*u),
 // and split-K (grid.y slices of K write fp32 slabs that splitk_reduce_kernel sums with bias / residual) for the
 // M = 769 x N = 3584 prefill shapes whose 56 tiles cannot fill 256 CUs.
-// Requires K % 64 == 0 (callers pad the contraction dim); M / N tails by row clamping + masked stores.
+// K tail (K % 64 != 0, K % 8 == 0): the 16-B chunks of the last K-tile that lie beyond K are DMA'd from a zero chunk in global
+// memory (LDS-DMA cannot predicate a lane's LDS write, but it can read a different address).  M / N tails by row clamping +
+// masked stores.  (Skipping the MFMAs of half-tiles beyond M was measured and does not pay: with one tile of prefetch the DMA
+// round trip of a K-tile costs as much as its 64 MFMAs, so an "empty" tile is not cheaper than a full one.)
 #include "kernels.h"
 
 #define T256_BK 64
@@ -24,6 +27,8 @@
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised)
 
 // MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators)
 template <int MODE, int EPI>
@@ -64,14 +69,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     auto issue_tile = [&](int t, int buf) {
         const int k0 = (kt0 + t) * T256_BK;
         char* base = smem + buf * BUF_BYTES + lds_lane_base;
+        if (k0 + T256_BK <= p.K) {                          // block-uniform: every K-tile but a ragged last one
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[h][i] + k0), (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
-                const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
-                __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc + boff[h][i] + k0), (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
-            }
+                for (int i = 0; i < 2; ++i) {
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[h][i] + k0), (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
+                    const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc + boff[h][i] + k0), (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
+                }
+        } else {
+            const bool kin = k0 + kch * 8 < p.K;            // this lane's 16-B chunk is inside K
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16_t* asrc = kin ? p.A + aoff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
+                    __builtin_amdgcn_global_load_lds((gbl_void*)asrc, (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
+                    const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
+                    wsrc = kin ? wsrc + boff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
+                    __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
+                }
+        }
     };
 
     // ---- fragment read offsets (bytes inside a half-tile) ----
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (MODE == 3) ? k_tiles_per_split : p.K / T256_BK;
+    const int nt = (MODE == 3) ? k_tiles_per_split : (p.K + T256_BK - 1) / T256_BK;
     issue_tile(0, 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -249,14 +268,14 @@ static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1) {
         VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int kt = a.K / T256_BK;
+    const int kt = cdiv(a.K, T256_BK);
     hipLaunchKernelGGL((gemm256_kernel<MODE, EPI>), dim3(tiles_m * tiles_n, splits), dim3(512), lds, s, a, tiles_m, kt / splits);
     VILA_LAUNCH_CHECK();
     return 0;
 }
 
 bool gemm256_supported(const GemmArgs& a) {
-    return a.K % T256_BK == 0 && a.K >= 2 * T256_BK && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
+    return a.K % 8 == 0 && a.K >= 2 * T256_BK && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
@@ -272,8 +291,8 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
 
 // split-K: C = sum over `splits` K-slices; `slab` = splits * M * N fp32 workspace owned by the caller
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s) {
-    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && (a.K / T256_BK) % splits == 0 && a.N % 4 == 0, "gemm256 split-K: K tiles (%d) must divide by %d",
-                 a.K / T256_BK, splits);
+    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && cdiv(a.K, T256_BK) % splits == 0 && a.N % 4 == 0, "gemm256 split-K: K tiles (%d) must divide by %d",
+                 cdiv(a.K, T256_BK), splits);
     GemmArgs b = a;
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
     VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits)));

@@ -1,0 +1,205 @@
+// 128x64x64 bf16 MFMA GEMM with a 4-deep LDS-DMA ring, for the SHORT contractions of the path: the ViT blocks (M = 1024 per
+// image, K = 1152 / 4304), the mm_projector and the S = 769 q/k/v projection.  
+//
+// Why a third kernel: those GEMMs are 3-10 GFLOP with 18-67 K-tiles.  gemm.hip stages HBM -> VGPR -> LDS with ONE tile of
+// prefetch, so every K-tile pays a full memory round trip (~0.7 us measured per tile, 7 % of the MFMA rate), and gemm256's
+// 256^2 tiles leave 90 % of the CUs idle (M = 1024, N = 1152 is 20 tiles).  Here the tile is small enough to spread over the
+// chip (128x64: 144 blocks for that shape) and the K loop keeps THREE K-tiles in flight: `global_load_lds` (16 B per lane, no
+// VGPR round trip) fills a ring of 4 stages x (A 16 KB + B 8 KB), counted `s_waitcnt vmcnt` releases tile t while t+1 and
+// t+2 are still landing, one barrier per K-tile.
+//   4 waves = 2 (M) x 2 (N), wave tile 64 x 32 = 4 x 2 accumulator fragments of v_mfma_f32_16x16x32_bf16, 16 MFMAs per wave
+//   and K-tile against 12 ds_read_b128: LDS-read-bound at ~2/3 of the MFMA rate — fine for GEMMs this small, and the reason
+//   the big contractions stay on gemm256 (0.375 reads per MFMA).
+//   LDS image is lane-linear for the DMA; the 16-B slot swizzle (slot ^= (row >> 1) & 7, conflict-free for ds_read_b128, same
+//   involution as gemm.hip / gemm256.hip) is applied on the per-lane SOURCE address and on the fragment reads.
+//   K tail: chunks of the last K-tile beyond K are DMA'd from a zero chunk.  M / N tails: row clamping + masked stores.
+// Epilogues: bias, GELU (tanh / erf), residual, bf16 out.
+#include "kernels.h"
+
+#define RG_BM 128
+#define RG_BN 64
+#define RG_BK 64
+#define RG_STG 36          // fp32 staging row stride (floats) of the epilogue
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __attribute__((aligned(16))) unsigned int g_ring_zero_chunk[4];   // K-tail source (zero-initialised)
+
+// STAGES = 4: one block per CU, three K-tiles in flight (grids of at most one round); STAGES = 3: two blocks per CU (72 KB each),
+// two K-tiles in flight each — a second wave per SIMD overlaps one block's LDS reads with the other's MFMAs
+template <int EPI, int RG_STAGES>
+__global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = RG_BM * RG_BK * 2;           // 16 KB
+    constexpr int B_BYTES = RG_BN * RG_BK * 2;           // 8 KB
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id % tiles_m, tn = id / tiles_m;
+    const int m0 = tm * RG_BM, n0 = tn * RG_BN;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // ---- DMA source offsets: chunk c = (i * 4 + wave) * 64 + lane of a tile: row = c >> 3, LDS slot = c & 7 ----
+    uint32_t aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 4 + wave) * 64 + lane, row = c >> 3;
+        const int kch = (c & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row; gm = gm < M ? gm : M - 1;
+        aoff[i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (i * 4 + wave) * 64 + lane, row = c >> 3;
+        const int kch = (c & 7) ^ ((row >> 1) & 7);
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        boff[i] = (uint32_t)gn * (uint32_t)p.ldw + kch * 8;
+    }
+    // row = c >> 3 = 8 * (i*4 + wave) + (lane >> 3)  =>  (row >> 1) & 7 = 4 * (wave & 1) + (lane >> 4), the same for every i
+    const int kch_lane = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 1024);
+    auto issue_tile = [&](int t) {
+        const int k0 = t * RG_BK;
+        char* base = smem + (t % RG_STAGES) * STAGE_BYTES + wave_lds;
+        if (k0 + RG_BK <= K) {                              // block-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[i] + k0), (lds_void*)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(p.W + boff[i] + k0), (lds_void*)(base + A_BYTES + i * 4096), 16, 0, 0);
+        } else {
+            const bool kin = k0 + kch_lane * 8 < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* src = kin ? p.A + aoff[i] + k0 : (const bf16_t*)g_ring_zero_chunk;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 4096), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16_t* src = kin ? p.W + boff[i] + k0 : (const bf16_t*)g_ring_zero_chunk;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + A_BYTES + i * 4096), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a tile) ----
+    const int swr = (l15 >> 1) & 7;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * 128 + (((ks * 4 + lg) ^ swr) << 4);
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (K + RG_BK - 1) / RG_BK;
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (RG_STAGES == 4 && nt > 2) issue_tile(2);
+    for (int t = 0; t < nt; ++t) {
+        // own DMAs of tile t have landed (6 per tile and lane; the later tiles may still be in flight)
+        if (RG_STAGES == 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // everyone's have; everyone has left tile t-1 (its stage is free)
+        asm volatile("" ::: "memory");
+        if (t + RG_STAGES - 1 < nt) issue_tile(t + RG_STAGES - 1);   // into the stage tile t-1 occupied
+        const char* cA = smem + (t % RG_STAGES) * STAGE_BYTES + wr * 64 * 128;
+        const char* cB = smem + (t % RG_STAGES) * STAGE_BYTES + A_BYTES + wc * 32 * 128;
+        bf16x8 af[4][2], bfr[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // all LDS reads of the last tile done before the ring is reused as staging
+
+    // ---- epilogue: per-wave fp32 staging [64][RG_STG], then row-coalesced bf16 stores (8 lanes x 8 B per row) ----
+    float* wst = (float*)smem + wave * 64 * RG_STG;
+    const int ncol0 = n0 + wc * 32;
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = ncol0 + j * 16 + l15;
+        bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
+                if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                wst[(i * 16 + lg * 4 + r) * RG_STG + j * 16 + l15] = v;
+            }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int rr0 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 8 + rr0;
+        const int gm = m0 + wr * 64 + rr, gc = ncol0 + c4;
+        if (gm < M && gc < N) {
+            f32x4 v = *(const f32x4*)(wst + rr * RG_STG + c4);
+            if (p.residual != nullptr) {
+                const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
+                v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+            }
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+        }
+    }
+}
+
+template <int EPI, int STAGES>
+static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = cdiv(a.M, RG_BM), tiles_n = cdiv(a.N, RG_BN);
+    const size_t lds = STAGES * (RG_BM + RG_BN) * RG_BK * 2;        // 98304 / 73728 >= 4 waves x 64 x 36 x 4 staging
+    static bool attr_set = false;
+    if (!attr_set) {
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, STAGES>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm_ring_supported(const GemmArgs& a) {
+    return a.epi != EPI_GATEUP && !a.out_f32 && a.K % 8 == 0 && a.K >= RG_BK && a.N % 4 == 0 && (int64_t)a.M * a.lda < (1ll << 31) &&
+           (int64_t)a.N * a.ldw < (1ll << 31);
+}
+
+int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s) {
+    if (stages == 3) {
+        switch (a.epi) {
+            case EPI_NONE: return launch_ring_t<EPI_NONE, 3>(a, s);
+            case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, 3>(a, s);
+            case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, 3>(a, s);
+        }
+    }
+    switch (a.epi) {
+        case EPI_NONE: return launch_ring_t<EPI_NONE, 4>(a, s);
+        case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, 4>(a, s);
+        case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, 4>(a, s);
+    }
+    VILA_FAIL(-1, "gemm_ring: unsupported epilogue %d", a.epi);
+}
