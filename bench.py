@@ -353,7 +353,8 @@ def main():
         "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
         "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
                                f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                   "decode": "hipGraph replay of 171 launches/token (6 per layer + embed/lm_head/argmax/advance)"},
+                   "decode": f"hipGraph replay of {c.num_hidden_layers * (5 if cache.c.max_ctx <= 2048 else 6) + 5} launches/token "
+                             f"({5 if cache.c.max_ctx <= 2048 else 6} per layer + embed/lm_head/argmax x2/advance)"},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
