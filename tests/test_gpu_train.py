@@ -78,7 +78,7 @@ def test_attention_backward(ops, bounds, Hq, Hkv, D, causal):
 
 
 @pytest.mark.parametrize("rms", [False, True])
-@pytest.mark.parametrize("rows,cols", [(300, 1152), (64, 3584), (10, 144)])
+@pytest.mark.parametrize("rows,cols", [(300, 1152), (64, 3584), (10, 144), (3076, 3584), (37, 4096), (5, 4608), (13, 100)])
 def test_norm_backward(ops, rms, rows, cols):
     x = randn_bf16(rows, cols, seed=9, scale=1.5) + 0.3
     w = randn_bf16(cols, seed=10, scale=0.1) + 1

@@ -325,11 +325,136 @@ __global__ void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = f2bf(src[i] + (accumulate ? bf2f(dst[i]) : 0.f));
 }
+// Wave-per-row variant for cols <= 512 * MAXI (the RMSNorm / LayerNorm widths of the model: 3584, 1152): a wave keeps the row's x
+// and dy in registers (16-B loads, one pass over HBM), all row reductions are wave-level (no block barriers), every wave walks
+// NB_ROWS rows accumulating its dw / db columns in registers; the four waves of a block meet once in LDS and the block issues
+// one fp32 atomic per column.  (The generic kernel above re-reads the row 4x with 2-B loads and crosses ~10 block barriers per
+// row: 127 us for [3076, 3584] vs ~20 us here.)
+#define NB_ROWS 3
+template <bool RMS, int MAXI>
+__global__ __launch_bounds__(256) void norm_bwd_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ dy,
+                                                            bf16_t* __restrict__ dx, float* __restrict__ dw32, float* __restrict__ db32,
+                                                            int rows, int cols, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4][cols] (+ [4][cols] for db)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = cols >> 3;
+    const float inv_cols = 1.f / (float)cols;
+    u32x4 wv[MAXI];
+    float dwacc[MAXI][8], dbacc[RMS ? 1 : MAXI][8];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        wv[i] = (c < nch) ? *(const u32x4*)(w + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[i][e] = 0.f; if (!RMS) dbacc[i][e] = 0.f; }
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * NB_ROWS;
+#pragma unroll 1
+    for (int r = 0; r < NB_ROWS; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;                                     // wave-uniform
+        const bf16_t* xr = x + (int64_t)row * cols;
+        const bf16_t* gr = dy + (int64_t)row * cols;
+        u32x4 xv[MAXI], gv[MAXI];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = (c < nch) ? *(const u32x4*)(xr + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+            gv[i] = (c < nch) ? *(const u32x4*)(gr + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float a = lo_bf(xv[i][k]), b = hi_bf(xv[i][k]); s1 += a + b; s2 += a * a + b * b; }
+        float mean = 0.f, rstd;
+        if (RMS) {
+            rstd = rsqrtf(wave_sum(s2) * inv_cols + eps);
+        } else {
+            mean = wave_sum(s1) * inv_cols;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                if (lane + 64 * i < nch) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float a = lo_bf(xv[i][k]) - mean, b = hi_bf(xv[i][k]) - mean; q += a * a + b * b; }
+                }
+            }
+            rstd = rsqrtf(wave_sum(q) * inv_cols + eps);
+        }
+        float sa = 0.f, sb = 0.f;                                   // sum(g), sum(g * xhat), g = dy * w
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g0 = lo_bf(gv[i][k]) * lo_bf(wv[i][k]), g1 = hi_bf(gv[i][k]) * hi_bf(wv[i][k]);
+                const float x0 = (lo_bf(xv[i][k]) - mean) * rstd, x1 = (hi_bf(xv[i][k]) - mean) * rstd;
+                if (lane + 64 * i < nch) { sa += g0 + g1; sb += g0 * x0 + g1 * x1; }
+            }
+        const float ma = RMS ? 0.f : wave_sum(sa) * inv_cols, mb = wave_sum(sb) * inv_cols;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d0 = lo_bf(gv[i][k]), d1 = hi_bf(gv[i][k]);
+                    const float x0 = (lo_bf(xv[i][k]) - mean) * rstd, x1 = (hi_bf(xv[i][k]) - mean) * rstd;
+                    o[k] = pack2bf(rstd * (d0 * lo_bf(wv[i][k]) - ma - x0 * mb), rstd * (d1 * hi_bf(wv[i][k]) - ma - x1 * mb));
+                    dwacc[i][2 * k] += d0 * x0; dwacc[i][2 * k + 1] += d1 * x1;
+                    if (!RMS) { dbacc[i][2 * k] += d0; dbacc[i][2 * k + 1] += d1; }
+                }
+                *(u32x4*)(dx + (int64_t)row * cols + c * 8) = o;
+            }
+        }
+    }
+    // ---- four waves meet in LDS, one atomic per column and block ----
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[wave * cols + c * 8 + e] = dwacc[i][e];
+                if (!RMS) red[(4 + wave) * cols + c * 8 + e] = dbacc[i][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < cols; c += 256) {
+        atomicAdd(dw32 + c, (red[c] + red[cols + c]) + (red[2 * cols + c] + red[3 * cols + c]));
+        if (!RMS && db32 != nullptr) atomicAdd(db32 + c, (red[4 * cols + c] + red[5 * cols + c]) + (red[6 * cols + c] + red[7 * cols + c]));
+    }
+}
+
+template <bool RMS, int MAXI>
+static void launch_norm_bwd_wave(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, float* dw32, float* db32, int rows, int cols, float eps,
+                                 hipStream_t s) {
+    const size_t lds = (size_t)(RMS ? 4 : 8) * cols * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)norm_bwd_wave_kernel<RMS, MAXI>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 * 2);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((norm_bwd_wave_kernel<RMS, MAXI>), dim3(cdiv(rows, 4 * NB_ROWS)), dim3(256), lds, s, x, w, dy, dx, dw32, db32, rows, cols, eps);
+}
+
 int launch_norm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, float* scratch /*2*cols fp32*/,
                     int rows, int cols, float eps, int rms, int accumulate, hipStream_t s) {
     VILA_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * cols * sizeof(float), s));
-    if (rms) hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, (float*)nullptr, rows, cols, eps);
-    else hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, scratch + cols, rows, cols, eps);
+    const bool aligned = cols % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)w % 16 == 0;
+    if (aligned && rms && cols <= 3584) {
+        launch_norm_bwd_wave<true, 7>(x, w, dy, dx, scratch, nullptr, rows, cols, eps, s);
+    } else if (aligned && rms && cols <= 4096) {
+        launch_norm_bwd_wave<true, 8>(x, w, dy, dx, scratch, nullptr, rows, cols, eps, s);
+    } else if (aligned && !rms && cols <= 1536) {
+        launch_norm_bwd_wave<false, 3>(x, w, dy, dx, scratch, scratch + cols, rows, cols, eps, s);
+    } else if (rms) {
+        hipLaunchKernelGGL(norm_bwd_kernel<true>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, (float*)nullptr, rows, cols, eps);
+    } else {
+        hipLaunchKernelGGL(norm_bwd_kernel<false>, dim3(cdiv(rows, 8)), dim3(256), 0, s, x, w, dy, dx, scratch, scratch + cols, rows, cols, eps);
+    }
     VILA_LAUNCH_CHECK();
     hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, scratch, dw, cols, accumulate);
     VILA_LAUNCH_CHECK();
