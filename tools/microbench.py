@@ -28,12 +28,13 @@ def rnd(*s, scale=1.0):
 def bench_gemm_tiles():
     from vila_amd import _lib
     lib = _lib.load()
-    print("== GEMM tile shapes (TFLOP/s): auto | 128x128 | 128x64 | 256x128 | 256x256dma | ring4 | ring3 ==")
+    print("== GEMM tile shapes (TFLOP/s): auto | 128x128 | 128x64 | 256x128 | 256x256dma | ring4 | ring3 | ring128 ==")
     for M, N, K in [(769, 4608, 3584), (769, 3584, 3584), (769, 3584, 18944), (1024, 1152, 1152), (1024, 1152, 4304), (1024, 4304, 1152),
-                    (1024, 3456, 1152), (4096, 1152, 1152), (4096, 1152, 4304), (4096, 4304, 1152), (256, 3584, 4608), (3076, 3584, 3584), (3076, 3584, 18944), (3584, 3584, 3080), (18944, 3584, 3080), (4096, 4096, 4096), (8192, 8192, 8192)]:
+                    (1024, 3456, 1152), (4096, 1152, 1152), (4096, 1152, 4304), (4096, 4304, 1152), (4096, 3456, 1152), (1152, 1152, 4096),
+                    (4304, 1152, 4096), (1152, 4304, 4096), (3456, 1152, 4096), (256, 3584, 4608), (3076, 3584, 3584), (3076, 3584, 18944), (3584, 3584, 3080), (18944, 3584, 3080), (4096, 4096, 4096), (8192, 8192, 8192)]:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
         res = []
-        for tile in (0, 1, 2, 3, 4, 6, 7):
+        for tile in (0, 1, 2, 3, 4, 6, 7, 8):
             lib.vila_gemm_force_tile(tile)
             t = timeit(lambda: ops.gemm(a, w), iters=10)
             res.append(2.0 * M * N * K / t / 1e12)

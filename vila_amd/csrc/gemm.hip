@@ -210,7 +210,7 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
 bool gemm_ring_supported(const GemmArgs& a);
 int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
-static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages
+static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 
 template <int EPI, bool OUT_F32>
@@ -234,16 +234,18 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);
     }
     if (sel == 5) sel = 0;
-    // short / under-filled problems: the 4-deep DMA ring (gemm_ring.hip) instead of the one-tile-ahead register staging
+    // everything below the gemm256 threshold: the LDS-DMA ring kernels (gemm_ring.hip) instead of the one-tile-ahead register staging
     if (EPI != EPI_GATEUP && !OUT_F32 && gemm_ring_supported(a)) {
         const int64_t tiles_ring = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64);
-        // measured (tools/microbench.py tiles): with two 3-stage blocks per CU the ring wins whenever its grid fits ~one round of
-        // 512 resident blocks — S=769 q/k/v 473 -> 675 TF/s, o_proj 397 -> 557, ViT fc2 168 -> 297 — and loses to the 128x128 /
-        // 256x256 tiles beyond that (LDS-read-bound at ~470 TF/s sustained)
-        if (sel == 7 || (sel == 0 && tiles_ring <= 560)) return launch_gemm_ring(a, 3, s);
+        // measured (tools/microbench.py tiles): the 128x64 3-stage ring wins while its grid fits about one round of the 512
+        // resident blocks (S=769 q/k/v 473 -> 675 TF/s, o_proj 397 -> 557, ViT fc2 168 -> 297); beyond that the 128x128 2-stage
+        // ring takes over from the register-staged 128x128 kernel (SFT ViT shapes 376-590 -> 459-697, 4096^3 810 -> 1015)
+        const int64_t tiles128r = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
+        if (sel == 7 || (sel == 0 && tiles_ring <= 560 && tiles128r < 270)) return launch_gemm_ring(a, 3, s);
         if (sel == 6) return launch_gemm_ring(a, 4, s);
+        if (sel == 8 || sel == 0) return launch_gemm_ring(a, 8, s);
     }
-    if (sel == 6 || sel == 7) sel = 0;
+    if (sel == 6 || sel == 7 || sel == 8) sel = 0;
     if (sel == 0) {
         const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
         if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;

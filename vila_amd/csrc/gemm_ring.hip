@@ -1,4 +1,4 @@
-// 128x64x64 bf16 MFMA GEMM with a 4-deep LDS-DMA ring, for the SHORT contractions of the path: the ViT blocks (M = 1024 per
+// 128x64x64 / 128x128x64 bf16 MFMA GEMM with an LDS-DMA ring, for the SHORT contractions of the path: the ViT blocks (M = 1024 per
 // image, K = 1152 / 4304), the mm_projector and the S = 769 q/k/v projection.  
 //
 // Why a third kernel: those GEMMs are 3-10 GFLOP with 18-67 K-tiles.  gemm.hip stages HBM -> VGPR -> LDS with ONE tile of
@@ -17,33 +17,37 @@
 #include "kernels.h"
 
 #define RG_BM 128
-#define RG_BN 64
 #define RG_BK 64
-#define RG_STG 36          // fp32 staging row stride (floats) of the epilogue
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __attribute__((aligned(16))) unsigned int g_ring_zero_chunk[4];   // K-tail source (zero-initialised)
 
-// STAGES = 4: one block per CU, three K-tiles in flight (grids of at most one round); STAGES = 3: two blocks per CU (72 KB each),
-// two K-tiles in flight each — a second wave per SIMD overlaps one block's LDS reads with the other's MFMAs
-template <int EPI, int RG_STAGES>
-__global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
+// NF = 16-column fragments per wave: NF = 2 -> 128 x 64 tile (24 KB per stage), NF = 4 -> 128 x 128 tile (32 KB per stage, wave
+// tile 64 x 64: 16 ds_read_b128 per 32 MFMAs).  RG_STAGES x stage bytes <= 72 KB keeps two blocks per CU, so a second wave per
+// SIMD overlaps one block's LDS reads with the other's MFMAs:  <NF=2, 3 stages> for grids of about one round (two K-tiles in
+// flight per block), <NF=4, 2 stages> for the mid-size GEMMs of the SFT step's ViT (M = 4096, N, K in 1152..4304).
+template <int EPI, int RG_STAGES, int NF>
+__global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 72 * 1024) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 32 * NF;
     constexpr int A_BYTES = RG_BM * RG_BK * 2;           // 16 KB
-    constexpr int B_BYTES = RG_BN * RG_BK * 2;           // 8 KB
+    constexpr int B_BYTES = BN * RG_BK * 2;              // 8 / 16 KB
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int B_IT = BN / 32;                        // DMA instructions per wave for the B tile (1 KB each)
+    constexpr int DMA_PER_TILE = 4 + B_IT;
+    constexpr int STG = 16 * NF + 4;                     // fp32 staging row stride (floats) of the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id % tiles_m, tn = id / tiles_m;
-    const int m0 = tm * RG_BM, n0 = tn * RG_BN;
+    const int m0 = tm * RG_BM, n0 = tn * BN;
     const int M = p.M, N = p.N, K = p.K;
 
     // ---- DMA source offsets: chunk c = (i * 4 + wave) * 64 + lane of a tile: row = c >> 3, LDS slot = c & 7 ----
-    uint32_t aoff[4], boff[2];
+    uint32_t aoff[4], boff[B_IT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 4 + wave) * 64 + lane, row = c >> 3;
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kerne
         aoff[i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_IT; ++i) {
         const int c = (i * 4 + wave) * 64 + lane, row = c >> 3;
         const int kch = (c & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row; gn = gn < N ? gn : N - 1;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kerne
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[i] + k0), (lds_void*)(base + i * 4096), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < B_IT; ++i)
                 __builtin_amdgcn_global_load_lds((gbl_void*)(p.W + boff[i] + k0), (lds_void*)(base + A_BYTES + i * 4096), 16, 0, 0);
         } else {
             const bool kin = k0 + kch_lane * 8 < K;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kerne
                 __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 4096), 16, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < B_IT; ++i) {
                 const bf16_t* src = kin ? p.W + boff[i] + k0 : (const bf16_t*)g_ring_zero_chunk;
                 __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + A_BYTES + i * 4096), 16, 0, 0);
             }
@@ -92,29 +96,30 @@ __global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kerne
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * 128 + (((ks * 4 + lg) ^ swr) << 4);
 
-    f32x4 acc[4][2];
+    f32x4 acc[4][NF];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = (K + RG_BK - 1) / RG_BK;
-    issue_tile(0);
-    if (nt > 1) issue_tile(1);
-    if (RG_STAGES == 4 && nt > 2) issue_tile(2);
+#pragma unroll
+    for (int t = 0; t < RG_STAGES - 1; ++t)
+        if (t < nt) issue_tile(t);
     for (int t = 0; t < nt; ++t) {
-        // own DMAs of tile t have landed (6 per tile and lane; the later tiles may still be in flight)
-        if (RG_STAGES == 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // own DMAs of tile t have landed; up to RG_STAGES - 2 later tiles may still be in flight (DMA_PER_TILE per tile and lane)
+        const int later = (nt - 1 - t) < (RG_STAGES - 2) ? (nt - 1 - t) : (RG_STAGES - 2);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_TILE) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // everyone's have; everyone has left tile t-1 (its stage is free)
         asm volatile("" ::: "memory");
         if (t + RG_STAGES - 1 < nt) issue_tile(t + RG_STAGES - 1);   // into the stage tile t-1 occupied
         const char* cA = smem + (t % RG_STAGES) * STAGE_BYTES + wr * 64 * 128;
-        const char* cB = smem + (t % RG_STAGES) * STAGE_BYTES + A_BYTES + wc * 32 * 128;
-        bf16x8 af[4][2], bfr[2][2];
+        const char* cB = smem + (t % RG_STAGES) * STAGE_BYTES + A_BYTES + wc * (16 * NF) * 128;
+        bf16x8 af[4][2], bfr[NF][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
 #pragma unroll
@@ -126,59 +131,65 @@ __global__ __launch_bounds__(256, (RG_STAGES == 3) ? 2 : 1) void gemm_ring_kerne
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
     }
     __syncthreads();   // all LDS reads of the last tile done before the ring is reused as staging
 
-    // ---- epilogue: per-wave fp32 staging [64][RG_STG], then row-coalesced bf16 stores (8 lanes x 8 B per row) ----
-    float* wst = (float*)smem + wave * 64 * RG_STG;
-    const int ncol0 = n0 + wc * 32;
-    float bv[2];
+    // ---- epilogue: two passes of 32 rows through per-wave fp32 staging [32][STG], then row-coalesced bf16 stores ----
+    float* wst = (float*)smem + wave * 32 * STG;
+    const int ncol0 = n0 + wc * (16 * NF);
+    float bv[NF];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NF; ++j) {
         const int col = ncol0 + j * 16 + l15;
         bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
     }
+    constexpr int LPR = 4 * NF, RPI = 64 / LPR;             // lanes per row (4 floats each), rows per store instruction
+    const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv[j];
-                if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
-                if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
-                wst[(i * 16 + lg * 4 + r) * RG_STG + j * 16 + l15] = v;
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[2 * h + ii][j][r] + bv[j];
+                    if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
+                    if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                    wst[(ii * 16 + lg * 4 + r) * STG + j * 16 + l15] = v;
+                }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + rr0;
+            const int gm = m0 + wr * 64 + h * 32 + rr, gc = ncol0 + c4;
+            if (gm < M && gc < N) {
+                f32x4 v = *(const f32x4*)(wst + rr * STG + c4);
+                if (p.residual != nullptr) {
+                    const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
+                    v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+                }
+                u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+                *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
             }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const int rr0 = lane >> 3, c4 = (lane & 7) * 4;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int rr = it * 8 + rr0;
-        const int gm = m0 + wr * 64 + rr, gc = ncol0 + c4;
-        if (gm < M && gc < N) {
-            f32x4 v = *(const f32x4*)(wst + rr * RG_STG + c4);
-            if (p.residual != nullptr) {
-                const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
-                v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
-            }
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int EPI, int STAGES>
+template <int EPI, int STAGES, int NF>
 static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
-    const int tiles_m = cdiv(a.M, RG_BM), tiles_n = cdiv(a.N, RG_BN);
-    const size_t lds = STAGES * (RG_BM + RG_BN) * RG_BK * 2;        // 98304 / 73728 >= 4 waves x 64 x 36 x 4 staging
+    const int tiles_m = cdiv(a.M, RG_BM), tiles_n = cdiv(a.N, 32 * NF);
+    const size_t lds = (size_t)STAGES * (RG_BM + 32 * NF) * RG_BK * 2;    // >= 4 waves x 32 x (16 NF + 4) x 4 B of staging
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, STAGES, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, STAGES>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, STAGES, NF>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
     VILA_LAUNCH_CHECK();
     return 0;
 }
@@ -188,18 +199,19 @@ bool gemm_ring_supported(const GemmArgs& a) {
            (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
-int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s) {
-    if (stages == 3) {
-        switch (a.epi) {
-            case EPI_NONE: return launch_ring_t<EPI_NONE, 3>(a, s);
-            case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, 3>(a, s);
-            case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, 3>(a, s);
-        }
-    }
+template <int STAGES, int NF>
+static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
-        case EPI_NONE: return launch_ring_t<EPI_NONE, 4>(a, s);
-        case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, 4>(a, s);
-        case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, 4>(a, s);
+        case EPI_NONE: return launch_ring_t<EPI_NONE, STAGES, NF>(a, s);
+        case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, STAGES, NF>(a, s);
+        case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, STAGES, NF>(a, s);
     }
     VILA_FAIL(-1, "gemm_ring: unsupported epilogue %d", a.epi);
+}
+
+// variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU)
+int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {
+    if (variant == 8) return launch_ring_epi<2, 4>(a, s);
+    if (variant == 4) return launch_ring_epi<4, 2>(a, s);
+    return launch_ring_epi<3, 2>(a, s);
 }
