@@ -193,10 +193,22 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VILA_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when the communicator is created; stdout must carry the one JSON line only,
+        # so fd 1 points at stderr while the process group and its first collective come up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if a.mode == "video":
         return video_main(a, rank, dev)
