@@ -86,6 +86,22 @@ def test_gemm_splitk_with_workspace(ops, M, N, K):
     assert rel_l2(x, a.float() @ w.float().t() + res.float()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(769, 18944, 1024), (769, 18944, 3584), (289, 18944, 3584), (600, 16640, 1096)])
+def test_gemm_gateup_tail_round_split(ops, M, N, K):
+    """Gate/up GEMM whose last round of 256x256 tiles is under-filled: full rounds fused + K-sliced tail + silu(g)*u reduce.
+    Must equal the single-launch result (same tolerance as every gate/up epilogue: rel-L2 <= 5e-3 vs fp32)."""
+    a = randn_bf16(M, K, seed=61)
+    w = randn_bf16(N, K, seed=62, scale=K ** -0.5)
+    w2 = randn_bf16(N, K, seed=63, scale=K ** -0.5)
+    ws = torch.empty(6 * M * 3584, device="cuda", dtype=torch.float32)
+    ref = torch.nn.functional.silu(a.float() @ w.float().t()) * (a.float() @ w2.float().t())
+    out_plain = ops.gemm(a, w, w2=w2, epi=3)
+    out_split = ops.gemm(a, w, w2=w2, epi=3, ws=ws)
+    assert rel_l2(out_plain, ref) < 5e-3
+    assert rel_l2(out_split, ref) < 5e-3, f"rel={rel_l2(out_split, ref):.3e}"
+    assert rel_l2(out_split, out_plain) < 3e-3
+
+
 def test_gemm_detects_transpose_and_identity(ops):
     """A = I with an asymmetric W must give exactly W^T rows (guide rule: symmetric inputs hide a swapped C layout)."""
     n = 256

@@ -178,7 +178,7 @@ extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T)
     b += align_up((size_t)T * F * 2, 256);                     // act
     b += 2 * align_up((size_t)T * (s->head_dim / 2) * 4, 256); // rope cos/sin
     b += align_up((size_t)T * H * 2, 256);                     // gathered last rows / final norm
-    b += align_up((size_t)4 * T * H * 4, 256);                 // split-K fp32 slabs (o_proj / down_proj at small T)
+    b += align_up((size_t)6 * T * H * 4, 256);                 // split-K fp32 slabs (down_proj; tail round of gate/up) at small T
     return b + 8192;
 }
 
@@ -201,8 +201,8 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     float* cs = a.take<float>((size_t)T * hd / 2);
     float* sn = a.take<float>((size_t)T * hd / 2);
     bf16_t* lastbuf = a.take<bf16_t>((size_t)T * H);
-    float* skws = a.take<float>((size_t)4 * T * H);
-    const size_t skws_bytes = (size_t)4 * T * H * 4;
+    float* skws = a.take<float>((size_t)6 * T * H);
+    const size_t skws_bytes = (size_t)6 * T * H * 4;
     VILA_REQUIRE(a.ok(), "llm_prefill: workspace arena overflow");
     if (cache != nullptr) VILA_REQUIRE(max_seqlen <= cache->max_ctx, "llm_prefill: sequence (%d) longer than the KV cache (%d)", max_seqlen, cache->max_ctx);
 
@@ -240,7 +240,7 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
         VILA_TRY(launch_attn_fwd(at, s));
         VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes));   // x += o_proj(attn)
         VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
-        VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, T, F, H, EPI_GATEUP, s, L.w_up));  // silu(gate)*up
+        VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, T, F, H, EPI_GATEUP, s, L.w_up, 0, skws, skws_bytes));  // silu(gate)*up
         VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, T, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes));  // x += down(...)
         if (taps) VILA_HIP(hipMemcpyAsync(taps + (size_t)(l + 1) * T * H, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
     }

@@ -30,18 +30,21 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised)
 
-// MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators)
+// MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
+//       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)
+// tile0 = first tile id of this launch (a GEMM may be issued as "full rounds" + "split tail"), col0 = first output column of the slab
 template <int MODE, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
     constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
-    constexpr bool GU = (MODE == 2);
+    constexpr bool GU = (MODE == 2 || MODE == 4);
+    constexpr bool SPLIT = (MODE == 3 || MODE == 4);
     constexpr int BN_OUT = GU ? 128 : 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int id = xcd_remap(blockIdx.x, gridDim.x) + tile0;
     const int tm = id % tiles_m, tn = id / tiles_m;
     const int m0 = tm * 256, n0 = tn * BN_OUT;
     const int M = p.M, N = p.N;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             boff[h][i] = (uint32_t)gn * (uint32_t)p.ldw + kch * 8;
         }
     const int lds_lane_base = __builtin_amdgcn_readfirstlane(wave * 1024);   // wave-uniform: 64 lanes x 16 B per DMA
-    const int kt0 = (MODE == 3) ? blockIdx.y * k_tiles_per_split : 0;
+    const int kt0 = SPLIT ? blockIdx.y * k_tiles_per_split : 0;
     auto issue_tile = [&](int t, int buf) {
         const int k0 = (kt0 + t) * T256_BK;
         char* base = smem + buf * BUF_BYTES + lds_lane_base;
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (MODE == 3) ? k_tiles_per_split : (p.K + T256_BK - 1) / T256_BK;
+    const int kt_all = (p.K + T256_BK - 1) / T256_BK;
+    const int nt = SPLIT ? ((kt_all - kt0) < k_tiles_per_split ? (kt_all - kt0) : k_tiles_per_split) : kt_all;   // last slice may be shorter
     issue_tile(0, 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     constexpr int NJ = GU ? 2 : 4;
     const int ncol0 = n0 + wc * WN_OUT;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 2 && MODE != 3) {
+    if (MODE != 2 && MODE != 3 && MODE != 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = ncol0 + j * 16 + l15;
@@ -185,7 +189,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     }
     constexpr int LPR = WN_OUT / 4, RPI = 64 / LPR;
     const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
-    float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc : nullptr;
+    // MODE 3: one fp32 slab per K-slice; MODE 4: two planes (gate, up) per K-slice, ldc = columns of the tail region
+    float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc
+                : (MODE == 4) ? (float*)p.C + (int64_t)blockIdx.y * 2 * M * p.ldc : nullptr;
+    constexpr int PASSES = (MODE == 4) ? 2 : 1;
+#pragma unroll
+    for (int pl = 0; pl < PASSES; ++pl) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -195,7 +204,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v;
-                    if (GU) {
+                    if (MODE == 4) {
+                        v = acc[2 * q + ii][j + 2 * pl][r];
+                    } else if (GU) {
                         v = silu_f(acc[2 * q + ii][j][r]) * acc[2 * q + ii][j + 2][r];
                     } else {
                         v = acc[2 * q + ii][j][r] + bv[j];
@@ -214,6 +225,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                 f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
                 if (MODE == 3) {
                     *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
+                } else if (MODE == 4) {
+                    *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
                 } else {
                     if (p.residual != nullptr) {
                         const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
@@ -230,6 +243,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+    }
+}
+
+// tail round of a gate/up GEMM: out[m][col0 + c] = bf16(silu(sum_s gate_s[m][c]) * sum_s up_s[m][c]); slab = [splits][2][M][tc] fp32
+__global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int splits, bf16_t* __restrict__ out, int64_t ldc, int M, int tc, int col0) {
+    const int n4 = tc >> 2;
+    const int64_t total = (int64_t)M * n4, plane = (int64_t)M * tc;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), c = (int)(i % n4) * 4;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float* b = slab + (int64_t)sidx * 2 * plane + (int64_t)m * tc + c;
+            const f32x4 a = *(const f32x4*)b, w = *(const f32x4*)(b + plane);
+            g[0] += a[0]; g[1] += a[1]; g[2] += a[2]; g[3] += a[3];
+            u[0] += w[0]; u[1] += w[1]; u[2] += w[2]; u[3] += w[3];
+        }
+        u32x2 o;
+        o[0] = pack2bf(silu_f(g[0]) * u[0], silu_f(g[1]) * u[1]);
+        o[1] = pack2bf(silu_f(g[2]) * u[2], silu_f(g[3]) * u[3]);
+        *(u32x2*)(out + (int64_t)m * ldc + col0 + c) = o;
     }
 }
 
@@ -258,10 +292,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
+// tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
 template <int MODE, int EPI>
-static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1) {
-    const int bn = (MODE == 2) ? 128 : 256;
+static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
+    const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
     const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, bn);
+    if (n_tiles < 0) n_tiles = tiles_m * tiles_n;
     const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
     static bool attr_set = false;
     if (!attr_set) {
@@ -269,7 +305,8 @@ static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1) {
         attr_set = true;
     }
     const int kt = cdiv(a.K, T256_BK);
-    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI>), dim3(tiles_m * tiles_n, splits), dim3(512), lds, s, a, tiles_m, kt / splits);
+    if (per <= 0) per = kt / splits;
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
     VILA_LAUNCH_CHECK();
     return 0;
 }
@@ -278,8 +315,36 @@ bool gemm256_supported(const GemmArgs& a) {
     return a.K % 8 == 0 && a.K >= 2 * T256_BK && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
+// Gate/up with an under-filled LAST round (S = 769: 592 tiles = 2 full rounds of 256 + 80): the full rounds run fused as usual, the
+// tail tiles are sliced over K so the last round costs 1/splits of a tile time; raw gate / up sums meet in a small reduce kernel.
+static int launch_gateup(const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, 128), kt = cdiv(a.K, T256_BK);
+    const int slots = 256;                                   // one 512-thread block per CU
+    const int full_tn = ((tiles_m * tiles_n) / slots) * slots / tiles_m;     // tile columns covered by whole rounds
+    const int tail_tn = tiles_n - full_tn, tail_tiles = tail_tn * tiles_m;
+    if (a.ws != nullptr && full_tn > 0 && tail_tiles > 0 && tail_tiles <= slots / 2 && kt >= 16) {
+        int splits = slots / tail_tiles;
+        if (splits > 4) splits = 4;
+        const int per = cdiv(kt, splits);
+        splits = cdiv(kt, per);
+        const int tc = tail_tn * 128 < a.N - full_tn * 128 ? tail_tn * 128 : a.N - full_tn * 128;      // output columns of the tail
+        if (splits >= 2 && (size_t)splits * 2 * a.M * tc * 4 <= a.ws_bytes && tc % 4 == 0) {
+            VILA_TRY((launch256_t<2, EPI_NONE>(a, s, 1, 0, full_tn * tiles_m)));
+            GemmArgs b = a;
+            b.C = a.ws; b.ldc = tc;
+            VILA_TRY((launch256_t<4, EPI_NONE>(b, s, splits, full_tn * tiles_m, tail_tiles, full_tn * 128, per)));
+            const int64_t total = (int64_t)a.M * (tc / 4);
+            const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            hipLaunchKernelGGL(splitk_gu_reduce_kernel, dim3(grid), dim3(256), 0, s, a.ws, splits, (bf16_t*)a.C, a.ldc, a.M, tc, full_tn * 128);
+            VILA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    return launch256_t<2, EPI_NONE>(a, s);
+}
+
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
-    if (a.epi == EPI_GATEUP) return launch256_t<2, EPI_NONE>(a, s);
+    if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
     if (a.out_f32) return launch256_t<1, EPI_NONE>(a, s);
     switch (a.epi) {
         case EPI_NONE: return launch256_t<0, EPI_NONE>(a, s);
