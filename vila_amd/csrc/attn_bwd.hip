@@ -210,10 +210,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16, CH = HD / 8;
     constexpr int KSTR = HDP + 8, QSTR = 40, QT = 32, KT = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* sQ = (bf16_t*)smem;                  // [32][KSTR]
-    bf16_t* sdO = sQ + QT * KSTR;                // [32][KSTR]
-    bf16_t* sQt = sdO + QT * KSTR;               // [DN*16][QSTR]
-    bf16_t* sdOt = sQt + DN * 16 * QSTR;         // [DN*16][QSTR]
+    // two stages of {Q [32][KSTR], dO [32][KSTR], Q^T [DN*16][QSTR], dO^T [DN*16][QSTR]} + the rows' lse / delta: the next query
+    // tile is written into the other stage while this one is consumed -> ONE barrier per tile, and no global load (lse, delta
+    // used to be fetched right where exp2 needs them: a full memory round trip per tile) sits on the critical path
+    constexpr int STAGE = 2 * QT * KSTR + 2 * DN * 16 * QSTR;       // bf16 elements
+    bf16_t* const stage0 = (bf16_t*)smem;
+    float* const s_ld = (float*)(stage0 + 2 * STAGE);                // [2 stages][lse*log2e | delta][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -224,14 +226,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int kb0 = blockIdx.x * KT;
     if (kb0 >= seqlen) return;
 
-    if constexpr (HDP > HD) {
-        for (int i = tid; i < 2 * QT * (HDP - HD); i += 256) {
-            const int row = i / (HDP - HD), c = i % (HDP - HD);
-            sQ[row * KSTR + HD + c] = 0;           // sQ and sdO are contiguous
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        bf16_t* sQ = stage0 + b * STAGE;
+        bf16_t* sQt = sQ + 2 * QT * KSTR;
+        bf16_t* sdOt = sQt + DN * 16 * QSTR;
+        if constexpr (HDP > HD) {
+            for (int i = tid; i < 2 * QT * (HDP - HD); i += 256) {
+                const int row = i / (HDP - HD), c = i % (HDP - HD);
+                sQ[row * KSTR + HD + c] = 0;           // sQ and sdO are contiguous
+            }
         }
-    }
-    if constexpr (DN * 16 > HD) {
-        for (int i = tid; i < (DN * 16 - HD) * QSTR; i += 256) { sQt[HD * QSTR + i] = 0; sdOt[HD * QSTR + i] = 0; }
+        if constexpr (DN * 16 > HD) {
+            for (int i = tid; i < (DN * 16 - HD) * QSTR; i += 256) { sQt[HD * QSTR + i] = 0; sdOt[HD * QSTR + i] = 0; }
+        }
     }
 
     // this wave's 16 keys as B operands (held in registers for the whole block)
@@ -263,11 +271,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     // staging: threads 0..127 -> Q, 128..255 -> dO ; work item = (q group of 4 rows, 16-B d chunk)
     const int op_sel = tid >> 7, wi = tid & 127;
     const int s_qg = wi & 7, s_dc = wi >> 3;
-    u32x4 rs[4];
-    auto gload = [&](int it) {
+    // two register sets: the tile a set holds was requested TWO iterations before it is written to LDS (one iteration of
+    // compute does not cover a memory round trip: with a single set every tile waited ~3 us for its loads)
+    struct TileRegs { u32x4 rs[4]; float ldv; };
+    TileRegs setA, setB;
+    setA.ldv = 0.f; setB.ldv = 0.f;
+    auto gload = [&](int it, TileRegs& T) {
+        u32x4 (&rs)[4] = T.rs;
+        float& ldv = T.ldv;
         const int g = it / ntq, qt = it % ntq;
         const int hq = kvh * G + g;
         const int q0 = q_begin + qt * QT;
+        if (tid < 64) {                                 // lanes 0..31: lse * log2(e), lanes 32..63: delta, of the tile's 32 rows
+            const int q = q0 + (tid & 31);
+            ldv = 0.f;
+            if (q < seqlen) {
+                const int64_t idx = (int64_t)hq * p.total_tokens + tok0 + q;
+                ldv = (tid < 32) ? p.lse[idx] * LOG2E : p.delta[idx];
+            }
+        }
         const bf16_t* base = op_sel ? (p.d_o + (int64_t)tok0 * p.do_tok_stride + hq * p.do_head_stride)
                                     : (p.q + (int64_t)tok0 * p.q_tok_stride + hq * p.q_head_stride);
         const int64_t ts = op_sel ? p.do_tok_stride : p.q_tok_stride;
@@ -278,7 +300,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
             if (s_dc < CH && q < seqlen) rs[i] = *(const u32x4*)(base + (int64_t)q * ts + s_dc * 8);
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int b, const TileRegs& T) {
+        const u32x4 (&rs)[4] = T.rs;
+        const float ldv = T.ldv;
+        bf16_t* sQ = stage0 + b * STAGE;
+        bf16_t* sdO = sQ + QT * KSTR;
+        bf16_t* sQt = sdO + QT * KSTR;
+        bf16_t* sdOt = sQt + DN * 16 * QSTR;
+        if (tid < 64) s_ld[b * 64 + tid] = ldv;
         if (s_dc >= CH) return;
         bf16_t* rm = (op_sel ? sdO : sQ) + (s_qg * 4) * KSTR + s_dc * 8;
 #pragma unroll
@@ -294,15 +323,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
         }
     };
 
-    gload(0);
+    gload(0, setA);
+    __syncthreads();                                    // padding zeros written
+    lstore(0, setA);
+    if (total_iters > 1) gload(1, setA);
+    if (total_iters > 2) gload(2, setB);
     __syncthreads();
-    lstore();
-    __syncthreads();
-    for (int it = 0; it < total_iters; ++it) {
-        if (it + 1 < total_iters) gload(it + 1);
-        const int g = it / ntq, qt = it % ntq;
-        const int hq = kvh * G + g;
+    auto tile_step = [&](int it, TileRegs& T) {
+        const int qt = it % ntq;
         const int q0 = q_begin + qt * QT;
+        const int b = it & 1;
+        const bf16_t* sQ = stage0 + b * STAGE;
+        const bf16_t* sdO = sQ + QT * KSTR;
+        const bf16_t* sQt = sdO + QT * KSTR;
+        const bf16_t* sdOt = sQt + DN * 16 * QSTR;
+        const float* lse2 = s_ld + b * 64;
+        const float* dlt = lse2 + 32;
         // S = Q K^T, dP = dO V^T  : C layout col = key (l15), rows = q (lg*4 + r) per 16-row q fragment
         f32x4 sacc[2], pacc[2];
 #pragma unroll
@@ -324,11 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + f * 16 + lg * 4 + r;
                 const bool ok = kok && (q < seqlen) && (!CAUSAL || key <= q);
-                float l2 = 0.f, dl = 0.f;
-                if (q < seqlen) {
-                    l2 = p.lse[(int64_t)hq * p.total_tokens + tok0 + q] * LOG2E;
-                    dl = p.delta[(int64_t)hq * p.total_tokens + tok0 + q];
-                }
+                const float l2 = lse2[f * 16 + lg * 4 + r], dl = dlt[f * 16 + lg * 4 + r];
                 pr[r] = ok ? __builtin_amdgcn_exp2f(sacc[f][r] * c - l2) : 0.f;
                 ds[r] = pr[r] * (pacc[f][r] - dl) * p.scale;
             }
@@ -348,9 +380,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
             const u32x4 wb = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
             dk[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb), dsfrag, dk[dn], 0, 0, 0);
         }
-        __syncthreads();
-        if (it + 1 < total_iters) lstore();
-        __syncthreads();
+        if (it + 1 < total_iters) lstore(b ^ 1, T);      // tile it+1 (requested two iterations ago) -> the other stage
+        if (it + 3 < total_iters) gload(it + 3, T);
+        __syncthreads();                                // stage b^1 complete for the next iteration; everyone is done reading stage b
+    };
+    for (int it = 0; it < total_iters; it += 2) {
+        tile_step(it, setA);                            // even tiles hand over set A (tile it+1), odd tiles set B (tile it+2)
+        if (it + 1 < total_iters) tile_step(it + 1, setB);
     }
     if (kok) {
         bf16_t* kp = p.dk + (int64_t)(tok0 + key) * p.dk_tok_stride + kvh * p.dk_head_stride;
@@ -372,7 +408,7 @@ template <int HD, bool CAUSAL>
 static int launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
     const size_t lds_dq = (size_t)(2 * 64 * (HDP + 8) + DN * 16 * 72) * 2;
-    const size_t lds_kv = (size_t)(2 * 32 * (HDP + 8) + 2 * DN * 16 * 40) * 2;
+    const size_t lds_kv = (size_t)2 * (2 * 32 * (HDP + 8) + 2 * DN * 16 * 40) * 2 + 2 * 64 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
