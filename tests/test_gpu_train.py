@@ -60,6 +60,8 @@ def _attn_ref_grads(q, k, v, do, causal, cu):
 @pytest.mark.parametrize("bounds,Hq,Hkv,D,causal", [
     ([0, 1024], 16, 16, 72, False), ([0, 196, 392], 2, 2, 72, False), ([0, 50], 2, 2, 72, False),
     ([0, 769], 28, 4, 128, True), ([0, 100, 357, 400, 401], 4, 2, 128, True), ([0, 130], 4, 4, 64, True), ([0, 97], 2, 1, 128, False),
+    # grids above one block per CU take the 4-wave dK/dV kernel (the cases above the 8-wave two-group one)
+    ([0, 1024, 2048], 16, 16, 72, False), ([0, 1300, 2600], 8, 8, 128, True),
 ])
 def test_attention_backward(ops, bounds, Hq, Hkv, D, causal):
     T = bounds[-1]

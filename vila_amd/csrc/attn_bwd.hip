@@ -205,8 +205,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 // ------------------------------------------------------------------------------------------------
 // dK, dV
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+// 8 waves = 2 groups x 4: both groups hold the SAME 64 keys (wave w and w+4 the same 16) and split the (query head, query tile)
+// sequence by parity, each with its own LDS stages; their dK / dV partial sums meet in LDS at the end.  Two waves per SIMD hide
+// the LDS-read latency that one wave per SIMD exposed (the grid is only 208 blocks at 4 x 769 tokens: one block per CU), and the
+// longest (causal, first key tile) block walks half as many tiles.  NG = 2 is used when the grid is at most one block per CU
+// (LLM: 521 -> 362 us per layer); large grids (ViT: 1024 blocks) keep NG = 1 with two 4-wave blocks per CU (181 us vs 229).
+template <int HD, bool CAUSAL, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16, CH = HD / 8;
     constexpr int KSTR = HDP + 8, QSTR = 40, QT = 32, KT = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,20 +219,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     // tile is written into the other stage while this one is consumed -> ONE barrier per tile, and no global load (lse, delta
     // used to be fetched right where exp2 needs them: a full memory round trip per tile) sits on the critical path
     constexpr int STAGE = 2 * QT * KSTR + 2 * DN * 16 * QSTR;       // bf16 elements
-    bf16_t* const stage0 = (bf16_t*)smem;
-    float* const s_ld = (float*)(stage0 + 2 * STAGE);                // [2 stages][lse*log2e | delta][32]
+    const int grp = (NG == 2) ? (threadIdx.x >> 8) : 0;             // group 0 / 1
+    bf16_t* const stage0 = (bf16_t*)smem + grp * 2 * STAGE;         // this group's two stages
+    float* const s_ld = (float*)((bf16_t*)smem + 2 * NG * STAGE) + grp * 128;   // [2 stages][lse*log2e | delta][32] per group
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // tid / wave: within the group
     const int l15 = lane & 15, lg = lane >> 4;
     const int kvh = blockIdx.y, seq = blockIdx.z;
     const int G = p.n_q_heads / p.n_kv_heads;
     int tok0 = seq * p.max_seqlen, seqlen = p.max_seqlen;
     if (p.cu_seqlens != nullptr) { tok0 = p.cu_seqlens[seq]; seqlen = p.cu_seqlens[seq + 1] - tok0; }
     const int kb0 = blockIdx.x * KT;
-    if (kb0 >= seqlen) return;
+    if (kb0 >= seqlen) return;                                       // block-uniform
 
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b) {                                    // each group pads its own stages
         bf16_t* sQ = stage0 + b * STAGE;
         bf16_t* sQt = sQ + 2 * QT * KSTR;
         bf16_t* sdOt = sQt + DN * 16 * QSTR;
@@ -266,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
 
     const int q_begin = CAUSAL ? (kb0 / QT) * QT : 0;
     const int ntq = (seqlen - q_begin + QT - 1) / QT;
-    const int total_iters = G * ntq;
+    const int total_iters = G * ntq;                                 // (head, query tile) pairs; this group takes it = NG j + grp
+    const int n_steps = (total_iters + NG - 1) / NG;                 // steps of group 0 (>= group 1's): both groups cross every barrier
 
     // staging: threads 0..127 -> Q, 128..255 -> dO ; work item = (q group of 4 rows, 16-B d chunk)
     const int op_sel = tid >> 7, wi = tid & 127;
@@ -323,16 +330,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
         }
     };
 
-    gload(0, setA);
+    if (grp < total_iters) gload(grp, setA);
     __syncthreads();                                    // padding zeros written
-    lstore(0, setA);
-    if (total_iters > 1) gload(1, setA);
-    if (total_iters > 2) gload(2, setB);
+    if (grp < total_iters) lstore(0, setA);
+    if (grp + NG < total_iters) gload(grp + NG, setA);
+    if (grp + 2 * NG < total_iters) gload(grp + 2 * NG, setB);
     __syncthreads();
-    auto tile_step = [&](int it, TileRegs& T) {
+    auto tile_step = [&](int j, TileRegs& T) {
+        const int it = NG * j + grp;
+        if (it >= total_iters) { __syncthreads(); return; }          // group-uniform: keep the barrier count equal
         const int qt = it % ntq;
         const int q0 = q_begin + qt * QT;
-        const int b = it & 1;
+        const int b = j & 1;
         const bf16_t* sQ = stage0 + b * STAGE;
         const bf16_t* sdO = sQ + QT * KSTR;
         const bf16_t* sQt = sdO + QT * KSTR;
@@ -380,13 +389,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
             const u32x4 wb = (u32x4){lo2[0], lo2[1], hi2[0], hi2[1]};
             dk[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb), dsfrag, dk[dn], 0, 0, 0);
         }
-        if (it + 1 < total_iters) lstore(b ^ 1, T);      // tile it+1 (requested two iterations ago) -> the other stage
-        if (it + 3 < total_iters) gload(it + 3, T);
-        __syncthreads();                                // stage b^1 complete for the next iteration; everyone is done reading stage b
+        if (it + NG < total_iters) lstore(b ^ 1, T);     // this group's next tile (requested two steps ago) -> the other stage
+        if (it + 3 * NG < total_iters) gload(it + 3 * NG, T);
+        __syncthreads();                                // stage b^1 complete for the next step; everyone is done reading stage b
     };
-    for (int it = 0; it < total_iters; it += 2) {
-        tile_step(it, setA);                            // even tiles hand over set A (tile it+1), odd tiles set B (tile it+2)
-        if (it + 1 < total_iters) tile_step(it + 1, setB);
+    for (int j = 0; j < n_steps; j += 2) {
+        tile_step(j, setA);                             // even steps hand over set A, odd steps set B
+        if (j + 1 < n_steps) tile_step(j + 1, setB);
+    }
+    // ---- the two groups' partial dK / dV meet in LDS (the stages are free now): group 1 writes, group 0 adds and stores ----
+    if constexpr (NG == 2) {
+        float* red = (float*)smem + (size_t)wave * DN * 64 * 8;      // per key-wave: [DN][64 lanes][8 floats]
+        if (grp == 1) {
+#pragma unroll
+            for (int dn = 0; dn < DN; ++dn) {
+                *(f32x4*)(red + (dn * 64 + lane) * 8) = dk[dn];
+                *(f32x4*)(red + (dn * 64 + lane) * 8 + 4) = dv[dn];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int dn = 0; dn < DN; ++dn) {
+            const f32x4 a = *(const f32x4*)(red + (dn * 64 + lane) * 8), b2 = *(const f32x4*)(red + (dn * 64 + lane) * 8 + 4);
+            dk[dn][0] += a[0]; dk[dn][1] += a[1]; dk[dn][2] += a[2]; dk[dn][3] += a[3];
+            dv[dn][0] += b2[0]; dv[dn][1] += b2[1]; dv[dn][2] += b2[2]; dv[dn][3] += b2[3];
+        }
     }
     if (kok) {
         bf16_t* kp = p.dk + (int64_t)(tok0 + key) * p.dk_tok_stride + kvh * p.dk_head_stride;
@@ -408,18 +436,22 @@ template <int HD, bool CAUSAL>
 static int launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
     const size_t lds_dq = (size_t)(2 * 64 * (HDP + 8) + DN * 16 * 72) * 2;
-    const size_t lds_kv = (size_t)2 * (2 * 32 * (HDP + 8) + 2 * DN * 16 * 40) * 2 + 2 * 64 * sizeof(float);
+    const size_t lds_stage = (size_t)(2 * 32 * (HDP + 8) + 2 * DN * 16 * 40) * 2;
+    const size_t lds_kv1 = 2 * lds_stage + 2 * 64 * sizeof(float), lds_kv2 = 4 * lds_stage + 4 * 64 * sizeof(float);   // groups x 2 stages
     static bool attr_set = false;
     if (!attr_set) {
         VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
-        VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+        VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, CAUSAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv1));
+        VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, CAUSAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv2));
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.total_tokens * a.n_q_heads, 16)), dim3(256), 0, s, a);
     VILA_LAUNCH_CHECK();
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL>), dim3(cdiv(a.max_seqlen, 64), a.n_q_heads, a.n_seq), dim3(256), lds_dq, s, a);
     VILA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL>), dim3(cdiv(a.max_seqlen, 64), a.n_kv_heads, a.n_seq), dim3(256), lds_kv, s, a);
+    const dim3 grid_kv(cdiv(a.max_seqlen, 64), a.n_kv_heads, a.n_seq);
+    if ((int64_t)grid_kv.x * grid_kv.y * grid_kv.z <= 320) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 2>), grid_kv, dim3(512), lds_kv2, s, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 1>), grid_kv, dim3(256), lds_kv1, s, a);
     VILA_LAUNCH_CHECK();
     return 0;
 }
