@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
         }
     };
+    float e_bias = 0.f, e_res = 0.f;
     auto finish = [&](int gg, float (&acc)[R]) {
         const int n = gg * 2;
         if constexpr (MODE == 1) {
@@ -134,12 +135,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             if (lane < 2 && n + lane < p.N) {
                 const int nn = n + lane;
                 float v = lane == 0 ? acc[0] : acc[1];
-                if (p.bias != nullptr) v += bf2f(p.bias[nn]);
+                v += e_bias;
                 if (p.y_f32 != nullptr) p.y_f32[nn] = v;
                 if (p.y != nullptr) {
-                    if (p.residual != nullptr) v = bfround(v) + bf2f(p.residual[nn]);
+                    if (p.residual != nullptr) v = bfround(v) + e_res;
                     p.y[nn] = f2bf(v);
                 }
+            }
+        }
+    };
+    // the epilogue's operands are requested BEFORE the dot product: fetched after the reduction they add a dependent memory round
+    // trip (~1 us) to the tail of every wave, i.e. to the kernel
+    auto epi_fetch = [&](int gg) {
+        if constexpr (MODE != 1) {
+            const int nn = gg * 2 + lane;
+            e_bias = 0.f; e_res = 0.f;
+            if (lane < 2 && nn < p.N) {
+                if (p.bias != nullptr) e_bias = bf2f(p.bias[nn]);
+                if (p.residual != nullptr && p.y != nullptr) e_res = bf2f(p.residual[nn]);
             }
         }
     };
@@ -151,6 +164,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     // stream); for K = 18944 the x staging is long and queuing the weight loads in front of it measured 13 % slower
     const bool early = has && (p.K <= 4096);
     if (early) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
+    if (has) epi_fetch(g);
     if constexpr (MODE == 2) {
         const int n_active = (*p.pos_ptr + DEC_KS) / DEC_KS;     // ceil((pos+1)/KS)
         stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
@@ -168,6 +182,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     }
     for (; g < n_groups; g += stride) {
         rows_of(g, rows);
+        epi_fetch(g);
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -236,16 +251,27 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         rows[0] = p.Wqkv + (int64_t)rows_i[0] * p.K;
         rows[1] = p.Wqkv + (int64_t)rows_i[1] * p.K;
     };
-    auto finish = [&](int gg, float (&acc)[2]) {
+    // epilogue operands (position, the pair's biases, its RoPE row) are requested before the dot product, not after the reduction
+    int e_pos = 0;
+    float e_b0 = 0.f, e_b1 = 0.f, e_c = 1.f, e_s = 0.f;
+    auto epi_fetch = [&](int gg) {
         if (lane >= 2) return;
         const int head = gg / gph, gi = gg % gph;
+        e_pos = *p.pos_ptr;
+        e_b0 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[0]]) : 0.f;
+        e_b1 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[1]]) : 0.f;
+        if (head < p.nq + p.nkv) { e_c = p.rope_cs[gi]; e_s = p.rope_cs[half + gi]; }
+    };
+    auto finish = [&](int gg, float (&acc)[2]) {
+        if (lane >= 2) return;
+        const int head = gg / gph;
         const bool is_v = head >= p.nq + p.nkv;
-        const int pos = *p.pos_ptr;
-        const float lo = bfround(acc[0] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[0]]) : 0.f));
-        const float hi = bfround(acc[1] + (p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[1]]) : 0.f));
+        const int pos = e_pos;
+        const float lo = bfround(acc[0] + e_b0);
+        const float hi = bfround(acc[1] + e_b1);
         float out = lane ? hi : lo;
         if (!is_v) {
-            const float c = p.rope_cs[gi], sn = p.rope_cs[half + gi];
+            const float c = e_c, sn = e_s;
             out = lane ? bfround(bfround(hi * c) + bfround(lo * sn)) : bfround(bfround(lo * c) + bfround(-hi * sn));
         }
         const int row = rows_i[lane];
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
 
     Batch<2, U> b0;
     const bool has = g < n_groups;
-    if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); }
+    if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); epi_fetch(g); }
     stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
         float acc[2] = {0.f, 0.f};
@@ -271,6 +297,7 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     }
     for (; g < n_groups; g += stride) {
         rows_of(g);
+        epi_fetch(g);
         float acc[2] = {0.f, 0.f};
         wave_rows_dot<2, U>(rows, sx, p.K, lane, acc, 0);
         finish(g, acc);
