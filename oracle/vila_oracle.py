@@ -171,8 +171,10 @@ def basic_image_encoder(images: Sequence[torch.Tensor], w, cfg) -> List[torch.Te
 # ----------------------------------------------------------------------------------------------
 def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, cfg,
                  labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
-                 padding_side: str = "right"):
-    """Returns (inputs_embeds [B,S,H], labels [B,S] i64, attention_mask [B,S] bool)."""
+                 padding_side: str = "right", max_length: Optional[int] = None):
+    """Returns (inputs_embeds [B,S,H], labels [B,S] i64, attention_mask [B,S] bool).
+    max_length = `tokenizer.model_max_length` in training mode: `__truncate_sequence` (llava_arch.py:519-526) cuts every sample
+    AFTER media expansion, only if some sample is longer."""
     labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
     attention_mask = attention_mask if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
     text = embed_tokens(input_ids, w)
@@ -196,6 +198,9 @@ def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, c
         labs.append(torch.cat(pl, 0))
     if queue:
         raise ValueError("Not all image embeddings are consumed!")   # :481-484
+    if max_length is not None and any(x.shape[0] > max_length for x in ins):      # :519-526
+        ins = [x[:max_length] for x in ins]
+        labs = [x[:max_length] for x in labs]
     S = max(x.shape[0] for x in ins)
     H = ins[0].shape[1]
     out_e = torch.zeros((B, S, H), dtype=ins[0].dtype)

@@ -46,6 +46,37 @@ def test_splice_plan_matches_oracle(side):
     assert plan.seqlens.tolist() == [9 - 1 + 5, 7 - 2 + 5 + 3, 4]
 
 
+@pytest.mark.parametrize("side", ["right", "left"])
+@pytest.mark.parametrize("max_len", [6, 9, 11, 40])
+def test_splice_plan_truncation_matches_oracle(side, max_len):
+    """`__truncate_sequence` (llava_arch.py:519-526): cut AFTER media expansion, through the middle of an image if need be,
+    and only when some sample exceeds model_max_length."""
+    cfg = configs.tiny()
+    g = torch.Generator().manual_seed(4)
+    H, V = 8, cfg.llm.vocab_size
+    table = torch.randn(V, H, generator=g)
+    w = {"llm.model.embed_tokens.weight": table}
+    img = cfg.image_token_id
+    ids = torch.randint(0, 900, (3, 7), generator=g)
+    mask = torch.ones(3, 7, dtype=torch.bool)
+    ids[0, 1] = img
+    ids[1, 0] = img; ids[1, 4] = img
+    mask[2, 3:] = False
+    labels = torch.randint(0, 900, (3, 7), generator=g)
+    media = [torch.randn(5, H, generator=g), torch.randn(4, H, generator=g), torch.randn(6, H, generator=g)]
+    e_ref, l_ref, m_ref = O.embed_splice(ids, [m.clone() for m in media], w, cfg, labels=labels, attention_mask=mask, padding_side=side,
+                                         max_length=max_len)
+    plan = host.splice_plan(ids, mask, labels, [m.shape[0] for m in media], img, side, max_length=max_len)
+    flat = torch.cat(media, 0)
+    e = torch.zeros(plan.B * plan.S, H)
+    e[plan.txt_dst.long()] = table[plan.txt_src.long()]
+    e[plan.img_dst.long()] = flat[plan.img_src.long()]
+    assert plan.truncated == (max_len < 15)                  # longest expanded sample: 7 - 2 + 4 + 6 = 15
+    assert torch.equal(e.view(plan.B, plan.S, H), e_ref)
+    assert torch.equal(plan.labels, l_ref)
+    assert torch.equal(plan.mask, m_ref)
+
+
 def test_splice_plan_errors_match_reference():
     cfg = configs.tiny()
     ids = torch.tensor([[1, cfg.image_token_id, 2]])

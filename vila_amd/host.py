@@ -16,9 +16,11 @@ from .configs import IGNORE_INDEX
 
 
 def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], labels: Optional[torch.Tensor],
-                media_lens: List[int], image_token_id: int, padding_side: str = "right") -> SimpleNamespace:
+                media_lens: List[int], image_token_id: int, padding_side: str = "right", max_length: Optional[int] = None) -> SimpleNamespace:
     """Row maps for `out[B*S, H]`: text rows come from the embedding table (`txt_src` = token ids -> `txt_dst`), media rows
-    from the concatenated media embeddings (row i -> `img_dst[i]`).  Vectorised: no per-token `.item()`."""
+    from the concatenated media embeddings (row `img_src[i]` -> `img_dst[i]`).  Vectorised: no per-token `.item()`.
+    max_length: training-time `__truncate_sequence` (llava_arch.py:519-526) — every sample is cut to `model_max_length` AFTER media
+    expansion (rows beyond it, text or media, are dropped from the maps)."""
     ids = input_ids
     B, L = ids.shape
     mask = attention_mask.bool() if attention_mask is not None else torch.ones_like(ids, dtype=torch.bool)
@@ -37,11 +39,16 @@ def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
     ends = torch.cumsum(lens, 1)
     starts = ends - lens
     S_k = ends[:, -1]
+    cut = max_length if (max_length is not None and B > 0 and int(S_k.max()) > max_length) else None
+    if cut is not None:
+        S_k = S_k.clamp(max=cut)
     S = int(S_k.max()) if B > 0 else 0
     right = padding_side == "right"
     base = torch.arange(B, device=ids.device)[:, None] * S + (0 if right else (S - S_k)[:, None])
     dst = base + starts
     is_txt = mask & ~is_img
+    if cut is not None:
+        is_txt = is_txt & (starts < cut)                                              # a text token occupies one position
     txt_src = ids[is_txt].to(torch.int32)
     txt_dst = dst[is_txt].to(torch.int32)
     out_labels = torch.full((B * S,), IGNORE_INDEX, dtype=labels.dtype, device=ids.device)
@@ -51,10 +58,15 @@ def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
     if n_img:
         offs = torch.cat([torch.arange(n, device=ids.device) for n in media_lens])
         img_dst = (torch.repeat_interleave(dst[is_img], lens_img) + offs).to(torch.int32)
+        img_src = torch.arange(int(lens_img.sum()), dtype=torch.int32, device=ids.device)
+        if cut is not None:                                                            # media rows beyond the cut are dropped
+            keep = (torch.repeat_interleave(starts[is_img], lens_img) + offs) < cut
+            img_dst, img_src = img_dst[keep], img_src[keep]
     else:
         img_dst = torch.zeros(0, dtype=torch.int32, device=ids.device)
-    return SimpleNamespace(B=B, S=S, seqlens=S_k, txt_src=txt_src, txt_dst=txt_dst, img_dst=img_dst,
-                           labels=out_labels.view(B, S), mask=out_mask)
+        img_src = torch.zeros(0, dtype=torch.int32, device=ids.device)
+    return SimpleNamespace(B=B, S=S, seqlens=S_k, txt_src=txt_src, txt_dst=txt_dst, img_dst=img_dst, img_src=img_src,
+                           truncated=cut is not None, labels=out_labels.view(B, S), mask=out_mask)
 
 
 def repack(attention_mask: torch.Tensor, labels: torch.Tensor) -> SimpleNamespace:

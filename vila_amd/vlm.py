@@ -127,7 +127,7 @@ class HipLlavaLlamaModel(nn.Module):
 
     # llava_arch.py:412-490 + 528-555
     def _embed(self, input_ids: torch.Tensor, media: Dict[str, List[torch.Tensor]], media_config: Optional[Dict[str, Dict[str, Any]]] = None,
-               labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None):
+               labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None, max_length: Optional[int] = None):
         dev = self.device
         media_config = media_config or {}
         labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
@@ -142,14 +142,15 @@ class HipLlavaLlamaModel(nn.Module):
 
         # ---- integer work on the ids (wherever they live); no per-token sync: vila_amd.host.splice_plan ----
         plan = splice_plan(input_ids, attention_mask, labels, [int(m.shape[0]) for m in media_embeds], img_id,
-                           getattr(self.tokenizer, "padding_side", "right"))
+                           getattr(self.tokenizer, "padding_side", "right"),
+                           max_length=max_length)                                      # __truncate_sequence, llava_arch.py:519-526
         S = plan.S
         out = torch.zeros((B * S, H), device=dev, dtype=self.dtype)
         table = self.llm.model.embed_tokens.weight
         ops.copy_rows(table, out, plan.txt_src.to(dev), plan.txt_dst.to(dev), int(plan.txt_src.numel()))
         if n_img:
             flat = torch.cat(media_embeds, 0).to(self.dtype)
-            ops.copy_rows(flat, out, None, plan.img_dst.to(dev), int(plan.img_dst.numel()))
+            ops.copy_rows(flat, out, plan.img_src.to(dev) if plan.truncated else None, plan.img_dst.to(dev), int(plan.img_dst.numel()))
         return out.view(B, S, H), plan.labels.to(dev), plan.mask.to(dev)
 
     # llava_llama.py:94-159 (inference/eval form: loss without autograd; SFT fwd+bwd lives in vila_amd.train)
@@ -157,7 +158,9 @@ class HipLlavaLlamaModel(nn.Module):
     def forward(self, input_ids=None, media=None, media_config=None, attention_mask=None, labels=None, packing: bool = True,
                 inputs_embeds=None, num_items_in_batch=None, **kw):
         if inputs_embeds is None:
-            inputs_embeds, labels, attention_mask = self._embed(input_ids, media, media_config, labels, attention_mask)
+            # the reference truncates to tokenizer.model_max_length only in training mode (llava_arch.py:522)
+            cut = getattr(self.tokenizer, "model_max_length", None) if (self.training and labels is not None) else None
+            inputs_embeds, labels, attention_mask = self._embed(input_ids, media, media_config, labels, attention_mask, max_length=cut)
         return self.llm(inputs_embeds=inputs_embeds, attention_mask=attention_mask, labels=labels, num_items_in_batch=num_items_in_batch)
 
     # llava_arch.py:823-833
