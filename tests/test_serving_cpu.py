@@ -1,0 +1,102 @@
+"""Serving shim (vila_amd/serving.py) on CPU with a stub model: prompt assembly, image pre-processing, endpoint schema."""
+import base64
+import io
+import json
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from vila_amd import configs, serving
+
+
+class _Tok:
+    """Whitespace tokenizer over a growing vocabulary (stands in for the checkpoint's tokenizer)."""
+    eos_token_id = 1
+
+    def __init__(self):
+        self.vocab = {"<eos>": 1}
+        self.inv = {1: "<eos>"}
+
+    def __call__(self, text, add_special_tokens=False):
+        ids = []
+        for w in text.split():
+            if w not in self.vocab:
+                self.vocab[w] = len(self.vocab) + 2
+                self.inv[self.vocab[w]] = w
+            ids.append(self.vocab[w])
+        return SimpleNamespace(input_ids=ids)
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(self.inv[i] for i in ids if not (skip_special_tokens and i == 1))
+
+
+class _Model:
+    """Records what the shim hands to `generate` and answers with fixed ids."""
+    def __init__(self, tok):
+        self.cfg = configs.tiny()
+        self.device = torch.device("cpu")
+        self.tok = tok
+        self.calls = []
+
+    def generate(self, input_ids, media, max_new_tokens, eos_token_id):
+        self.calls.append((input_ids, media, max_new_tokens, eos_token_id))
+        reply = self.tok("a red square").input_ids + [1, 99]       # EOS then a token that must be dropped
+        return torch.tensor([reply])
+
+
+def _png_data_url(arr):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="PNG")
+    return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+
+
+def test_preprocess_image_matches_siglip_processor_semantics():
+    arr = (np.arange(100 * 80 * 3) % 256).astype(np.uint8).reshape(100, 80, 3)
+    x = serving.preprocess_image(arr, 56)
+    assert x.shape == (3, 56, 56) and x.dtype == torch.float32
+    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
+    same = serving.preprocess_image(np.full((56, 56, 3), 255, np.uint8), 56)      # no resize: exact (1 - 0.5) / 0.5
+    assert torch.equal(same, torch.ones(3, 56, 56))
+
+
+def test_generate_content_builds_ids_media_and_decodes():
+    tok = _Tok()
+    m = _Model(tok)
+    img = np.zeros((70, 70, 3), np.uint8)
+    out = serving.generate_content(m, tok, [img, "what is this ?"], max_new_tokens=7)
+    assert out == "a red square"
+    ids, media, n, eos = m.calls[0]
+    assert n == 7 and eos == 1
+    assert int((ids == m.cfg.image_token_id).sum()) == 1 and len(media["image"]) == 1
+    assert media["image"][0].shape == (3, m.cfg.vision.image_size, m.cfg.vision.image_size) and media["image"][0].dtype == torch.bfloat16
+    # the <image> id sits where the part was, inside the user turn
+    text_ids = tok("<|im_start|>user").input_ids
+    pos = int((ids[0] == m.cfg.image_token_id).nonzero()[0])
+    assert ids[0, :pos].tolist()[-len(text_ids):] == text_ids
+
+
+def test_chat_completions_endpoint_schema_and_errors():
+    fastapi = pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    tok = _Tok()
+    m = _Model(tok)
+    client = TestClient(serving.create_app(m, tok, model_name="NVILA-8B"))
+    url = _png_data_url(np.full((20, 30, 3), 128, np.uint8))
+    body = {"model": "NVILA-8B", "max_tokens": 16,
+            "messages": [{"role": "user", "content": [{"type": "text", "text": "describe"}, {"type": "image_url", "image_url": {"url": url}}]}]}
+    r = client.post("/chat/completions", json=body)
+    assert r.status_code == 200
+    j = r.json()
+    assert j["object"] == "chat.completion" and j["choices"][0]["message"]["content"][0] == {"type": "text", "text": "a red square"}
+    assert len(m.calls[-1][1]["image"]) == 1
+    r = client.post("/chat/completions", json=dict(body, stream=True))
+    events = [l for l in r.text.split("\n\n") if l]
+    assert events[-1] == "data: [DONE]" and json.loads(events[0][6:])["object"] == "chat.completion.chunk"
+    assert "".join(json.loads(e[6:])["choices"][0]["delta"]["content"] for e in events[:-1]).strip() == "a red square"
+    r = client.post("/chat/completions", json=dict(body, model="other"))
+    assert r.status_code == 500 and "configured to use the model" in r.json()["error"]
+    r = client.post("/chat/completions", json=dict(body, temperature=0.7))
+    assert r.status_code == 500 and "greedy" in r.json()["error"]
