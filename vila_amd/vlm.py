@@ -130,18 +130,22 @@ class HipLlavaLlamaModel(nn.Module):
                labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None, max_length: Optional[int] = None):
         dev = self.device
         media_config = media_config or {}
-        labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
-        attention_mask = attention_mask if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
-        attention_mask = attention_mask.bool()
+        # The integer work of the splice runs on the HOST while the tower runs on the GPU: ids / mask / labels are brought over
+        # first (the GPU is idle, the copy costs one short sync), then the encoders are enqueued, then the plan is computed on the
+        # CPU under them and only its small index tensors go back.  (Planning on device tensors forced 3-4 stream syncs — boolean
+        # indexing, .sum() — each waiting for the whole tower.)
+        ids_h = input_ids.cpu()
+        labels_h = labels.cpu() if labels is not None else torch.full_like(ids_h, IGNORE_INDEX)
+        mask_h = attention_mask.cpu().bool() if attention_mask is not None else torch.ones_like(ids_h, dtype=torch.bool)
         images = list(media.get("image", [])) if media else []
         media_embeds = self.encoders["image"](images, media_config.get("image", {})) if images else []
         n_img = len(media_embeds)
         img_id = self.tokenizer.media_token_ids["image"]
-        B, L = input_ids.shape
+        B, L = ids_h.shape
         H = self.cfg.llm.hidden_size
 
-        # ---- integer work on the ids (wherever they live); no per-token sync: vila_amd.host.splice_plan ----
-        plan = splice_plan(input_ids, attention_mask, labels, [int(m.shape[0]) for m in media_embeds], img_id,
+        # ---- integer work on the ids; no per-token sync: vila_amd.host.splice_plan ----
+        plan = splice_plan(ids_h, mask_h, labels_h, [int(m.shape[0]) for m in media_embeds], img_id,
                            getattr(self.tokenizer, "padding_side", "right"),
                            max_length=max_length)                                      # __truncate_sequence, llava_arch.py:519-526
         S = plan.S
