@@ -54,7 +54,10 @@ def test_full_size_decode_matches_prefill_and_graph_matches_eager(full):
         dec_rows, pre_rows = a[0, 0, :, S0:S0 + n - 1], b[0, 0, :, S0:S0 + n - 1]
         assert float(pre_rows.float().abs().max()) > 0
         assert rel_l2(dec_rows, pre_rows) < 1e-2, f"layer-0 {name} rows appended by decode vs prefill rel={rel_l2(dec_rows, pre_rows):.3e}"
-        assert torch.equal(a[:, 0, :, :S0], b[:, 0, :, :S0])          # the prompt part was written by the same prefill kernels
+        # the prompt part: written by a 769-row prefill there and a 780-row prefill here (other GEMM tilings / K-slices, and row 768's
+        # MLP through the GEMV path only in the 769-row run), so equal up to bf16 rounding through 28 layers, not bit for bit
+        assert rel_l2(a[:, 0, :, :S0], b[:, 0, :, :S0]) < 2e-2, f"prompt {name} rel={rel_l2(a[:, 0, :, :S0], b[:, 0, :, :S0]):.3e}"
+        assert torch.equal(a[0, 0, :, :S0], b[0, 0, :, :S0]) or rel_l2(a[0, 0, :, :S0], b[0, 0, :, :S0]) < 4e-3     # layer 0: one GEMM deep
     # where the prefill's top-1 margin exceeds 4x the observed error the greedy ids must coincide
     err = float((lg.float() - ref.float()).abs().max())
     top2 = ref.float().topk(2, -1).values

@@ -195,3 +195,16 @@ def test_wide_llm_prefill_and_decode(wide):
     decisive = (top2[:, 0] - top2[:, 1]) > 4 * err
     assert rel_l2(lg, lg_o) < 3e-2, f"decode logits rel={rel_l2(lg, lg_o):.3e}"
     assert torch.equal(out[0].cpu()[decisive], ids_o[decisive])
+
+
+@pytest.mark.parametrize("S", [257, 260])
+def test_wide_llm_prefill_tail_rows_via_gemv(wide, S):
+    """S = k * 256 + (1..4): the MLP of the leftover rows runs through the decode GEMV kernels, the rest through the GEMMs — every row
+    must still match the oracle, the tail rows included."""
+    cfg, w, model = wide
+    g = torch.Generator().manual_seed(S)
+    e = (torch.randn(1, S, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16)
+    r = model.llm.prefill_packed(e[0].cuda(), torch.arange(S, dtype=torch.int32, device="cuda"), None, S, want_all_logits=True)
+    logits, _ = O.qwen2_forward(e.float(), w, cfg.llm)
+    assert rel_l2(r.all_logits, logits[0]) < 3e-2, f"all rows rel={rel_l2(r.all_logits, logits[0]):.3e}"
+    assert rel_l2(r.all_logits[256:], logits[0, 256:]) < 3e-2, f"tail rows rel={rel_l2(r.all_logits[256:], logits[0, 256:]):.3e}"

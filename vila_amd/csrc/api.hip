@@ -211,6 +211,8 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     bf16_t* taps = B(layer_hidden);
     if (taps) VILA_HIP(hipMemcpyAsync(taps, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
 
+    const int tail_rows = (T > 256 && T % 256 >= 1 && T % 256 <= 4 && H % 8 == 0 && F % 8 == 0) ? T % 256 : 0;
+    const int Tg = T - tail_rows;     // rows of the gate/up and down GEMMs; the rest via GEMV
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];
         VILA_TRY(launch_rmsnorm(x, B(L.ln1_w), h, T, H, sh.rms_eps, s));
@@ -240,8 +242,21 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
         VILA_TRY(launch_attn_fwd(at, s));
         VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes));   // x += o_proj(attn)
         VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
-        VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, T, F, H, EPI_GATEUP, s, L.w_up, 0, skws, skws_bytes));  // silu(gate)*up
-        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, T, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes));  // x += down(...)
+        // MLP.  A prompt of 3 x 256 + 1 tokens (the benchmark's 769) would spend a whole extra row-tile round on ONE row in the two
+        // big GEMMs; those 1-4 leftover rows go through the decode GEMV kernels instead (the weights stream once more at HBM rate:
+        // 44 + 25 us per row against 94 + 40 us for the extra tile round)
+        VILA_TRY(gemm(h, H, L.w_gate, H, nullptr, nullptr, 0, act, F, Tg, F, H, EPI_GATEUP, s, L.w_up, 0, skws, skws_bytes));  // silu(gate)*up
+        for (int r = Tg; r < T; ++r) {
+            GemvArgs g{};
+            g.x = h + (size_t)r * H; g.W = B(L.w_gate); g.W2 = B(L.w_up); g.y = act + (size_t)r * F; g.N = F; g.K = H; g.mode = 1;
+            VILA_TRY(launch_gemv(g, s));
+        }
+        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, Tg, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes));  // x += down(...)
+        for (int r = Tg; r < T; ++r) {
+            GemvArgs g{};
+            g.x = act + (size_t)r * F; g.W = B(L.w_down); g.residual = x + (size_t)r * H; g.y = x + (size_t)r * H; g.N = H; g.K = F; g.mode = 0;
+            VILA_TRY(launch_gemv(g, s));
+        }
         if (taps) VILA_HIP(hipMemcpyAsync(taps + (size_t)(l + 1) * T * H, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
     }
 

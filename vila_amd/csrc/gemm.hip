@@ -224,9 +224,13 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     // under-filled grid of 256^2 tiles (S = 769 prefill: 56 tiles for N = 3584): slice K over grid.y when a workspace is given
     if ((sel == 0 || sel == 5) && EPI == EPI_NONE && !OUT_F32 && a.ws != nullptr && a.M >= 512 && gemm256_supported(a)) {
         const int kt = cdiv(a.K, 64);
-        int splits = 0;      // largest power of two that keeps every slice resident at once (1 block of 512 threads per CU)
-        for (int c = 2; c <= 8; c *= 2)
-            if (kt % c == 0 && kt / c >= 8 && tiles256 * c <= 256 && (size_t)c * a.M * a.N * 4 <= a.ws_bytes) splits = c;
+        // as many K-slices as keep every block resident at once (one 512-thread block per CU), at most 8, at least 8 K-tiles each;
+        // slices need not be equal (the last one takes the remainder): 42 tiles x 6 slices fills 252 CUs where 4 would fill 168
+        int splits = (int)(256 / tiles256);
+        if (splits > 8) splits = 8;
+        while (splits >= 2 && (cdiv(kt, splits) < 8 || (size_t)splits * a.M * a.N * 4 > a.ws_bytes)) --splits;
+        if (splits >= 2) splits = cdiv(kt, cdiv(kt, splits));      // drop empty trailing slices
+        if (splits < 2) splits = 0;
         // K < 8192 (o_proj at S = 769): the DMA ring below does it in one launch at 557 TF/s vs 482 incl. the reduce
         if (kt < 128 && sel == 0) splits = 0;
         // measured at M = 769 (tools/microbench.py prefill): N=3584,K=18944 233 -> 122 us; N=3584,K=3584 51 -> 41 us;

@@ -356,11 +356,12 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
 
 // split-K: C = sum over `splits` K-slices; `slab` = splits * M * N fp32 workspace owned by the caller
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s) {
-    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && cdiv(a.K, T256_BK) % splits == 0 && a.N % 4 == 0, "gemm256 split-K: K tiles (%d) must divide by %d",
-                 cdiv(a.K, T256_BK), splits);
+    const int kt = cdiv(a.K, T256_BK), per = cdiv(kt, splits);
+    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && a.N % 4 == 0 && splits >= 1 && (splits - 1) * per < kt,
+                 "gemm256 split-K: %d K tiles cannot be cut into %d non-empty slices", kt, splits);
     GemmArgs b = a;
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
-    VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits)));
+    VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
