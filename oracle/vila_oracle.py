@@ -22,7 +22,6 @@ All tensors fp32 unless noted.  `w` is a flat dict keyed by the reference's stat
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vila_oracle as O
-from tests.gpu_util import max_abs, rel_l2
+from tests.gpu_util import rel_l2
 from vila_amd import configs, synthetic
 
 pytestmark = pytest.mark.gpu

@@ -1,6 +1,5 @@
 """GPU parity tests, operator level: every HIP kernel (called through the C-ABI) against a plain PyTorch fp32
 reference of the same op on the same seeded bf16 inputs.  Tolerances are stated per test."""
-import math
 
 import pytest
 import torch

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import json
 import os
-from typing import Dict, Iterable, Optional
+from typing import Dict, Iterable
 
 import torch
 from safetensors import safe_open

@@ -8,7 +8,6 @@ pins the values used here.
 from __future__ import annotations
 
 from dataclasses import dataclass, field, asdict
-from typing import Optional
 
 IGNORE_INDEX = -100  # llava/constants.py:26
 

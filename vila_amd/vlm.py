@@ -8,7 +8,7 @@ instead of a python loop with `.item()` per token; greedy generation never leave
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Optional
 
 import torch
 import torch.nn as nn
