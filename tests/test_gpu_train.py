@@ -154,8 +154,8 @@ def test_depth_to_space_is_adjoint_of_space_to_depth(ops):
         assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + 1)
 
 
-def test_adamw_matches_torch(ops):
-    n = 4096 + 24
+@pytest.mark.parametrize("n", [4096 + 24, 4096 + 27, 3])
+def test_adamw_matches_torch(ops, n):
     p0 = torch.randn(n, device="cuda")
     ref_p = p0.clone().requires_grad_(True)
     opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)

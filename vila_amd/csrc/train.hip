@@ -586,24 +586,50 @@ int launch_rope_bwd(bf16_t* dqkv, const float* cs, const float* sn, int S, int n
 // AdamW (torch.optim.AdamW semantics, adamw_torch in llava/train/args.py:223): fp32 master weight + m + v, bf16 grad in,
 // bf16 param out.  One flat launch over the whole model.
 // ------------------------------------------------------------------------------------------------
-__global__ void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v, const bf16_t* __restrict__ grad,
-                             bf16_t* __restrict__ param, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                             float grad_scale) {
-    EW_LOOP(n) {
-        const float g = bf2f(grad[i]) * grad_scale;
-        float p = master[i];
-        const float mi = b1 * m[i] + (1.f - b1) * g;
-        const float vi = b2 * v[i] + (1.f - b2) * g * g;
-        p *= (1.f - lr * wd);
-        p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
-        m[i] = mi; v[i] = vi; master[i] = p;
-        param[i] = f2bf(p);
+__device__ __forceinline__ void adamw_one(float& p, float& mi, float& vi, float g, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                          float bc2) {
+    mi = b1 * mi + (1.f - b1) * g;
+    vi = b2 * vi + (1.f - b2) * g * g;
+    p *= (1.f - lr * wd);
+    p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+// 4 parameters per lane: 16-B non-temporal accesses of master / m / v (read + write), 8 B of grad in and of the bf16 parameter out —
+// 28 B per parameter, every byte touched once per step (nothing to keep in L2 / MALL)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    const bf16_t* __restrict__ grad, bf16_t* __restrict__ param, int64_t n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2, float grad_scale) {
+    const int64_t n4 = n >> 2;
+    EW_LOOP(n4) {
+        f32x4 p = __builtin_nontemporal_load((const f32x4*)master + i);
+        f32x4 mi = __builtin_nontemporal_load((const f32x4*)m + i);
+        f32x4 vi = __builtin_nontemporal_load((const f32x4*)v + i);
+        const u32x2 g2 = __builtin_nontemporal_load((const u32x2*)grad + i);
+        const float g[4] = {lo_bf(g2[0]) * grad_scale, hi_bf(g2[0]) * grad_scale, lo_bf(g2[1]) * grad_scale, hi_bf(g2[1]) * grad_scale};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p[k], mk = mi[k], vk = vi[k];
+            adamw_one(pk, mk, vk, g[k], lr, b1, b2, eps, wd, bc1, bc2);
+            p[k] = pk; mi[k] = mk; vi[k] = vk;
+        }
+        __builtin_nontemporal_store(mi, (f32x4*)m + i);
+        __builtin_nontemporal_store(vi, (f32x4*)v + i);
+        __builtin_nontemporal_store(p, (f32x4*)master + i);
+        u32x2 o; o[0] = pack2bf(p[0], p[1]); o[1] = pack2bf(p[2], p[3]);
+        __builtin_nontemporal_store(o, (u32x2*)param + i);
+    }
+    // tail (n % 4)
+    const int64_t t = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < n) {
+        float p = master[t], mi = m[t], vi = v[t];
+        adamw_one(p, mi, vi, bf2f(grad[t]) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        m[t] = mi; v[t] = vi; master[t] = p; param[t] = f2bf(p);
     }
 }
 int launch_adamw(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, int step, float grad_scale, hipStream_t s) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(EW_GRID(n)), dim3(256), 0, s, master, m, v, grad, param, n, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
+    VILA_REQUIRE(((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && ((uintptr_t)grad | (uintptr_t)param) % 8 == 0, "adamw: buffers must be 16-B (fp32) / 8-B (bf16) aligned");
+    hipLaunchKernelGGL(adamw_kernel, dim3(EW_GRID((n >> 2) > 0 ? (n >> 2) : 1)), dim3(256), 0, s, master, m, v, grad, param, n, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
     VILA_LAUNCH_CHECK();
     return 0;
 }
