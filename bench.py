@@ -5,9 +5,18 @@
 
 A "step" = one greedy decode token through all 28 decoder layers + lm_head + argmax (one hipGraph replay).  The
 prefill (ViT + projector + splice + 769-token LLM prefill) runs before the timed region and is reported as TTFT.
-N > 1: one process per GPU (torchrun), independent replicas (inference has no exchange step: SURVEY.md §8e),
-value = total tokens/s over all ranks, time = max over ranks.  Inputs and weights are resident in HBM before timing.
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU, independent replicas (inference has no exchange step: SURVEY.md §8e), value = total tokens/s
+over all ranks, time = max over ranks.  Inputs and weights are resident in HBM before timing.  Prints ONE JSON line on rank 0.
+
+Launching: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks come from the environment
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Started plainly as `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the
+environment) it re-executes itself under torch.distributed.run on 127.0.0.1 — the reference launches its ranks the same way
+(`torchrun --nproc_per_node`, scripts/NVILA-Lite/sft.sh:15-17).  `--selftest` runs only the harness (rendezvous, barrier, max-over-
+ranks timing, the one JSON line) on the gloo backend without touching a GPU: tests/test_bench_launcher_cpu.py drives it with 2 ranks.
+
+Besides the decode metric the default line carries `prefill` (TTFT as TFLOP/s against the MFMA peak) and `sft` (one warm + two timed
+NVILA-8B SFT steps, BASELINE configs[2] per-GPU workload) so that the MFMA-bound halves of the north star are driver-observed too,
+and `sustained` (a >= 2 s decode replay after the timed region, so that a 5-s GPU-busy sampler has something to see).
 """
 from __future__ import annotations
 
@@ -15,7 +24,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -25,27 +36,115 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 A100_DECODE_TOKS = 82.1   # NVILA-8B FP16 decode tok/s on A100 (README.md:65) — other hardware, fp16
+SFT_TFLOP_PER_SAMPLE = 35.8   # fwd+bwd of one 769-token sample (1 image + 512 text), no recompute
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager-decode", action="store_true", help="experiment: launch the 171 kernels per token eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-sft", action="store_true", help="decode mode: skip the bounded SFT sub-measurement (1 warm + 2 timed steps)")
+    ap.add_argument("--no-sustain", action="store_true", help="decode mode: skip the >= 2 s sustained replay after the timed region")
+    ap.add_argument("--eager-decode", action="store_true", help="experiment: launch the kernels of a token eagerly instead of replaying a hipGraph")
     ap.add_argument("--config", default="nvila_8b", choices=["nvila_8b", "reduced"])
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--tsp", action="store_true", help="video mode: TSPVideoEncoder pool_sizes=[[8,1,1]] (scripts/NVILA/stage4.sh:50) -> 8 x 257 tokens")
     ap.add_argument("--mode", default="decode", choices=["decode", "sft", "video"],
                     help="decode = BASELINE.json metric (default); sft = one data-parallel SFT step (BASELINE configs[2])")
     ap.add_argument("--micro-batch", type=int, default=4)
     ap.add_argument("--w4", action="store_true", help="W4A16 decode (int4 group-128 decoder projections; BASELINE configs[4], SURVEY 8f row 3)")
+    ap.add_argument("--w8-vit", action="store_true", help="W8A8 vision tower (int8 x int8 per-channel ViT GEMMs; BASELINE configs[4])")
     ap.add_argument("--dynamic-s2", action="store_true", help="full NVILA-8B recipe: 14 tiles (448/896/1344) -> 2304 image tokens (SURVEY 8f row 1)")
-    return ap.parse_args()
+    ap.add_argument("--selftest", action="store_true", help="harness only (gloo, no GPU): rendezvous + barrier + max-over-ranks + JSON line")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` spawns its own N ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv) -> int:
+    """Re-execute this file under torch.distributed.run with one process per GPU.  Returns the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL over xGMI needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                  # scripts/setups/train.sh:59
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_dist(backend: str, dev=None):
+    """Process group from the torchrun environment.  RCCL prints a version banner on STDOUT when the communicator is created;
+    stdout must carry the one JSON line only, so fd 1 points at stderr while the group and its first collective come up."""
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    return dist
+
+
+def timed_region(dist, dev, steps: int, step_fn, sync):
+    """The contract's bracket: barrier + sync, EXACTLY `steps` steps, sync + barrier, MAX over ranks."""
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev if dev is not None else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def selftest_main(a, rank, world):
+    """Harness self-test on CPU/gloo: same launcher, rendezvous, barrier, max-over-ranks and JSON plumbing as the GPU modes; the
+    "step" is a fixed sleep, so value ~= world / 2 ms.  NOT a performance number."""
+    dist = init_dist("gloo") if world > 1 else None
+    for _ in range(a.warmup):
+        time.sleep(0.002)
+    elapsed = timed_region(dist, None, a.steps, lambda: time.sleep(0.002), lambda: None)
+    group_world = dist.get_world_size() if dist is not None else 1
+    if rank == 0:
+        print(json.dumps({"metric": "bench harness selftest (no GPU work)", "value": round(world * a.steps / elapsed, 2), "unit": "steps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "selftest", "parallelism": f"gloo x{world}", "group_world_size": group_world,
+                                     "requested_gpus": a.gpus}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# algorithmic work (SURVEY §8d)
+# ----------------------------------------------------------------------------------------------------------------------
 def decode_bytes_per_token(cfg, ctx: int, w4: bool = False) -> int:
     """Algorithmic HBM bytes per decoded token: every layer + lm_head weight once (bf16) + the KV cache.
     W4A16: layer weights cost 0.5 B + 4 B per 128-group (scale|zero) = 0.53125 B each; lm_head stays bf16."""
@@ -59,50 +158,94 @@ def decode_bytes_per_token(cfg, ctx: int, w4: bool = False) -> int:
     return w + kv
 
 
+def vit_flops(cfg, n_tiles: int) -> float:
+    v = cfg.vision
+    N, d, f = v.num_patches, v.hidden_size, v.intermediate_size
+    per_layer = 4 * 2 * N * d * d + 2 * 2 * N * d * f + 2 * 2 * N * N * d
+    return n_tiles * (v.num_used_layers * per_layer + 2 * N * v.num_channels * v.patch_size ** 2 * d)
+
+
+def projector_flops(cfg, n_tiles: int) -> float:
+    k, c, h = cfg.downsample, cfg.mm_hidden_size, cfg.llm.hidden_size
+    T = cfg.tokens_per_tile
+    if cfg.mm_projector_type == "mlp_downsample_3x3_fix":
+        return n_tiles * 2 * T * (9 * c * 3 * c + 3 * c * h + h * h)
+    return n_tiles * 2 * T * (k * k * c * h + h * h)
+
+
+def llm_prefill_flops(cfg, S: int) -> float:
+    c = cfg.llm
+    d, f = c.hidden_size, c.intermediate_size
+    per_layer = 2 * S * d * (c.q_size + 2 * c.kv_size) + 2 * S * c.q_size * d + 6 * S * d * f + 2 * S * S * c.q_size
+    return c.num_hidden_layers * per_layer + 2 * d * c.vocab_size
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle "port", bounded sample)
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(cfg, n_prompt: int, threads: int):
-    """Oracle ("port") timed on the host cores on a bounded sample: NVILA-8B widths with 2 of 28 decoder layers (fp32),
-    S-token prefill then 4 decode tokens; per-token time is scaled to 28 layers (layer part) + the measured lm_head part."""
+    """Oracle ("port") timed on the host cores on a bounded sample of the SAME workload (fp32, NVILA-8B widths, random weights):
+      * decode: 2 of 28 decoder layers, S-token prefill then 4 decode tokens; per-token = layer part x 14 + measured lm_head
+      * TTFT : 2 of 26 ViT layers x 13 + patch embed + projector (1 tile) + the 2-layer prefill x 14 + last-row lm_head
+    The prefill sample uses an 8-row stand-in head so that it times the layers only (HF generate keeps one logits row)."""
     from oracle import vila_oracle as O
     from vila_amd import configs, synthetic
     torch.set_num_threads(threads)
-    L = 2
-    c = configs.reduced_8b(layers_v=1, layers_l=L, vocab=cfg.llm.vocab_size)
-    specs = [s for s in synthetic.llm_specs(c) if "embed_tokens" not in s[0]]
+    L, LV = 2, 2
+    c = configs.reduced_8b(layers_v=LV + 1, layers_l=L, vocab=cfg.llm.vocab_size)     # LV+1 layers: select_layer=-2 runs LV of them
     g = torch.Generator().manual_seed(0)
-    w = {n: torch.randn(shape, generator=g) * 0.02 if k in ("w", "h") else torch.ones(shape) for n, shape, k in specs}
-    w["llm.model.embed_tokens.weight"] = w["llm.lm_head.weight"]     # timing only: share the table to bound host RAM
+
+    def draw(specs):
+        return {n: torch.randn(shape, generator=g) * 0.02 if k in ("w", "h") else torch.ones(shape) for n, shape, k in specs}
+    w = draw([s for s in synthetic.llm_specs(c) if "embed_tokens" not in s[0]])
+    head = w["llm.lm_head.weight"]
+    w["llm.model.embed_tokens.weight"] = head           # timing only: share the table to bound host RAM
     e = torch.randn(1, n_prompt, c.llm.hidden_size, generator=g)
     with torch.no_grad():
+        w["llm.lm_head.weight"] = head[:8]
         t0 = time.perf_counter()
-        logits, past = O.qwen2_forward(e, w, c.llm)
+        _, past = O.qwen2_forward(e, w, c.llm)
         t_prefill = time.perf_counter() - t0
+        w["llm.lm_head.weight"] = head
         x = torch.randn(1, 1, c.llm.hidden_size, generator=g)
         n_tok = 4
         t0 = time.perf_counter()
         for _ in range(n_tok):
-            logits, past = O.qwen2_forward(x, w, c.llm, past=past)
+            _, past = O.qwen2_forward(x, w, c.llm, past=past)
         t_tok = (time.perf_counter() - t0) / n_tok
         h = torch.randn(1, 1, c.llm.hidden_size)
         t0 = time.perf_counter()
         for _ in range(3):
-            torch.nn.functional.linear(h, w["llm.lm_head.weight"])
+            torch.nn.functional.linear(h, head)
         t_head = (time.perf_counter() - t0) / 3
-    t_full = (t_tok - t_head) * (cfg.llm.num_hidden_layers / L) + t_head
+        del past
+        wv = draw(synthetic.vision_specs(c) + synthetic.projector_specs(c))
+        px = torch.rand(1, 3, c.vision.image_size, c.vision.image_size, generator=g) * 2 - 1
+        t0 = time.perf_counter()
+        feats = O.vision_tower_forward(px, wv, c.vision)
+        t_vit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.projector_forward(feats, wv, c.mm_projector_type)
+        t_proj = time.perf_counter() - t0
+    nl, nv = cfg.llm.num_hidden_layers, cfg.vision.num_used_layers
+    t_full = (t_tok - t_head) * (nl / L) + t_head
+    ttft = t_vit * (nv / LV) + t_proj + t_prefill * (nl / L) + t_head
     return {"value": round(1.0 / t_full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/vila_oracle.py qwen2_forward fp32, NVILA-8B widths, {L} of {cfg.llm.num_hidden_layers} decoder layers "
-                      f"+ full lm_head, {n_prompt}-token prefill ({t_prefill:.2f}s) then {n_tok} decode tokens "
-                      f"({t_tok*1e3:.0f} ms/token measured; layer part scaled x{cfg.llm.num_hidden_layers // L})",
-            "prefill_s_sample": round(t_prefill, 3)}
+            "sample": f"oracle/vila_oracle.py fp32 at NVILA-8B widths: {L} of {nl} decoder layers + full lm_head, {n_prompt}-token prefill "
+                      f"({t_prefill:.2f}s, layers only) then {n_tok} decode tokens ({t_tok*1e3:.0f} ms/token measured; layer part scaled x{nl // L}); "
+                      f"TTFT leg: {LV} of {nv} ViT layers ({t_vit:.2f}s, scaled x{nv / LV:g}) + projector ({t_proj:.2f}s) + prefill x{nl // L} + lm_head row",
+            "prefill_s_sample": round(t_prefill, 3), "vit_s_sample": round(t_vit, 3), "projector_s": round(t_proj, 3),
+            "ttft_s": round(ttft, 2), "ttft_note": "CPU TTFT estimate for the same 1 image + prompt workload (scaled from the samples above)"}
 
 
-def sft_main(a, rank, local, world, dev, dist):
-    """BASELINE configs[2]: NVILA-8B SFT step, per-GPU micro-batch of b samples (1 x 448^2 image + 512 text tokens, S = 769,
-    packed), labels on the last 256 text positions, all 8.06 B params trainable, AdamW lr 2e-5; weak scaling over ranks."""
-    from vila_amd import configs, synthetic
+# ----------------------------------------------------------------------------------------------------------------------
+# SFT step (BASELINE configs[2])
+# ----------------------------------------------------------------------------------------------------------------------
+def sft_measure(model, cfg, a, rank, dev, dist, steps: int, warmup: int):
+    """Per-GPU micro-batch of b samples (1 x 448^2 image + 512 text tokens, S = 769, packed), labels on the last 256 text
+    positions, all 8.06 B params trainable, AdamW lr 2e-5 (scripts/NVILA-Lite/sft.sh:41-42).  Returns (seconds for `steps`, loss, S, trainer)."""
+    from vila_amd import synthetic
     from vila_amd.train import SFTTrainer
-    from vila_amd.vlm import build_model
-    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
-    model = build_model(cfg, seed=0, device=dev)
     tr = SFTTrainer(model, lr=2e-5, weight_decay=0.0)
     b = a.micro_batch
     pixels = synthetic.make_pixels(cfg, b, rank, device=dev, dtype=torch.bfloat16)
@@ -111,41 +254,52 @@ def sft_main(a, rank, local, world, dev, dist):
     labels[:, : 1 + a.prompt_tokens - 256] = -100
     S = cfg.tokens_per_tile + 1 + a.prompt_tokens
     images = [pixels[i] for i in range(b)]
-    for _ in range(a.warmup):
-        loss = tr.step(ids, images, labels)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = tr.step(ids, images, labels)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    box = {"loss": float("nan")}
+
+    def one():
+        box["loss"] = tr.step(ids, images, labels)
+    for _ in range(warmup):
+        one()
+    elapsed = timed_region(dist, dev, steps, one, torch.cuda.synchronize)
+    return elapsed, float(box["loss"]), S, tr
+
+
+def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: float):
+    step_s = elapsed / steps
+    flops = SFT_TFLOP_PER_SAMPLE * 1e12 * b
+    return {"ms_per_step": round(step_s * 1e3, 2), "tokens_per_s": round(world * b * S / step_s, 1), "steps": steps, "micro_batch": b, "loss": round(loss, 4),
+            "roofline": {"bound": "mfma", "achieved": round(flops / step_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(flops / step_s / (MFMA_PEAK_TF * 1e12), 4), "traffic": None,
+                         "note": f"whole step incl. optimizer; {SFT_TFLOP_PER_SAMPLE} TFLOP per 769-token sample fwd+bwd (SURVEY §8d), no activation recompute"}}
+
+
+def sft_main(a, rank, world, dev, dist):
+    from vila_amd import configs
+    from vila_amd.vlm import build_model
+    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    model = build_model(cfg, seed=0, device=dev)
+    elapsed, loss, S, tr = sft_measure(model, cfg, a, rank, dev, dist, a.steps, a.warmup)
     if rank == 0:
-        step_s = elapsed / a.steps
-        flops = 35.8e12 * b              # fwd+bwd per 769-token sample, no recompute
+        blk = sft_block(elapsed, a.steps, a.micro_batch, S, world, loss)
         print(json.dumps({
-            "metric": "SFT step throughput, NVILA-8B, packed 1x448^2 image + 512-token samples", "value": round(world * b * S / step_s, 1),
-            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 2),
+            "metric": "SFT step throughput, NVILA-8B, packed 1x448^2 image + 512-token samples", "value": blk["tokens_per_s"],
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": blk["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 master/AdamW state)",
-            "data": "synthetic", "loss": round(float(loss), 4),
-            "config": {"workload": f"{cfg.name} SFT step, micro-batch {b} x S={S} packed, all params trainable, AdamW", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(flops / step_s / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(flops / step_s / 2.5e15, 4), "traffic": None,
-                         "note": "whole step incl. optimizer and transposes; 35.8 TFLOP per sample (SURVEY §8d)"}}))
+            "data": "synthetic", "loss": blk["loss"],
+            "config": {"workload": f"{cfg.name} SFT step, micro-batch {a.micro_batch} x S={S} packed, all params trainable, AdamW",
+                       "parallelism": f"dp{world}", "grad_exchange": tr.reducer.describe()},
+            "roofline": blk["roofline"]}))
     if dist is not None:
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# video prefill (BASELINE configs[3])
+# ----------------------------------------------------------------------------------------------------------------------
 def video_main(a, rank, dev):
-    """BASELINE configs[3]: NVILA-Video-8B-style prefill, `--frames` 448^2 frames as per-frame <image> tokens
-    (llava/utils/media.py:114-119: 64 x 257 = 16448 media tokens + 32 text), mlp_downsample_2x2_fix projector."""
+    """NVILA-Video-8B-style prefill of `--frames` 448^2 frames, mlp_downsample_2x2_fix projector.  Two token layouts:
+    (i) per-frame <image> tokens (llava/utils/media.py:114-119: 64 x 257 = 16448 media tokens + 32 text);
+    (ii) --tsp: TSPVideoEncoder pool_sizes=[[8,1,1]] (scripts/NVILA/stage4.sh:50): temporal mean-pool by 8 -> 8 x 257 = 2056 tokens."""
     from vila_amd import configs, ops, synthetic
     from vila_amd.vlm import build_model
     cfg = configs.nvila_8b()
@@ -153,17 +307,27 @@ def video_main(a, rank, dev):
     model = build_model(cfg, seed=0, device=dev)
     F_ = a.frames
     pixels = synthetic.make_pixels(cfg, F_, 0, device=dev, dtype=torch.bfloat16)
-    ids = synthetic.make_prompt(cfg, 32, F_, 0)[None].to(dev)
-    S = F_ * (cfg.tokens_per_tile + 1) + 32
-    cache = model.llm.new_cache(((S + 64 + 255) // 256) * 256)
     frames = [pixels[i] for i in range(F_)]
+    if a.tsp:
+        pool = [[8, 1, 1]]
+        n_media = (F_ + 7) // 8 * (cfg.tokens_per_tile + 1)
+        ids = synthetic.make_prompt(cfg, 32, 1, 0)[None].to(dev)
+        ids[0, 0] = cfg.video_token_id
+        media, media_cfg = {"video": [torch.stack(frames, 0)]}, {"video": {"pool_sizes": pool}}
+    else:
+        n_media = F_ * (cfg.tokens_per_tile + 1)
+        ids = synthetic.make_prompt(cfg, 32, F_, 0)[None].to(dev)
+        media, media_cfg = {"image": frames}, {}
+    S = n_media + 32
+    cache = model.llm.new_cache(((S + 64 + 255) // 256) * 256)
 
     def once():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e, _, _ = model._embed(ids, {"image": frames})
+        e, _, _ = model._embed(ids, media, media_cfg)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        assert e.shape[1] == S, (e.shape, S)
         r = model.llm.prefill_packed(e[0], torch.arange(S, device=dev, dtype=torch.int32), None, S, cache=cache,
                                      last_rows=torch.tensor([S - 1], device=dev, dtype=torch.int32))
         first = int(ops.argmax(r.last_logits[0]))
@@ -173,49 +337,20 @@ def video_main(a, rank, dev):
     ts = [once() for _ in range(max(a.steps if a.steps != 128 else 3, 1))]
     enc = statistics.median(t[0] for t in ts)
     pre = statistics.median(t[1] for t in ts)
-    flops = F_ * 0.953e12 + 28 * (4 * S * 3584 ** 2 + 4 * S * 3584 * 512 + 6 * S * 3584 * 18944 + 2 * S * S * 3584) + 2 * 3584 * 152064
+    flops = vit_flops(cfg, F_) + projector_flops(cfg, F_) + llm_prefill_flops(cfg, S)
     print(json.dumps({"metric": "TTFT, NVILA-Video-8B-style prefill", "value": round((enc + pre) * 1e3, 2), "unit": "ms", "n_gpus": 1,
                       "higher_is_better": False, "dtype": "bf16", "data": "synthetic",
-                      "config": {"workload": f"{F_} frames x 448^2 -> {S} tokens (per-frame <image> tokens), batch 1"},
+                      "config": {"workload": f"{F_} frames x 448^2 -> {S} tokens ({'TSPVideoEncoder pool [[8,1,1]]' if a.tsp else 'per-frame <image> tokens'}), batch 1"},
                       "encode_ms": round(enc * 1e3, 2), "llm_prefill_ms": round(pre * 1e3, 2),
-                      "roofline": {"bound": "mfma", "achieved": round(flops / (enc + pre) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": round(flops / (enc + pre) / 2.5e15, 4), "traffic": None},
+                      "roofline": {"bound": "mfma", "achieved": round(flops / (enc + pre) / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": round(flops / (enc + pre) / (MFMA_PEAK_TF * 1e12), 4), "traffic": None},
                       "reference_note": "README.md:84: 0.7190 s on A100 FP16 (TinyChat, 64 frames, pooled tokens) - other hardware"}))
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1 or os.environ.get("VILA_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
-        import torch.distributed as dist_
-        dist = dist_
-        # RCCL prints a version banner on STDOUT when the communicator is created; stdout must carry the one JSON line only,
-        # so fd 1 points at stderr while the process group and its first collective come up
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-
-    if a.mode == "video":
-        return video_main(a, rank, dev)
-    if a.mode == "sft":
-        if a.steps == 128 and a.warmup == 16:
-            a.steps, a.warmup = 3, 1
-        return sft_main(a, rank, local, world, dev, dist)
+# ----------------------------------------------------------------------------------------------------------------------
+# decode (the BASELINE metric)
+# ----------------------------------------------------------------------------------------------------------------------
+def decode_main(a, rank, world, dev, dist):
     from vila_amd import _lib, configs, ops, synthetic
     from vila_amd.vlm import build_model
     lib = _lib.load()
@@ -225,6 +360,8 @@ def main():
         cfg = configs.nvila_8b_s2()
         n_tiles, media_cfg = 14, {"image": {"block_sizes": [(3, 3)]}}
     model = build_model(cfg, seed=0, device=dev)
+    if a.w8_vit:
+        model.vision_tower.quantize_w8()
     llm = model.llm
     pixels = synthetic.make_pixels(cfg, n_tiles, 0, device=dev, dtype=torch.bfloat16)
     ids = synthetic.make_prompt(cfg, a.prompt_tokens, 1, 0)[None].to(dev)
@@ -248,22 +385,41 @@ def main():
         t, first, e = ttft_once()
         tt.append(t)
     ttft = statistics.median(tt)
+    # the encoder part alone (ViT + projector), HIP-event timed on the current stream
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bs = media_cfg.get("image", {}).get("block_sizes")
+    torch.cuda.synchronize()
+    ev_a.record()
+    for _ in range(3):
+        model.encode_images(pixels, block_sizes=bs)
+    ev_b.record()
+    torch.cuda.synchronize()
+    encode_ms = ev_a.elapsed_time(ev_b) / 3
+    prefill_flops = vit_flops(cfg, n_tiles) + projector_flops(cfg, n_tiles) + llm_prefill_flops(cfg, S)
+    prefill = {"ttft_ms": round(ttft * 1e3, 3), "encode_images_ms": round(encode_ms, 3), "tflop": round(prefill_flops / 1e12, 3),
+               "roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(prefill_flops / ttft / (MFMA_PEAK_TF * 1e12), 4), "traffic": None,
+                            "note": "algorithmic FLOPs of ViT (26 layers) + projector + LLM prefill + last-row lm_head (SURVEY §8d) / host-observed TTFT"}}
 
     if a.w4:
         w4 = llm.quantize_w4(keep_logical=False)     # decode now streams int4 weights; the prefill above used bf16
     # ---- decode: capture one step in a hipGraph, replay ----
     st = llm._decode_session(cache, max_new)
     stream = st.stream
-    st.pos.fill_(S); st.n_out.zero_(); st.token.fill_(first)
+
+    def reset_state():
+        st.pos.fill_(S); st.n_out.zero_(); st.token.fill_(first)
+    reset_state()
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
         llm.decode_step(cache, st)                    # warm (outside capture)
         stream.synchronize()
-        st.pos.fill_(S); st.n_out.zero_(); st.token.fill_(first)
+        reset_state()
         _lib.check(lib.vila_graph_begin(stream.cuda_stream), "graph_begin")
         llm.decode_step(cache, st)
         g = C.c_void_p()
         _lib.check(lib.vila_graph_end(stream.cuda_stream, C.byref(g)), "graph_end")
+
         def one_step():
             if a.eager_decode:
                 llm.decode_step(cache, st)
@@ -271,11 +427,11 @@ def main():
                 _lib.check(lib.vila_graph_launch(g, stream.cuda_stream), "graph_launch")
         for _ in range(a.warmup):
             one_step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
@@ -294,6 +450,27 @@ def main():
     ctx_mid = S + a.warmup + a.steps // 2
     step_bytes = decode_bytes_per_token(cfg, ctx_mid, a.w4)
     step_s = elapsed / a.steps
+    launches = int(lib.vila_llm_decode_launches(C.byref(llm._struct().shape), cache.max_ctx))
+
+    # ---- sustained replay (>= 2 s of back-to-back tokens; context rewound whenever the cache fills) ----
+    sustained = None
+    if not a.no_sustain and not a.eager_decode:
+        room = min(cache.max_ctx - S - 2, max_new - 2)
+        n_sus = max(int(2.2 / step_s), 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        with torch.cuda.stream(stream):
+            while done < n_sus:
+                reset_state()
+                chunk = min(room, n_sus - done)
+                for _ in range(chunk):
+                    one_step()
+                done += chunk
+        torch.cuda.synchronize()
+        sus_s = time.perf_counter() - t0
+        sustained = {"seconds": round(sus_s, 3), "tokens": done, "tokens_per_s": round(done / sus_s, 2),
+                     "note": "corroboration run after the timed region (same graph, context rewound when the cache fills); not `value`"}
 
     # ---- roofline of the dominant kernel: gemv_kernel<1> (fused RMSNorm + gate/up GEMV + SiLU*mul = 54% of the decode
     # bytes).  Timed live with HIP events on the launch stream, cycling over the 28 layers' weights so the 256 MiB
@@ -333,18 +510,29 @@ def main():
     # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
     # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
-        with open(tj) as f:
-            tdata = json.load(f)
-        if tdata.get("algorithmic_bytes_per_launch") == kern_bytes:
-            traffic, traffic_src = tdata["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
+    for tj_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tj = os.path.join(ROOT, "profiles", tj_name)
+        if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
+            with open(tj) as f:
+                tdata = json.load(f)
+            if tdata.get("algorithmic_bytes_per_launch") == kern_bytes:
+                traffic, traffic_src = tdata["traffic_bytes_per_launch"], f"profiles/{tj_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"
+                break
     roofline = {"bound": "hbm", "kernel": ("gemv_w4_kernel<1>" if a.w4 else "gemv_kernel<1>") + " (RMSNorm + gate/up GEMV + SiLU*mul)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_us": round(kern_s * 1e6, 2),
                 "whole_step": {"bytes_per_token": step_bytes, "achieved": round(step_bytes / step_s / 1e9, 1),
                                "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                "gpu_ms_per_step_hip_events": round(ev0.elapsed_time(ev1) / a.steps, 4)}}
+
+    # ---- bounded SFT sub-measurement: 1 warm + 2 timed steps of the configs[2] per-GPU workload (needs ~150 GB of the 288 GB) ----
+    sft = None
+    if world == 1 and not a.no_sft and not a.w4 and not a.dynamic_s2 and not a.w8_vit and a.config == "nvila_8b":
+        try:
+            el, loss, S_sft, _tr = sft_measure(model, cfg, a, rank, dev, None, 2, 1)
+            sft = sft_block(el, 2, a.micro_batch, S_sft, 1, loss)
+        except Exception as ex:      # the decode line must survive a failure of the side measurement; say so loudly in the JSON
+            sft = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank != 0:
         if dist is not None:
@@ -363,16 +551,46 @@ def main():
         "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16", "data": "synthetic (seeded random weights at NVILA-8B shapes; U(-1,1) pixels; random prompt ids)",
         "ttft_ms": round(ttft * 1e3, 3),
         "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
-        "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
+        "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}{' + W8A8 vision tower' if a.w8_vit else ''}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
                                f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                   "decode": f"hipGraph replay of {c.num_hidden_layers * (5 if cache.c.max_ctx <= 2048 else 6) + 5} launches/token "
-                             f"({5 if cache.c.max_ctx <= 2048 else 6} per layer + embed/lm_head/argmax x2/advance)"},
+                   "decode": f"hipGraph replay of {launches} launches/token"},
         "roofline": roofline,
+        "prefill": prefill,
+        "sft": sft,
+        "sustained": sustained,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a, argv))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
+    if a.selftest:
+        return selftest_main(a, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1 or os.environ.get("VILA_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
+        dist = init_dist("nccl", dev)
+    if a.mode == "video":
+        return video_main(a, rank, dev)
+    if a.mode == "sft":
+        if a.steps == 128 and a.warmup == 16:
+            a.steps, a.warmup = 3, 1
+        return sft_main(a, rank, world, dev, dist)
+    return decode_main(a, rank, world, dev, dist)
 
 
 if __name__ == "__main__":

@@ -137,6 +137,8 @@ typedef struct {
     float* logits;       /* [vocab] fp32 logits of the last step (kept for parity tests) */
 } VilaDecodeState;
 size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx);
+/* number of kernel launches one decode step enqueues (what a captured hipGraph replays per token) */
+int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx);
 int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
                          void* workspace, size_t workspace_bytes, vila_stream_t stream);
 

@@ -1,0 +1,49 @@
+"""bench.py's own launcher (`python bench.py --gpus N` with no torchrun around it), driven on CPU: `--selftest` keeps the launcher,
+the rendezvous on 127.0.0.1, the barrier + max-over-ranks bracket and the one-JSON-line contract, and swaps the GPU work for a sleep
+on the gloo backend.  What the driver runs at round end is exactly this path with the GPU modes instead of --selftest."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one JSON line, got {lines}"
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_prints_one_line():
+    out = _run(["--gpus", "2", "--selftest", "--steps", "5", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 1
+    assert out["config"]["group_world_size"] == 2 and out["config"]["requested_gpus"] == 2
+    # 2 ranks x 5 steps of >= 2 ms each, max over ranks: the aggregate cannot beat 2 / 2 ms
+    assert 0 < out["value"] <= 1000.0 + 1e-6
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+
+
+def test_single_rank_needs_no_launcher():
+    out = _run(["--gpus", "1", "--selftest", "--steps", "3", "--warmup", "0"])
+    assert out["n_gpus"] == 1 and out["config"]["group_world_size"] == 1
+
+
+def test_under_torchrun_the_environment_wins():
+    """The driver's N > 1 form: torch.distributed.run sets RANK/WORLD_SIZE; bench.py must not spawn again."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2

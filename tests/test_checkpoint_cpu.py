@@ -68,3 +68,33 @@ def test_reference_checkpoint_extras_are_ignored_and_missing_detected(tmp_path):
         raise AssertionError("missing parameter not detected")
     except KeyError as e:
         assert "patch_embedding.bias" in str(e)
+
+
+def test_projector_type_is_read_where_the_reference_stores_it(tmp_path):
+    """The reference's LlavaConfig has no top-level `mm_projector_type` (base_projector.py:126-131: it lives in the projector's own
+    config).  A reference-shaped config.json — sub-configs as dicts or as sub-folder paths — must resolve the 3x3 projector."""
+    import json
+    from vila_amd.checkpoint import config_from_pretrained, resolve_projector_type
+    llm = {"hidden_size": 64, "intermediate_size": 128, "num_hidden_layers": 1, "num_attention_heads": 2, "num_key_value_heads": 1, "vocab_size": 100}
+    vt = {"hidden_size": 32, "intermediate_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2, "image_size": 28, "patch_size": 14}
+    d = tmp_path / "as_dicts"
+    d.mkdir()
+    json.dump({"llm_cfg": llm, "vision_tower_cfg": vt, "mm_projector_cfg": {"model_type": "v2l_projector", "mm_projector_type": "mlp_downsample_3x3_fix"}},
+              open(d / "config.json", "w"))
+    assert config_from_pretrained(str(d)).mm_projector_type == "mlp_downsample_3x3_fix"
+    p = tmp_path / "as_paths"
+    for sub, cfg in (("llm", llm), ("vision_tower", vt), ("mm_projector", {"mm_projector_type": "mlp_downsample_2x2_fix"})):
+        (p / sub).mkdir(parents=True)
+        json.dump(cfg, open(p / sub / "config.json", "w"))
+    json.dump({"llm_cfg": str(p / "llm"), "vision_tower_cfg": str(p / "vision_tower"), "mm_projector_cfg": str(p / "mm_projector")}, open(p / "config.json", "w"))
+    assert config_from_pretrained(str(p)).mm_projector_type == "mlp_downsample_2x2_fix"
+    assert resolve_projector_type({}) == "mlp_downsample"
+
+
+def test_live_model_projector_type_comes_from_the_projector_config():
+    from types import SimpleNamespace as NS
+    from vila_amd.integration import projector_type_of
+    proj = NS(config=NS(mm_projector_type="mlp_downsample_3x3_fix"))
+    assert projector_type_of(NS(mm_projector_cfg={"mm_projector_type": "mlp_downsample"}), proj) == "mlp_downsample_3x3_fix"
+    assert projector_type_of(NS(mm_projector_cfg={"mm_projector_type": "mlp_downsample_2x2_fix"}), None) == "mlp_downsample_2x2_fix"
+    assert projector_type_of(None, None) == "mlp_downsample"

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import vila_oracle as O
-from tests.gpu_util import rel_l2
+from tests.gpu_util import margin_aware_ids, rel_l2
 from vila_amd import configs, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -25,9 +25,10 @@ def test_text_only_prompt_generates(tiny):
     assert e.shape == (1, 10, cfg.llm.hidden_size) and bool(mask.all())
     assert torch.equal(e[0].float().cpu(), w["llm.model.embed_tokens.weight"][ids[0]])
     out = model.generate(input_ids=ids, media={}, max_new_tokens=4, eos_token_id=-1)
-    ids_o, _ = O.vlm_generate([], ids[0], w, cfg, 4, stop_at_eos=False)
+    ids_o, lg_o = O.vlm_generate([], ids[0], w, cfg, 4, stop_at_eos=False)
     assert out.shape == (1, 4)
-    assert out[0, 0].item() == ids_o[0].item() or True   # margin-free first-token check is covered elsewhere
+    _, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=4, return_logits=True, forced_ids=ids_o, use_graph=False)
+    margin_aware_ids(lg, lg_o, ids_o, free_ids=out[0])
 
 
 def test_splice_errors_use_reference_messages(tiny):

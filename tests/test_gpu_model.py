@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import vila_oracle as O
-from tests.gpu_util import max_abs, rel_l2
+from tests.gpu_util import margin_aware_ids, max_abs, rel_l2
 from vila_amd import configs, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +45,7 @@ def test_vision_tower_vs_golden_and_oracle(case):
     out = model.vision_tower(px.cuda())
     ref = O.vision_tower_forward(px.float(), w, cfg.vision)
     assert rel_l2(out, ref) < 2e-2, f"vs oracle rel={rel_l2(out, ref):.3e}"
-    assert rel_l2(out, torch.from_numpy(fx["vit_selected"])) < 3e-2, f"vs golden rel={rel_l2(out, torch.from_numpy(fx['vit_selected'])):.3e}"
+    assert rel_l2(out, torch.from_numpy(fx["vit_selected"])) < 2e-2, f"vs golden rel={rel_l2(out, torch.from_numpy(fx['vit_selected'])):.3e}"
 
 
 def test_projector_vs_golden_and_oracle(case):
@@ -55,7 +55,7 @@ def test_projector_vs_golden_and_oracle(case):
     ref = O.projector_forward(feats.float(), w, cfg.mm_projector_type)
     assert out.shape == ref.shape
     assert rel_l2(out, ref) < 2e-2, f"vs oracle rel={rel_l2(out, ref):.3e}"
-    assert rel_l2(out, torch.from_numpy(fx["projector_out"])) < 3e-2
+    assert rel_l2(out, torch.from_numpy(fx["projector_out"])) < 2e-2
 
 
 def test_embed_splice_vs_golden(case):
@@ -132,9 +132,13 @@ def test_vlm_generate_end_to_end(case):
     n = len(fx["greedy_ids"])
     out = model.generate(input_ids=ids, media={"image": [px[0].cuda()]}, max_new_tokens=n, eos_token_id=-1)
     assert out.shape == (1, n)
-    ids_o, _ = O.vlm_generate([px[0].float()], ids[0], w, cfg, n, stop_at_eos=False)
-    # first token must agree whenever it is decisive; report the rest
-    assert out[0, 0].item() == ids_o[0].item() or True
+    ids_o, lg_o = O.vlm_generate([px[0].float()], ids[0], w, cfg, n, stop_at_eos=False)
+    # the whole VLM path (tower -> projector -> splice -> prefill -> decode), teacher-forced with the oracle's ids: bit-exact ids at
+    # every decisive step, and the free-running graph path must follow the oracle up to the first non-decisive step
+    e, _, _ = model._embed(ids, {"image": [px[0].cuda()]})
+    _, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, forced_ids=ids_o, use_graph=False)
+    assert rel_l2(lg, lg_o) < 3e-2, f"end-to-end logits rel={rel_l2(lg, lg_o):.3e}"
+    margin_aware_ids(lg, lg_o, ids_o, free_ids=out[0])
 
 
 def test_forward_loss_padded_batch(case):

@@ -100,3 +100,14 @@ def test_chat_completions_endpoint_schema_and_errors():
     assert r.status_code == 500 and "configured to use the model" in r.json()["error"]
     r = client.post("/chat/completions", json=dict(body, temperature=0.7))
     assert r.status_code == 500 and "greedy" in r.json()["error"]
+
+
+def test_prompt_split_matches_extract_media():
+    """llava/utils/media.py:93-122: one `<image>` per image part and nothing else (the "\\n" is an embedding appended by the encoder);
+    media tokens typed inside a text part are removed and the part stripped."""
+    from vila_amd.serving import _split_prompt
+    img = object()
+    assert _split_prompt(["look: ", img, "what is it?"]) == ("look: <image>what is it?", [img])
+    assert _split_prompt("a literal <image> token") == ("a literal  token", [])
+    text, images = _split_prompt(["<image> describe", img])
+    assert text == "describe<image>" and images == [img]

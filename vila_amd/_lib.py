@@ -75,6 +75,7 @@ PROTOTYPES = {
                                  C.POINTER(VilaKvCache), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "vila_llm_decode_workspace_bytes": (c_size_t, [C.POINTER(VilaLlmShape), c_int]),
+    "vila_llm_decode_launches": (c_int, [C.POINTER(VilaLlmShape), c_int]),
     "vila_llm_decode_step": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeState),
                                      c_void_p, c_size_t, c_void_p]),
     "vila_graph_begin": (c_int, [c_void_p]),

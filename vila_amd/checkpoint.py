@@ -95,6 +95,23 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
         json.dump(top, f, indent=1)
 
 
+def resolve_projector_type(top: dict, model_dir: str = "") -> str:
+    """The reference's LlavaConfig has NO top-level `mm_projector_type`: the type lives in the projector's own config
+    (`MultimodalProjectorConfig.mm_projector_type`, base_projector.py:126-131), reachable as the `mm_projector_cfg` dict of the top
+    config.json or as <dir>/mm_projector/config.json (llava/model/utils/utils.py:25-55).  Our own save_pretrained also writes a
+    top-level copy; it is only the last fallback."""
+    pj = top.get("mm_projector_cfg")
+    if isinstance(pj, dict) and pj.get("mm_projector_type"):
+        return pj["mm_projector_type"]
+    for path in ([pj] if isinstance(pj, str) else []) + ([os.path.join(model_dir, "mm_projector")] if model_dir else []):
+        f = os.path.join(path, "config.json")
+        if os.path.exists(f):
+            t = json.load(open(f)).get("mm_projector_type")
+            if t:
+                return t
+    return top.get("mm_projector_type") or "mlp_downsample"
+
+
 def config_from_pretrained(model_dir: str) -> VilaConfig:
     top = json.load(open(os.path.join(model_dir, "config.json")))
 
@@ -115,7 +132,7 @@ def config_from_pretrained(model_dir: str) -> VilaConfig:
                        num_channels=v.get("num_channels", 3), layer_norm_eps=v.get("layer_norm_eps", 1e-6),
                        select_layer=top.get("mm_vision_select_layer", -2))
     scales = top.get("s2_scales", "448,896,1344")
-    return VilaConfig(vision=vis, llm=llm, mm_projector_type=top.get("mm_projector_type", "mlp_downsample"),
+    return VilaConfig(vision=vis, llm=llm, mm_projector_type=resolve_projector_type(top, model_dir),
                       image_token_id=top.get("image_token_id", 151649), newline_token_id=top.get("newline_token_id", 198),
                       dynamic_s2=bool(top.get("dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
                       s2_resize_output_to_scale_idx=top.get("s2_resize_output_to_scale_idx", -1), name=os.path.basename(model_dir.rstrip("/")))

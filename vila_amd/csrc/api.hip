@@ -285,6 +285,11 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
 // LLM decode step (batch 1, greedy)
 // =================================================================================================
 static inline int dec_splits(int max_ctx) { return cdiv(max_ctx, 64); }
+// kernel launches of one vila_llm_decode_step: prologue + per layer {qkv, attention (1 launch up to 2048 cached positions, else
+// split-KV + merge), o_proj, gate/up, down} + lm_head + argmax x2 + advance
+extern "C" int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx) {
+    return 1 + s->n_layers * (max_ctx <= 2048 ? 5 : 6) + 4;
+}
 extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx) {
     const size_t H = s->hidden, F = s->inter, QS = (size_t)s->q_heads * s->head_dim;
     const size_t ns = dec_splits(max_ctx);

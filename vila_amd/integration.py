@@ -19,7 +19,17 @@ def _get(cfg, name, default=None):
     return cfg.get(name, default) if isinstance(cfg, dict) else getattr(cfg, name, default)
 
 
-def vila_config_from_hf(llm_cfg, vision_cfg, top_cfg=None) -> VilaConfig:
+def projector_type_of(top_cfg=None, projector=None) -> str:
+    """mm_projector_type the way the reference stores it: on the live projector's own config (`vlm.mm_projector.config`,
+    base_projector.py:126-137) or inside LlavaConfig.mm_projector_cfg; a top-level field exists only in configs this repo wrote."""
+    t = _get(getattr(projector, "config", None), "mm_projector_type") if projector is not None else None
+    if not t and top_cfg is not None:
+        t = _get(_get(top_cfg, "mm_projector_cfg"), "mm_projector_type") if _get(top_cfg, "mm_projector_cfg") is not None else None
+        t = t or _get(top_cfg, "mm_projector_type")
+    return t or "mlp_downsample"
+
+
+def vila_config_from_hf(llm_cfg, vision_cfg, top_cfg=None, projector=None) -> VilaConfig:
     """VilaConfig from the HF sub-configs a VILA checkpoint carries (Qwen2Config, SiglipVisionConfig, LlavaConfig)."""
     rope_theta = _get(llm_cfg, "rope_theta")
     if rope_theta is None:                                  # newer transformers keep it inside rope_parameters
@@ -43,8 +53,7 @@ def vila_config_from_hf(llm_cfg, vision_cfg, top_cfg=None) -> VilaConfig:
         for src, dst in (("image_token_id", "image_token_id"), ("newline_token_id", "newline_token_id")):
             if _get(top_cfg, src) is not None:
                 kw[dst] = _get(top_cfg, src)
-    return VilaConfig(vision=vis, llm=llm, mm_projector_type=_get(top_cfg, "mm_projector_type", "mlp_downsample") if top_cfg is not None
-                      else "mlp_downsample", dynamic_s2=bool(_get(top_cfg, "dynamic_s2", False)) if top_cfg is not None else False,
+    return VilaConfig(vision=vis, llm=llm, mm_projector_type=projector_type_of(top_cfg, projector), dynamic_s2=bool(_get(top_cfg, "dynamic_s2", False)) if top_cfg is not None else False,
                       s2_scales=tuple(int(s) for s in scales.split(",")),
                       s2_resize_output_to_scale_idx=_get(top_cfg, "s2_resize_output_to_scale_idx", -1) if top_cfg is not None else -1,
                       name="from-hf", **kw)
@@ -54,7 +63,7 @@ def swap_in_hip_modules(vlm, cfg: Optional[VilaConfig] = None, device=None, stri
     """Replace vlm.llm / vlm.vision_tower / vlm.mm_projector by their HIP counterparts, weights included.  Returns the VilaConfig."""
     from .modules import HipMultimodalProjector, HipQwen2ForCausalLM, HipSiglipVisionTower
     if cfg is None:
-        cfg = vila_config_from_hf(vlm.llm.config, vlm.vision_tower.config, getattr(vlm, "config", None))
+        cfg = vila_config_from_hf(vlm.llm.config, vlm.vision_tower.config, getattr(vlm, "config", None), getattr(vlm, "mm_projector", None))
     for name, cls in (("llm", HipQwen2ForCausalLM), ("vision_tower", HipSiglipVisionTower), ("mm_projector", HipMultimodalProjector)):
         old = getattr(vlm, name)
         dev = device or next(old.parameters()).device

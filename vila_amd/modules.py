@@ -76,6 +76,17 @@ class _HipModule(nn.Module):
         self._cstruct = None
         self._ws = None
 
+    def _invalidate(self) -> None:
+        """Parameter storage moved (.to(), refuse(), FlatParams re-pointing, W4 quantisation): every cached object that baked in
+        a weight pointer is dropped — the ctypes weight struct and, for the LLM, the decode session with its captured hipGraph."""
+        self._cstruct = None
+        st = getattr(self, "_decode", None)
+        if st is not None:
+            if getattr(st, "graph", None) is not None:
+                _lib.load().vila_graph_destroy(st.graph)
+                st.graph = None
+            self._decode = None
+
     def refuse(self) -> None:
         """Re-establish the fused q/k/v storage after an op that re-allocated parameters (.to(), .half(), ...)."""
         for g in self._fused_groups:
@@ -85,13 +96,13 @@ class _HipModule(nn.Module):
             for t in ts:
                 t.data = buf[o:o + t.shape[0]]
                 o += t.shape[0]
-        self._cstruct = None
+        self._invalidate()
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         if getattr(self, "_fused_groups", None):
             self.refuse()
-        self._cstruct = None
+        self._invalidate()
         self._ws = None
         return r
 
@@ -343,26 +354,47 @@ class HipQwen2ForCausalLM(_HipModule):
         else:
             seq_id = torch.repeat_interleave(torch.arange(seqlens.numel(), device=dev), seqlens.long())
             pos = (torch.arange(idx.numel(), device=dev, dtype=torch.int32) - cu[:-1][seq_id]).to(torch.int32)
-        r = self.prefill_packed(packed, pos, cu, int(seqlens.max()), want_all_logits=True)
-        logits = torch.zeros((Bn * S, self.lcfg.vocab_size), device=dev, dtype=torch.float32)
-        logits.index_copy_(0, idx, r.all_logits)
-        logits = logits.view(Bn, S, -1)
+        want_logits = labels is None or bool(kw.get("return_logits", False))
+        r = self.prefill_packed(packed, pos, cu, int(seqlens.max()), want_all_logits=want_logits, want_final_hidden=labels is not None)
+        logits = None
+        if want_logits:
+            logits = torch.zeros((Bn * S, self.lcfg.vocab_size), device=dev, dtype=torch.float32)
+            logits.index_copy_(0, idx, r.all_logits)
+            logits = logits.view(Bn, S, -1)
         loss = None
         if labels is not None:
-            lg = logits[..., :-1, :].reshape(-1, logits.shape[-1])
-            lb = labels[..., 1:].reshape(-1).to(dev)
-            if num_items_in_batch is None:
-                loss = torch.nn.functional.cross_entropy(lg, lb, ignore_index=IGNORE_INDEX, reduction="mean")
+            # HF ForCausalLMLoss: position t predicts labels[t+1] inside each row; only rows WITH a target go through the head:
+            # gather -> [n_valid, V] fp32 logits -> ce_kernel (no [B*S, V] tensor, no torch loss kernels on this path)
+            lb = labels.to(dev)
+            tgt = torch.full((Bn, S), IGNORE_INDEX, dtype=torch.int64, device=dev)
+            tgt[:, :-1] = lb[:, 1:]
+            inv = torch.full((Bn * S,), -1, dtype=torch.int64, device=dev)
+            inv[idx] = torch.arange(idx.numel(), device=dev)
+            tgt = tgt.reshape(-1)
+            ok = (tgt != IGNORE_INDEX) & (inv >= 0)
+            rows = inv[ok].to(torch.int32)
+            n_valid = int(rows.numel())
+            acc = torch.zeros((1,), device=dev, dtype=torch.float32)
+            if n_valid:
+                hv = torch.empty((n_valid, H), device=dev, dtype=self.dtype)
+                ops.copy_rows(r.final_hidden, hv, rows, None, n_valid)
+                head = self.model.embed_tokens.weight if self.lcfg.tie_word_embeddings else self.lm_head.weight
+                lg = ops.gemm(hv, head, out_f32=True)
+                denom = n_valid if num_items_in_batch is None else int(num_items_in_batch)
+                ops.ce_loss(lg, tgt[ok].contiguous(), acc, 1.0 / max(denom, 1))
+                loss = acc[0]
             else:
-                loss = torch.nn.functional.cross_entropy(lg, lb, ignore_index=IGNORE_INDEX, reduction="sum") / num_items_in_batch
+                loss = acc[0] * float("nan") if num_items_in_batch is None else acc[0]     # F.cross_entropy(mean) of no targets is nan
         return CausalLMOutput(loss=loss, logits=logits, past_key_values=None)
 
     # ---- greedy generate ---------------------------------------------------------------------------------------
     def _decode_session(self, cache, max_new_tokens: int):
         """Device-resident decode state + workspace (+ captured hipGraph) reused across generate() calls."""
-        key = (cache.k.data_ptr(), max_new_tokens)
+        key = (cache.k.data_ptr(), max_new_tokens, self.model.embed_tokens.weight.data_ptr(),
+               _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr())
         if self._decode is not None and self._decode.key == key:
             return self._decode
+        self._invalidate()          # another cache / length / weight storage: drop the old session and its graph
         dev = self.device
         lib = _lib.load()
         w = self._struct()
@@ -385,7 +417,7 @@ class HipQwen2ForCausalLM(_HipModule):
         (vila_llm_decode_step_w4); prefill keeps using the bf16 weights."""
         from .quant import W4Weights
         self._w4 = W4Weights(self, keep_logical)
-        self._decode = None
+        self._invalidate()
         return self._w4
 
     def decode_step(self, cache, st) -> None:

@@ -33,7 +33,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual   (nn.Linear semantics; EPI_GATEUP: silu(a w^T) * (a w2^T))."""
     _need(a, name="a"); _need(w, name="w")
     # w may carry extra zero-padded columns (transpose() pads the contraction dim to 64): K is a's width
-    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] <= w.shape[1]
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    if a.shape[1] != w.shape[1] and w.shape[1] != (a.shape[1] + 63) // 64 * 64:
+        raise ValueError(f"gemm: contraction widths differ (a: {a.shape[1]}, w: {w.shape[1]}); only the zero padding of transpose() to a "
+                         "multiple of 64 is accepted")
     M, K = a.shape
     N = w.shape[0]
     if out is None:

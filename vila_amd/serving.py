@@ -52,16 +52,18 @@ def load_image(url: str):
 
 
 def _split_prompt(prompt: Union[str, Sequence[Any]]):
-    """llava/utils/media.py:extract_media: text with one <image> per image part, images in order."""
-    if isinstance(prompt, str):
-        return prompt, []
+    """llava/utils/media.py:93-122 (extract_media): text with exactly one `<image>` per image part (the "\n" after an image is NOT
+    text: BasicImageEncoder appends it as an embedding, encoders/image/basic.py:22-27), images in order; media tokens typed by the
+    user inside a text part are removed and the part stripped (:104-108)."""
     text, images = "", []
-    for part in prompt:
+    for part in ([prompt] if isinstance(prompt, str) else prompt):
         if isinstance(part, str):
+            if IMAGE_TOKEN in part:
+                part = part.replace(IMAGE_TOKEN, "").strip()
             text += part
         else:
             images.append(part)
-            text += IMAGE_TOKEN + "\n"
+            text += IMAGE_TOKEN
     return text, images
 
 

@@ -70,13 +70,32 @@ class FlatParams:
                 view.copy_(p.data)
                 p.data = view
         for mod in (model.llm, model.vision_tower, model.mm_projector):
-            mod._cstruct = None
+            mod._invalidate()       # weight structs AND the LLM's captured decode graph point at the old storage
         self.master = self.m = self.v = None
         if with_optimizer_state:
             self.master = self.params.float()
             self.m = torch.zeros_like(self.master)
             self.v = torch.zeros_like(self.master)
         self.step_count = 0
+
+    def sync_master_from_params(self) -> None:
+        """Call after the bf16 parameters were overwritten behind the trainer's back (checkpoint.load_weights_into / model.load_weights
+        on a live trainer): the fp32 master copy is re-seeded from them, otherwise the next AdamW step would write values derived from
+        the stale master over the loaded weights."""
+        if self.master is not None:
+            self.master.copy_(self.params)
+
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        return {"master": self.master, "exp_avg": self.m, "exp_avg_sq": self.v,
+                "step": torch.tensor([self.step_count], dtype=torch.int64), "numel": torch.tensor([self.numel], dtype=torch.int64)}
+
+    def load_optimizer_state(self, sd: Dict[str, torch.Tensor]) -> None:
+        if int(sd["numel"][0]) != self.numel:
+            raise ValueError(f"optimizer state holds {int(sd['numel'][0])} elements, the model has {self.numel}")
+        with torch.no_grad():
+            self.master.copy_(sd["master"]); self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+            self.params.copy_(self.master)               # bf16 params are the rounding of the master copy
+        self.step_count = int(sd["step"][0])
 
     def grad(self, name: str) -> torch.Tensor:
         o, k, shape = self.index[name]
@@ -118,6 +137,13 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+
+    def describe(self) -> str:
+        w = self.dist.get_world_size(self.group) if self.dist is not None else 1
+        be = self.dist.get_backend(self.group) if self.dist is not None else "none"
+        nb = len(self.log)
+        return (f"{nb} buckets (one per layer, reverse order), SUM all-reduce of flat bf16 grad slices, backend={be}, world={w}"
+                + ("" if w > 1 else " (single rank: no exchange issued)"))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -331,6 +357,9 @@ class SFTTrainer:
         """Forward + backward of the packed batch; gradients land in self.flat.grads (already all-reduced when DP > 1).
         Returns the (local) loss = sum CE / num_items_in_batch as a device scalar."""
         model, cfg, flat = self.model, self.cfg, self.flat
+        if getattr(cfg, "dynamic_s2", False):
+            raise NotImplementedError("SFTTrainer: the dynamic_s2 merge (llava_arch.py:298-390) has no backward here; train with the plain "
+                                      "single-scale tower (cfg.dynamic_s2 = False)")
         dev = model.device
         P, G = flat.param, flat.grad
         flat.grads.zero_()
@@ -348,7 +377,9 @@ class SFTTrainer:
             Tm = 0
         table = P("llm.model.embed_tokens.weight")
         # ---- splice + pack (llava_arch.py:412-490, 744-800) ----
-        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right")
+        # training truncates every sample to tokenizer.model_max_length AFTER media expansion (llava_arch.py:519-526)
+        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right",
+                           max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
         # packed row index of every padded-grid position
@@ -358,12 +389,19 @@ class SFTTrainer:
         x0 = torch.empty((T, H), device=dev, dtype=torch.bfloat16)
         ops.copy_rows(table, x0, plan.txt_src.to(dev), txt_dst, int(txt_dst.numel()))
         if n_img:
-            img_dst = inv[plan.img_dst.long()].view(n_img, Tm + 1).to(torch.int32).to(dev)
-            feat_dst = img_dst[:, :Tm].reshape(-1).contiguous()
-            nl_dst = img_dst[:, Tm].contiguous()
-            ops.copy_rows(proj.reshape(n_img * Tm, H), x0, None, feat_dst, n_img * Tm)
-            nl_src = torch.full((n_img,), cfg.newline_token_id, dtype=torch.int32, device=dev)
-            ops.copy_rows(table, x0, nl_src, nl_dst, n_img)
+            # media row i of the [n_img, Tm + 1] block list: r < Tm -> projector row, r == Tm -> the "\n" end token; rows cut off by the
+            # truncation are absent from plan.img_src / img_dst
+            src = plan.img_src.long()
+            dst_p = inv[plan.img_dst.long()]
+            is_nl = (src % (Tm + 1)) == Tm
+            feat_src = ((src // (Tm + 1)) * Tm + src % (Tm + 1))[~is_nl].to(torch.int32).to(dev)
+            feat_dst = dst_p[~is_nl].to(torch.int32).to(dev)
+            nl_dst = dst_p[is_nl].to(torch.int32).to(dev)
+            n_feat, n_nl = int(feat_dst.numel()), int(nl_dst.numel())
+            ops.copy_rows(proj.reshape(n_img * Tm, H), x0, feat_src, feat_dst, n_feat)
+            nl_src = torch.full((n_nl,), cfg.newline_token_id, dtype=torch.int32, device=dev)
+            if n_nl:
+                ops.copy_rows(table, x0, nl_src, nl_dst, n_nl)
         pos = rp.position_ids.to(dev)
         cu = rp.cu_seqlens.to(dev)
         lab = rp.labels.to(dev)
@@ -398,14 +436,15 @@ class SFTTrainer:
         dtxt = torch.empty((int(txt_dst.numel()), H), device=dev, dtype=torch.bfloat16)
         ops.copy_rows(dx0, dtxt, txt_dst, None, int(txt_dst.numel()))
         ops.scatter_add_rows(dtxt, ge, plan.txt_src.to(dev))
-        if n_img:
-            dnl = torch.empty((n_img, H), device=dev, dtype=torch.bfloat16)
-            ops.copy_rows(dx0, dnl, nl_dst, None, n_img)
+        if n_img and n_nl:
+            dnl = torch.empty((n_nl, H), device=dev, dtype=torch.bfloat16)
+            ops.copy_rows(dx0, dnl, nl_dst, None, n_nl)
             ops.scatter_add_rows(dnl, ge, nl_src)
         self.reducer.ready("llm.model.embed_tokens.")
         if n_img:
-            dproj = torch.empty((n_img * Tm, H), device=dev, dtype=torch.bfloat16)
-            ops.copy_rows(dx0, dproj, feat_dst, None, n_img * Tm)
+            full = n_feat == n_img * Tm
+            dproj = (torch.empty if full else torch.zeros)((n_img * Tm, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
+            ops.copy_rows(dx0, dproj, feat_dst, feat_src, n_feat)
             dfeats = self._proj_bwd(dproj.view(n_img, Tm, H), proj_saved)
             self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
         self.reducer.wait()
@@ -443,6 +482,8 @@ def count_targets(input_ids, labels, attention_mask, image_token_id: int) -> int
     n = 0
     for k in range(input_ids.shape[0]):
         ids_k, lab_k = input_ids[k][mask[k]], labels[k][mask[k]]
+        if ids_k.numel() == 0:                # fully masked row: contributes nothing
+            continue
         keep = (ids_k != image_token_id) & (lab_k != IGNORE_INDEX)
         keep[0] = False                       # first token of a sample is never a target (llava_arch.py:760-762 + HF shift)
         n += int(keep.sum())
