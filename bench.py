@@ -309,11 +309,12 @@ def video_main(a, rank, dev):
     pixels = synthetic.make_pixels(cfg, F_, 0, device=dev, dtype=torch.bfloat16)
     frames = [pixels[i] for i in range(F_)]
     if a.tsp:
-        pool = [[8, 1, 1]]
-        n_media = (F_ + 7) // 8 * (cfg.tokens_per_tile + 1)
+        from vila_amd.vlm import TSPVideoEncoder
+        model.encoders["video"] = TSPVideoEncoder(model, [[8, 1, 1]])      # the hydra target of scripts/NVILA/stage4.sh:50
+        n_media = F_ // 8 * (cfg.tokens_per_tile + 1)
         ids = synthetic.make_prompt(cfg, 32, 1, 0)[None].to(dev)
         ids[0, 0] = cfg.video_token_id
-        media, media_cfg = {"video": [torch.stack(frames, 0)]}, {"video": {"pool_sizes": pool}}
+        media, media_cfg = {"video": [torch.stack(frames, 0)]}, {}
     else:
         n_media = F_ * (cfg.tokens_per_tile + 1)
         ids = synthetic.make_prompt(cfg, 32, F_, 0)[None].to(dev)

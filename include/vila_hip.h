@@ -224,6 +224,17 @@ int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_
 
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Video encoders — replaces `pool` + `_process_features` of TSPVideoEncoder
+ * (llava/model/encoders/video/tsp.py:10-11,28-52) and `_process_features` of BasicVideoEncoder (video/basic.py:30-41):
+ *   feats [n_frames, grid*grid, C] bf16 (projected frames of ONE video) ->
+ *   out   [(n_frames/pool_t) * (n_start + (grid/pool_h)*(grid/pool_w) + n_end), C]: per pooled frame the start-token rows, the mean over
+ *   every (pool_t, pool_h, pool_w) window (fp32 accumulate), the end-token rows.  pool = (1,1,1) is BasicVideoEncoder.
+ *   A ragged split (a pooled dimension not divisible by its pool size) is an error, as the reference's view() raises.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vila_video_pool_bf16(const void* feats, void* out, int n_frames, int grid, int channels, int pool_t, int pool_h, int pool_w,
+                         const void* start_rows, int n_start, const void* end_rows, int n_end, vila_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * W4A16 decode (BASELINE configs[4]).  The reference's W4A16 backend is the external TinyChat
  * (README.md:87), with no code in-tree: the packed format is defined in vila_amd/csrc/gemv_w4.hip and produced by
  * vila_amd/quant.py; parity is against a CPU dequantise-then-fp32 oracle of the same quantised weights.

@@ -166,19 +166,72 @@ def basic_image_encoder(images: Sequence[torch.Tensor], w, cfg) -> List[torch.Te
 
 
 # ----------------------------------------------------------------------------------------------
+# a7 (video): BasicVideoEncoder (llava/model/encoders/video/basic.py:13-53), TSPVideoEncoder (video/tsp.py:10-64)
+# ----------------------------------------------------------------------------------------------
+def pool(x: torch.Tensor, size: int, dim: int) -> torch.Tensor:
+    """tsp.py:10-11."""
+    return x.view(x.shape[:dim] + (-1, size) + x.shape[dim + 1:]).mean(dim + 1)
+
+
+def video_process_features(features: torch.Tensor, start: Optional[torch.Tensor], end: Optional[torch.Tensor]) -> torch.Tensor:
+    """BasicVideoEncoder._process_features (basic.py:30-41): features [n_frames, n_tok, H]; start / end [k, H] token embeddings
+    are put before / after EVERY frame's tokens; frames are then flattened."""
+    if start is not None:
+        features = torch.cat([torch.stack([start] * features.shape[0], 0), features], 1)
+    if end is not None:
+        features = torch.cat([features, torch.stack([end] * features.shape[0], 0)], 1)
+    return features.flatten(0, 1)
+
+
+def tsp_process_features(inputs: torch.Tensor, pool_sizes, start, end, sep=None) -> torch.Tensor:
+    """TSPVideoEncoder._process_features (tsp.py:28-52): for every pool size, mean-pool the [nt, nl, nl, H] grid over dims 0,1,2 in
+    turn, flatten (h, w), add start/end tokens per pooled frame, append the separator; outputs of all pool sizes concatenated."""
+    nt, ns = inputs.shape[:2]
+    nl = int(ns ** 0.5)
+    outputs = []
+    for pool_size in pool_sizes:
+        f = inputs.view(nt, nl, nl, -1)
+        for dim, p in enumerate(pool_size):
+            f = pool(f, p, dim=dim)
+        f = video_process_features(f.flatten(1, 2), start, end)
+        if sep is not None:
+            f = torch.cat([f, sep], 0)
+        outputs.append(f)
+    return torch.cat(outputs, 0)
+
+
+def basic_video_encoder(videos: Sequence[torch.Tensor], w, cfg) -> List[torch.Tensor]:
+    """video/basic.py:43-53: all frames of all videos through encode_images, split per video, tokens assembled per frame."""
+    feats = encode_images(torch.cat(list(videos), 0), w, cfg)
+    end = embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+    return [video_process_features(f, None, end) for f in torch.split(feats, [int(v.shape[0]) for v in videos])]
+
+
+def tsp_video_encoder(videos: Sequence[torch.Tensor], w, cfg, pool_sizes, sep_ids: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+    """video/tsp.py:54-64."""
+    feats = encode_images(torch.cat(list(videos), 0), w, cfg)
+    end = embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+    sep = embed_tokens(torch.tensor(list(sep_ids)), w) if sep_ids else None
+    return [tsp_process_features(f, pool_sizes, None, end, sep) for f in torch.split(feats, [int(v.shape[0]) for v in videos])]
+
+
+# ----------------------------------------------------------------------------------------------
 # a8: LlavaMetaForCausalLM._embed + __batchify_sequence (llava_arch.py:412-490, 528-555)
 # ----------------------------------------------------------------------------------------------
-def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, cfg,
+def embed_splice(input_ids: torch.Tensor, media_embeds, w, cfg,
                  labels: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                  padding_side: str = "right", max_length: Optional[int] = None):
     """Returns (inputs_embeds [B,S,H], labels [B,S] i64, attention_mask [B,S] bool).
+    media_embeds: list of image embedding blocks, or {name: blocks} with names "image" / "video" (one deque per name, each popped
+    when ITS media token is met: llava_arch.py:454-466).
     max_length = `tokenizer.model_max_length` in training mode: `__truncate_sequence` (llava_arch.py:519-526) cuts every sample
     AFTER media expansion, only if some sample is longer."""
     labels = labels if labels is not None else torch.full_like(input_ids, IGNORE_INDEX)
     attention_mask = attention_mask if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
     text = embed_tokens(input_ids, w)
     B = input_ids.shape[0]
-    queue = list(media_embeds)
+    queues = {n: list(v) for n, v in media_embeds.items()} if isinstance(media_embeds, dict) else {"image": list(media_embeds)}
+    media_tokens = {cfg.image_token_id: "image", getattr(cfg, "video_token_id", -1): "video"}       # :454-457
     ins, labs = [], []
     for k in range(B):
         ids_k = input_ids[k][attention_mask[k]]      # :449-450 remove padding
@@ -186,8 +239,8 @@ def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, c
         lb_k = labels[k][attention_mask[k]]
         pi, pl = [], []
         for pos in range(len(ids_k)):                # :459-477 (run-length form of the while loop)
-            if int(ids_k[pos]) == cfg.image_token_id:
-                m = queue.pop(0)
+            if int(ids_k[pos]) in media_tokens:
+                m = queues.get(media_tokens[int(ids_k[pos])], []).pop(0)
                 pi.append(m)
                 pl.append(torch.full((m.shape[0],), IGNORE_INDEX, dtype=lb_k.dtype))
             else:
@@ -195,8 +248,9 @@ def embed_splice(input_ids: torch.Tensor, media_embeds: List[torch.Tensor], w, c
                 pl.append(lb_k[pos:pos + 1])
         ins.append(torch.cat(pi, 0))
         labs.append(torch.cat(pl, 0))
-    if queue:
-        raise ValueError("Not all image embeddings are consumed!")   # :481-484
+    for name, q in queues.items():
+        if q:
+            raise ValueError(f"Not all {name} embeddings are consumed!")   # :481-484
     if max_length is not None and any(x.shape[0] > max_length for x in ins):      # :519-526
         ins = [x[:max_length] for x in ins]
         labs = [x[:max_length] for x in labs]

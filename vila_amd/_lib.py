@@ -121,6 +121,7 @@ PROTOTYPES = {
                                   c_int, c_int, c_int, c_void_p]),
     "vila_llm_decode_step_w4": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),
                                         C.POINTER(VilaDecodeState), c_void_p, c_size_t, c_void_p]),
+    "vila_video_pool_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "vila_s2_merge_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
 }
 

@@ -78,6 +78,7 @@ class VilaConfig:
     # base_projector.py:145-174
     mm_projector_type: str = "mlp_downsample"
     image_token_id: int = 151649     # "<image>" added token (llava/constants.py:39-48)
+    video_token_id: int = 151650     # "<vila/video>" (llava/constants.py:46)
     newline_token_id: int = 198      # tokenizer("\n").input_ids for Qwen2 (encoders/image/basic.py:22-27)
     init_std: float = 0.02
     lm_head_std: float = 0.05
@@ -134,6 +135,7 @@ def tiny(proj: str = "mlp_downsample", layers_v: int = 3, layers_l: int = 2, tie
                       tie_word_embeddings=tied, eos_token_id=999),
         mm_projector_type=proj,
         image_token_id=998,
+        video_token_id=997,
         newline_token_id=11,
         init_std=0.05,
         lm_head_std=0.08,

@@ -34,9 +34,9 @@ inline bf16_t* B(void* p) { return (bf16_t*)p; }
 
 int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const bf16_t* res, int64_t ldr,
          void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0,
-         float* ws = nullptr, size_t ws_bytes = 0) {
+         float* ws = nullptr, size_t ws_bytes = 0, int res_mod = 0) {
     GemmArgs g;
-    g.ws = ws; g.ws_bytes = ws_bytes;
+    g.ws = ws; g.ws_bytes = ws_bytes; g.res_mod = res_mod;
     g.A = A; g.lda = lda; g.W = B(W); g.ldw = ldw; g.W2 = B(W2); g.bias = B(bias); g.residual = res; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.M = M; g.N = N; g.K = K; g.epi = epi;
     return launch_gemm(g, s);
@@ -77,12 +77,12 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
     bf16_t* f = a.take<bf16_t>((size_t)M * F);
     VILA_REQUIRE(a.ok(), "vit: workspace arena overflow");
 
-    // a2: patch embed = im2col + GEMM (+bias) + position embedding as the residual operand, per image
+    // a2: patch embed = im2col + ONE GEMM over all images (+bias) with the position embedding as a periodic residual operand
+    // (row m of the batch reads pos_emb[m % N]): 64 frames are one launch with one tail, not 64
     VILA_TRY(launch_im2col(B(pixels), patches, n_images, sh.channels, sh.image, sh.image, sh.patch, Kp, s));
     VILA_TRY(launch_pad_rows(B(w->patch_w), wpad, D, Kc, Kp, s));
     bf16_t* x0 = (sh.n_layers_run == 0) ? B(out) : x;
-    for (int b = 0; b < n_images; ++b)
-        VILA_TRY(gemm(patches + (size_t)b * N * Kp, Kp, wpad, Kp, w->patch_b, B(w->pos_emb), D, x0 + (size_t)b * N * D, D, N, D, Kp, EPI_NONE, s));
+    VILA_TRY(gemm(patches, Kp, wpad, Kp, w->patch_b, B(w->pos_emb), D, x0, D, M, D, Kp, EPI_NONE, s, nullptr, 0, nullptr, 0, N));
 
     for (int l = 0; l < sh.n_layers_run; ++l) {
         const VilaVitLayer& L = w->layers[l];
@@ -505,6 +505,12 @@ extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* d
     int sp[4] = {1, 1, 1, 1};
     for (int k = 0; k < n_scales - 1 && k < 4; ++k) sp[k] = splits[k];
     return launch_s2_merge(B(feats), B(out), desc, n_blocks, grid, channels, n_scales, sp, S(stream));
+}
+
+// video encoders: BasicVideoEncoder (pool 1,1,1) / TSPVideoEncoder token assembly in one launch
+extern "C" int vila_video_pool_bf16(const void* feats, void* out, int n_frames, int grid, int channels, int pool_t, int pool_h, int pool_w,
+                                    const void* start_rows, int n_start, const void* end_rows, int n_end, vila_stream_t stream) {
+    return launch_video_pool(B(feats), B(out), n_frames, grid, channels, pool_t, pool_h, pool_w, B(start_rows), n_start, B(end_rows), n_end, S(stream));
 }
 
 // =================================================================================================

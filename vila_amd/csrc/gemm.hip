@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16_tn(Gemm
         if (gm < M && gc < N) {
             f32x4 v = *(const f32x4*)(wst + rr * STG + c4);
             if (p.residual != nullptr) {
-                const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
+                const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
                 v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
             }
             if constexpr (OUT_F32) {

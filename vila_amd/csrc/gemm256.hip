@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                     *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
                 } else {
                     if (p.residual != nullptr) {
-                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)gm * p.ldr + gc);
+                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
                         v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
                     }
                     if constexpr (MODE == 1) {
@@ -269,7 +269,7 @@ __global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int spli
 
 // out[m][n] = bf16(sum_s slab[s][m][n] + bias[n] + residual[m][n])
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t slab_stride, const bf16_t* __restrict__ bias,
-                                     const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int M, int N) {
+                                     const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int M, int N, int res_mod) {
     const int n4 = N >> 2;
     const int64_t total = (int64_t)M * n4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -284,7 +284,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
             v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
         }
         if (residual != nullptr) {
-            const u32x2 r = *(const u32x2*)(residual + (int64_t)m * ldr + c);
+            const u32x2 r = *(const u32x2*)(residual + (int64_t)(res_mod > 0 ? m % res_mod : m) * ldr + c);
             v[0] += lo_bf(r[0]); v[1] += hi_bf(r[0]); v[2] += lo_bf(r[1]); v[3] += hi_bf(r[1]);
         }
         u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
@@ -365,7 +365,7 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
-                       (bf16_t*)a.C, a.ldc, a.M, a.N);
+                       (bf16_t*)a.C, a.ldc, a.M, a.N, a.res_mod);
     VILA_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,7 @@ struct GemmArgs {
     const bf16_t* W2 = nullptr;
     const bf16_t* bias = nullptr;
     const bf16_t* residual = nullptr; int64_t ldr = 0;
+    int res_mod = 0;                            // > 0: the residual has res_mod rows and row m reads residual[m % res_mod] (position embeddings of a batch)
     void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
     int M = 0, N = 0, K = 0; int epi = EPI_NONE;
     float* ws = nullptr; size_t ws_bytes = 0;   // optional fp32 workspace: enables split-K for under-filled grids
@@ -38,6 +39,10 @@ int launch_argmax(const float* logits, int V, int64_t* out, float* tmpv, int* tm
 // dynamic_s2 merge (s2.hip): tower output -> projector input, desc = device [n_blocks][6] {tile_base, bh, bw, i, j, single}
 int launch_s2_merge(const bf16_t* feats, bf16_t* out, const int32_t* desc, int n_blocks, int g, int C, int n_scales, const int* splits,
                     hipStream_t s);
+
+// video token assembly (video.hip): temporal / spatial mean pooling + start / end token rows per pooled frame
+int launch_video_pool(const bf16_t* feats, bf16_t* out, int nt, int nl, int C, int pt, int ph, int pw, const bf16_t* start_rows, int n_start,
+                      const bf16_t* end_rows, int n_end, hipStream_t s);
 
 // ---- attention (attn.hip) ----
 struct AttnArgs {

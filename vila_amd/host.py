@@ -16,26 +16,44 @@ from .configs import IGNORE_INDEX
 
 
 def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], labels: Optional[torch.Tensor],
-                media_lens: List[int], image_token_id: int, padding_side: str = "right", max_length: Optional[int] = None) -> SimpleNamespace:
+                media_lens, media_token_ids, padding_side: str = "right", max_length: Optional[int] = None) -> SimpleNamespace:
     """Row maps for `out[B*S, H]`: text rows come from the embedding table (`txt_src` = token ids -> `txt_dst`), media rows
     from the concatenated media embeddings (row `img_src[i]` -> `img_dst[i]`).  Vectorised: no per-token `.item()`.
+    media_lens / media_token_ids: {name: [rows of each embedding block]} / {name: token id} (a plain list + int = {"image": ...});
+    the flat media row space is the blocks of every name concatenated in the dict's order, each name consumed like its deque
+    (`media_embeds[name].popleft()`, llava_arch.py:462-466) in sample-major order of ITS token.
     max_length: training-time `__truncate_sequence` (llava_arch.py:519-526) — every sample is cut to `model_max_length` AFTER media
     expansion (rows beyond it, text or media, are dropped from the maps)."""
+    if not isinstance(media_lens, dict):
+        media_lens, media_token_ids = {"image": list(media_lens)}, {"image": int(media_token_ids)}
     ids = input_ids
     B, L = ids.shape
+    dev = ids.device
     mask = attention_mask.bool() if attention_mask is not None else torch.ones_like(ids, dtype=torch.bool)
     labels = labels if labels is not None else torch.full_like(ids, IGNORE_INDEX)
-    n_img = len(media_lens)
-    is_img = (ids == image_token_id) & mask
-    n_tok_img = int(is_img.sum())
-    if n_tok_img < n_img:
-        raise ValueError("Not all image embeddings are consumed!")                    # llava_arch.py:481-484
-    if n_tok_img > n_img:
-        raise IndexError("pop from an empty deque")                                   # media_embeds[name].popleft() on exhausted media
-    lens_img = torch.tensor(media_lens, dtype=torch.long, device=ids.device)
-    order = torch.cumsum(is_img.reshape(-1).long(), 0).reshape(B, L) - 1              # j-th image, sample-major = deque order
-    one = torch.ones_like(ids)
-    lens = torch.where(is_img, lens_img[order.clamp(min=0)] if n_img else one, one) * mask.long()
+    is_img = torch.zeros_like(mask)
+    lens = torch.ones_like(ids)
+    src0 = torch.zeros_like(ids)
+    base, identity = 0, True
+    for name, tok in media_token_ids.items():
+        blocks = [int(n) for n in media_lens.get(name, [])]
+        is_n = (ids == int(tok)) & mask
+        n_tok = int(is_n.sum())
+        if n_tok < len(blocks):
+            raise ValueError(f"Not all {name} embeddings are consumed!")                  # llava_arch.py:481-484
+        if n_tok > len(blocks):
+            raise IndexError("pop from an empty deque")                                   # media_embeds[name].popleft() on exhausted media
+        if blocks:
+            ln = torch.tensor(blocks, dtype=torch.long, device=dev)
+            pref = torch.cumsum(ln, 0) - ln
+            order = (torch.cumsum(is_n.reshape(-1).long(), 0).reshape(B, L) - 1).clamp(min=0)   # j-th block of this name, sample-major
+            lens = torch.where(is_n, ln[order], lens)
+            src0 = torch.where(is_n, base + pref[order], src0)
+            identity = identity and not bool(is_img.any())          # a second name with blocks: flat order != occurrence order in general
+            is_img = is_img | is_n
+            base += int(ln.sum())
+    lens = lens * mask.long()
+    n_img = int(is_img.sum())
     ends = torch.cumsum(lens, 1)
     starts = ends - lens
     S_k = ends[:, -1]
@@ -44,29 +62,32 @@ def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
         S_k = S_k.clamp(max=cut)
     S = int(S_k.max()) if B > 0 else 0
     right = padding_side == "right"
-    base = torch.arange(B, device=ids.device)[:, None] * S + (0 if right else (S - S_k)[:, None])
-    dst = base + starts
+    row0 = torch.arange(B, device=dev)[:, None] * S + (0 if right else (S - S_k)[:, None])
+    dst = row0 + starts
     is_txt = mask & ~is_img
     if cut is not None:
         is_txt = is_txt & (starts < cut)                                              # a text token occupies one position
     txt_src = ids[is_txt].to(torch.int32)
     txt_dst = dst[is_txt].to(torch.int32)
-    out_labels = torch.full((B * S,), IGNORE_INDEX, dtype=labels.dtype, device=ids.device)
+    out_labels = torch.full((B * S,), IGNORE_INDEX, dtype=labels.dtype, device=dev)
     out_labels[txt_dst.long()] = labels[is_txt]
-    span = torch.arange(S, device=ids.device)[None, :]
+    span = torch.arange(S, device=dev)[None, :]
     out_mask = (span < S_k[:, None]) if right else (span >= (S - S_k)[:, None])
     if n_img:
-        offs = torch.cat([torch.arange(n, device=ids.device) for n in media_lens])
-        img_dst = (torch.repeat_interleave(dst[is_img], lens_img) + offs).to(torch.int32)
-        img_src = torch.arange(int(lens_img.sum()), dtype=torch.int32, device=ids.device)
+        lens_occ = lens[is_img]                                                        # occurrence (row-major) order
+        total = int(lens_occ.sum())
+        offs = torch.arange(total, device=dev) - torch.repeat_interleave(torch.cumsum(lens_occ, 0) - lens_occ, lens_occ)
+        img_dst = (torch.repeat_interleave(dst[is_img], lens_occ) + offs).to(torch.int32)
+        img_src = (torch.repeat_interleave(src0[is_img], lens_occ) + offs).to(torch.int32)
         if cut is not None:                                                            # media rows beyond the cut are dropped
-            keep = (torch.repeat_interleave(starts[is_img], lens_img) + offs) < cut
+            keep = (torch.repeat_interleave(starts[is_img], lens_occ) + offs) < cut
             img_dst, img_src = img_dst[keep], img_src[keep]
+            identity = False
     else:
-        img_dst = torch.zeros(0, dtype=torch.int32, device=ids.device)
-        img_src = torch.zeros(0, dtype=torch.int32, device=ids.device)
+        img_dst = torch.zeros(0, dtype=torch.int32, device=dev)
+        img_src = torch.zeros(0, dtype=torch.int32, device=dev)
     return SimpleNamespace(B=B, S=S, seqlens=S_k, txt_src=txt_src, txt_dst=txt_dst, img_dst=img_dst, img_src=img_src,
-                           truncated=cut is not None, labels=out_labels.view(B, S), mask=out_mask)
+                           img_src_identity=identity, truncated=cut is not None, labels=out_labels.view(B, S), mask=out_mask)
 
 
 def repack(attention_mask: torch.Tensor, labels: torch.Tensor) -> SimpleNamespace:

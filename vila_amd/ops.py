@@ -154,6 +154,29 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, src_row: Optional[torch.Tens
     check(_lib.load().vila_copy_rows(src.data_ptr(), dst.data_ptr(), _p(src_row), _p(dst_row), n, src.shape[-1], _stream()), "copy_rows")
 
 
+def video_pool(feats: torch.Tensor, pool, start_rows: Optional[torch.Tensor] = None, end_rows: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feats [nt, nl*nl, C] (one video's projected frames) -> [(nt/pt) * (n_start + (nl/ph)(nl/pw) + n_end), C]: TSPVideoEncoder's
+    pool + _process_features (video/tsp.py:10-11,28-52); pool (1,1,1) = BasicVideoEncoder (video/basic.py:30-41)."""
+    _need(feats, name="feats")
+    nt, ns, Cc = feats.shape
+    nl = int(round(ns ** 0.5))
+    assert nl * nl == ns
+    pt, ph, pw = (int(p) for p in pool)
+    n_s = 0 if start_rows is None else start_rows.shape[0]
+    n_e = 0 if end_rows is None else end_rows.shape[0]
+    if pt <= 0 or ph <= 0 or pw <= 0 or nt % pt or nl % ph or nl % pw:
+        raise ValueError(f"shape '[{nt}, {nl}, {nl}]' is invalid for pooling by ({pt}, {ph}, {pw}): every pooled dimension must divide evenly")
+    rows = (nt // pt) * (n_s + (nl // ph) * (nl // pw) + n_e)
+    if out is None:
+        out = torch.empty((rows, Cc), device=feats.device, dtype=feats.dtype)
+    assert out.shape == (rows, Cc) and out.is_contiguous()
+    check(_lib.load().vila_video_pool_bf16(feats.contiguous().data_ptr(), out.data_ptr(), nt, nl, Cc, pt, ph, pw,
+                                           _p(start_rows.contiguous() if start_rows is not None else None), n_s,
+                                           _p(end_rows.contiguous() if end_rows is not None else None), n_e, _stream()), "video_pool")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # SFT-step operators (backward + optimizer)
 # ----------------------------------------------------------------------------------------------------------------------

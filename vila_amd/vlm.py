@@ -48,12 +48,63 @@ class BasicImageEncoder(nn.Module):
         return out
 
 
+class BasicVideoEncoder(nn.Module):
+    """encoders/video/basic.py:13-53: every video [n_frames, 3, H, W] -> encode_images on all frames of all videos at once -> per frame
+    [start tokens | frame tokens | end tokens], flattened.  The assembly is one `vila_video_pool_bf16` launch per video (pool 1,1,1)."""
+
+    pool_sizes = ((1, 1, 1),)
+    sep_tokens: Optional[str] = None
+
+    def __init__(self, parent: "HipLlavaLlamaModel", start_tokens: Optional[str] = None, end_tokens: Optional[str] = "\n"):
+        super().__init__()
+        object.__setattr__(self, "_parent", parent)
+        self.start_tokens, self.end_tokens = start_tokens, end_tokens
+
+    @property
+    def parent(self):
+        return self._parent
+
+    def embed_tokens(self, tokens: Optional[str]) -> Optional[torch.Tensor]:
+        if tokens is None:
+            return None
+        ids = self.parent.tokenizer(tokens).input_ids
+        return self.parent.llm.embed_tokens(torch.tensor(ids, device=self.parent.device))
+
+    def _process_features(self, feats: torch.Tensor, start, end, sep) -> torch.Tensor:
+        """feats [nt, ns, H] of one video -> token block (tsp.py:28-52 / basic.py:30-41)."""
+        feats = feats.to(self.parent.dtype)
+        outs = []
+        for pool in self.pool_sizes:
+            outs.append(ops.video_pool(feats, pool, start, end))
+            if sep is not None:
+                outs.append(sep)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def forward(self, videos: List[torch.Tensor], config: Dict[str, Any]) -> List[torch.Tensor]:
+        num_frames = [int(v.shape[0]) for v in videos]
+        images = torch.cat(list(videos), dim=0)
+        feats = self.parent.encode_images(images)
+        start, end, sep = self.embed_tokens(self.start_tokens), self.embed_tokens(self.end_tokens), self.embed_tokens(self.sep_tokens)
+        return [self._process_features(f, start, end, sep) for f in torch.split(feats, num_frames)]
+
+
+class TSPVideoEncoder(BasicVideoEncoder):
+    """encoders/video/tsp.py:14-64: mean-pool the projected frames over (t, h, w) windows for every entry of `pool_sizes`
+    (NVILA-Video: [[8, 1, 1]], scripts/NVILA/stage4.sh:50), then the start/end tokens per pooled frame and an optional separator."""
+
+    def __init__(self, parent: "HipLlavaLlamaModel", pool_sizes, start_tokens: Optional[str] = None, end_tokens: Optional[str] = "\n",
+                 sep_tokens: Optional[str] = None):
+        super().__init__(parent, start_tokens=start_tokens, end_tokens=end_tokens)
+        self.pool_sizes = tuple(tuple(int(x) for x in p) for p in pool_sizes)
+        self.sep_tokens = sep_tokens
+
+
 class _SyntheticTokenizer:
     """Stands in for the HF tokenizer the reference attaches (`self.tokenizer`): only what the hot path touches —
     `media_token_ids`, `tokenizer("\\n").input_ids`, `padding_side`, `model_max_length`."""
 
     def __init__(self, cfg: VilaConfig, model_max_length: int = 8192):
-        self.media_token_ids = {"image": cfg.image_token_id}
+        self.media_token_ids = {"image": cfg.image_token_id, "video": cfg.video_token_id}
         self.padding_side = "right"
         self.model_max_length = model_max_length
         self.eos_token_id = cfg.llm.eos_token_id
@@ -76,7 +127,8 @@ class HipLlavaLlamaModel(nn.Module):
         self.vision_tower = HipSiglipVisionTower(cfg, device, dtype)
         self.mm_projector = HipMultimodalProjector(cfg, device, dtype)
         self.tokenizer = tokenizer if tokenizer is not None else _SyntheticTokenizer(cfg)
-        self.encoders = {"image": BasicImageEncoder(self)}
+        # configuration_llava.py:67-68: image_encoder / video_encoder hydra targets; the defaults are the two Basic encoders
+        self.encoders = {"image": BasicImageEncoder(self), "video": BasicVideoEncoder(self)}
         self.training = False
 
     @property
@@ -137,24 +189,28 @@ class HipLlavaLlamaModel(nn.Module):
         ids_h = input_ids.cpu()
         labels_h = labels.cpu() if labels is not None else torch.full_like(ids_h, IGNORE_INDEX)
         mask_h = attention_mask.cpu().bool() if attention_mask is not None else torch.ones_like(ids_h, dtype=torch.bool)
-        images = list(media.get("image", [])) if media else []
-        media_embeds = self.encoders["image"](images, media_config.get("image", {})) if images else []
-        n_img = len(media_embeds)
-        img_id = self.tokenizer.media_token_ids["image"]
+        # __embed_media_tokens (llava_arch.py:492-517): one deque of embedding blocks per media name, in the caller's dict order
+        embeds: Dict[str, List[torch.Tensor]] = {}
+        for name in (media or {}):
+            items = list(media[name])
+            if items:
+                embeds[name] = list(self.encoders[name](items, media_config.get(name, {})))
+        tok_ids = dict(self.tokenizer.media_token_ids)
         B, L = ids_h.shape
         H = self.cfg.llm.hidden_size
 
         # ---- integer work on the ids; no per-token sync: vila_amd.host.splice_plan ----
-        plan = splice_plan(ids_h, mask_h, labels_h, [int(m.shape[0]) for m in media_embeds], img_id,
+        plan = splice_plan(ids_h, mask_h, labels_h, {n: [int(m.shape[0]) for m in embeds.get(n, [])] for n in tok_ids}, tok_ids,
                            getattr(self.tokenizer, "padding_side", "right"),
                            max_length=max_length)                                      # __truncate_sequence, llava_arch.py:519-526
         S = plan.S
         out = torch.zeros((B * S, H), device=dev, dtype=self.dtype)
         table = self.llm.model.embed_tokens.weight
         ops.copy_rows(table, out, plan.txt_src.to(dev), plan.txt_dst.to(dev), int(plan.txt_src.numel()))
-        if n_img:
-            flat = torch.cat(media_embeds, 0).to(self.dtype)
-            ops.copy_rows(flat, out, plan.img_src.to(dev) if plan.truncated else None, plan.img_dst.to(dev), int(plan.img_dst.numel()))
+        blocks = [m for n in tok_ids for m in embeds.get(n, [])]
+        if blocks:
+            flat = (blocks[0] if len(blocks) == 1 else torch.cat(blocks, 0)).to(self.dtype)
+            ops.copy_rows(flat, out, None if plan.img_src_identity else plan.img_src.to(dev), plan.img_dst.to(dev), int(plan.img_dst.numel()))
         return out.view(B, S, H), plan.labels.to(dev), plan.mask.to(dev)
 
     # llava_llama.py:94-159 (inference/eval form: loss without autograd; SFT fwd+bwd lives in vila_amd.train)
@@ -177,9 +233,10 @@ class HipLlavaLlamaModel(nn.Module):
 
 
 def build_model(cfg: VilaConfig, weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, device="cuda",
-                dtype=torch.bfloat16) -> HipLlavaLlamaModel:
+                dtype=torch.bfloat16, draw_device=None) -> HipLlavaLlamaModel:
     """Construct the VLM and fill it with `weights` (reference state_dict names) or seeded synthetic weights drawn
-    directly on `device` (no checkpoints exist offline)."""
+    directly on `device` (no checkpoints exist offline).  draw_device="cpu" draws every tensor with the CPU generator (one tensor
+    at a time, so 8 B parameters never sit in host RAM at once): the values a CPU-side oracle run can reproduce."""
     from . import synthetic
     m = HipLlavaLlamaModel(cfg, device, dtype)
     if weights is not None:
@@ -190,5 +247,5 @@ def build_model(cfg: VilaConfig, weights: Optional[Dict[str, torch.Tensor]] = No
                                        (m.mm_projector, "mm_projector.", synthetic.projector_specs(cfg))):
                 params = dict(mod.named_parameters())
                 for name, shape, kind in specs:
-                    params[name[len(prefix):]].copy_(synthetic._draw(name, shape, kind, cfg, seed, device))
+                    params[name[len(prefix):]].copy_(synthetic._draw(name, shape, kind, cfg, seed, draw_device or device))
     return m
