@@ -160,6 +160,17 @@ int vila_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
 int vila_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const void* W2, const void* bias,
                       const void* residual, int64_t ldr, void* C, int64_t ldc, int out_f32, int M, int N, int K, int epi,
                       void* ws, size_t ws_bytes, vila_stream_t stream);
+/* Backward GEMMs on the forward tensors AS THEY LIE (replaces the transposed operand copies autograd's mm backward / cuBLAS NT-TN
+ * variants stand for): C[M,N] = A.B^T (+bias)(+residual), bf16 out.  a_cm / b_cm = 1: that operand is stored contraction-major,
+ * X[K][rows] with rows contiguous (lda / ldw = its stored leading dimension), instead of [rows][K]:
+ *   dgrad  dX[T,K] = dY[T,N] . W[N,K]     : A = dY (a_cm 0), B = W   (b_cm 1, ldw = K),  contraction N
+ *   wgrad  dW[N,K] = dY[T,N]^T . X[T,K]   : A = dY (a_cm 1, lda = N), B = X (b_cm 1, ldw = K), contraction T (any T; zero-filled tail)
+ * A contraction-major operand needs rows %% 8 == 0.  ws (nullable): fp32 workspace enabling split-K on under-filled grids. */
+int vila_gemm_bf16_t(const void* A, int64_t lda, int a_cm, const void* W, int64_t ldw, int b_cm, const void* bias,
+                     const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, void* ws, size_t ws_bytes,
+                     vila_stream_t stream);
+/* tuning hook for the 256x256 kernel's DMA schedule (gemm256_kernel.h SCHED): 0 default, 1 / 2 deep-prefetch variants, 9 ablation */
+void vila_gemm_force_sched(int sched);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */
 void vila_gemm_force_tile(int tile);
 int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream);

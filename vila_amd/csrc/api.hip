@@ -397,6 +397,17 @@ extern "C" int vila_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int6
                                  void* ws, size_t ws_bytes, vila_stream_t stream) {
     return gemm(B(A), lda, W, ldw, bias, B(residual), ldr, C, ldc, M, N, K, epi, S(stream), W2, out_f32, (float*)ws, ws_bytes);
 }
+// C[M,N] = A . B^T (+bias)(+residual) with either operand stored contraction-major: dgrad (b_cm: B = W[K][N] as it lies) and wgrad
+// (a_cm, b_cm: A = dY[K=tokens][M], B = X[K=tokens][N]) read the forward tensors in place, no transposed copies
+extern "C" int vila_gemm_bf16_t(const void* A, int64_t lda, int a_cm, const void* W, int64_t ldw, int b_cm, const void* bias,
+                                const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, void* ws, size_t ws_bytes,
+                                vila_stream_t stream) {
+    GemmArgs g;
+    g.A = B(A); g.lda = lda; g.a_cm = a_cm ? 1 : 0; g.W = B(W); g.ldw = ldw; g.b_cm = b_cm ? 1 : 0; g.bias = B(bias);
+    g.residual = B(residual); g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE;
+    g.ws = (float*)ws; g.ws_bytes = ws_bytes;
+    return launch_gemm(g, S(stream));
+}
 extern "C" int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream) {
     return launch_layernorm(B(x), B(w), B(b), B(y), rows, cols, eps, S(stream));
 }

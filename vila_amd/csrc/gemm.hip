@@ -263,8 +263,30 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     return launch_cfg<EPI, OUT_F32, 2, 4>(a, s);
 }
 
+// dgrad / wgrad on the tensors as they lie (contraction-major operands, gemm256_kernel.h): always the 256x256 kernel, sliced over K
+// when its tiles cannot fill the chip and the caller lent a workspace
+static int launch_gemm_cm(const GemmArgs& a, hipStream_t s) {
+    VILA_REQUIRE(a.epi == EPI_NONE && !a.out_f32 && a.W2 == nullptr, "gemm: contraction-major operands take the plain bf16 epilogue only");
+    VILA_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) && a.lda % 8 == 0 && a.ldw % 8 == 0 &&
+                 a.ldc % 4 == 0 && a.N % 4 == 0, "gemm: pointers / leading dims must keep 16-B row alignment");
+    VILA_REQUIRE(a.residual == nullptr || (a.ldr % 4 == 0 && (uintptr_t)a.residual % 8 == 0), "gemm: residual alignment");
+    VILA_REQUIRE(gemm256_supported(a), "gemm: contraction-major operand needs rows %% 8 == 0, K >= 128 (M=%d N=%d K=%d a_cm=%d b_cm=%d)",
+                 a.M, a.N, a.K, a.a_cm, a.b_cm);
+    const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+    if (a.ws != nullptr && tiles256 < 150) {
+        const int kt = cdiv(a.K, 64);
+        int splits = (int)(256 / tiles256);
+        if (splits > 8) splits = 8;
+        while (splits >= 2 && (cdiv(kt, splits) < 8 || (size_t)splits * a.M * a.N * 4 > a.ws_bytes)) --splits;
+        if (splits >= 2) splits = cdiv(kt, cdiv(kt, splits));
+        if (splits >= 2) return launch_gemm256_splitk(a, splits, a.ws, s);
+    }
+    return launch_gemm256(a, s);
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.a_cm || a.b_cm) return launch_gemm_cm(a, s);
     VILA_REQUIRE(a.K % 8 == 0 && a.N % 4 == 0, "gemm: K (%d) must be a multiple of 8 and N (%d) of 4", a.K, a.N);
     VILA_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 4 == 0, "gemm: leading dims must keep 16-B row alignment");
     VILA_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0), "gemm: pointers must be 16-B aligned");

@@ -20,232 +20,9 @@
 // memory (LDS-DMA cannot predicate a lane's LDS write, but it can read a different address).  M / N tails by row clamping +
 // masked stores.  (Skipping the MFMAs of half-tiles beyond M was measured and does not pay: with one tile of prefetch the DMA
 // round trip of a K-tile costs as much as its 64 MFMAs, so an "empty" tile is not cheaper than a full one.)
-#include "kernels.h"
-
-#define T256_BK 64
-#define T256_STG 68
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
+#include "gemm256_kernel.h"
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised)
-
-// MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
-//       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)
-// tile0 = first tile id of this launch (a GEMM may be issued as "full rounds" + "split tail"), col0 = first output column of the slab
-template <int MODE, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
-    constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
-    constexpr bool GU = (MODE == 2 || MODE == 4);
-    constexpr bool SPLIT = (MODE == 3 || MODE == 4);
-    constexpr int BN_OUT = GU ? 128 : 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int id = xcd_remap(blockIdx.x, gridDim.x) + tile0;
-    const int tm = id % tiles_m, tn = id / tiles_m;
-    const int m0 = tm * 256, n0 = tn * BN_OUT;
-    const int M = p.M, N = p.N;
-
-    // ---- DMA source offsets: thread's chunk c = tid + 512*i of a half-tile: row = c >> 3, LDS slot = c & 7 ----
-    const int srow = tid >> 3;                         // + 64 i
-    const int kch = (tid & 7) ^ ((srow >> 1) & 7);     // global k-chunk that lands in this lane's LDS slot
-    uint32_t aoff[2][2], boff[2][2];                   // [half][round] element offsets of the row starts
-    bool b_up[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int gm = m0 + h * 128 + srow + 64 * i; gm = gm < M ? gm : M - 1;
-            aoff[h][i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
-            const int rb = h * 128 + srow + 64 * i;    // row of the 256-row B tile; wave column = rb >> 6
-            int gn;
-            if (GU) { gn = n0 + (rb >> 6) * 32 + (rb & 31); b_up[h][i] = (rb & 32) != 0; }
-            else { gn = n0 + rb; b_up[h][i] = false; }
-            gn = gn < N ? gn : N - 1;
-            boff[h][i] = (uint32_t)gn * (uint32_t)p.ldw + kch * 8;
-        }
-    const int lds_lane_base = __builtin_amdgcn_readfirstlane(wave * 1024);   // wave-uniform: 64 lanes x 16 B per DMA
-    const int kt0 = SPLIT ? blockIdx.y * k_tiles_per_split : 0;
-    auto issue_tile = [&](int t, int buf) {
-        const int k0 = (kt0 + t) * T256_BK;
-        char* base = smem + buf * BUF_BYTES + lds_lane_base;
-        if (k0 + T256_BK <= p.K) {                          // block-uniform: every K-tile but a ragged last one
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(p.A + aoff[h][i] + k0), (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
-                    const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc + boff[h][i] + k0), (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
-                }
-        } else {
-            const bool kin = k0 + kch * 8 < p.K;            // this lane's 16-B chunk is inside K
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bf16_t* asrc = kin ? p.A + aoff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
-                    __builtin_amdgcn_global_load_lds((gbl_void*)asrc, (lds_void*)(base + h * HALF_BYTES + i * 8192), 16, 0, 0);
-                    const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
-                    wsrc = kin ? wsrc + boff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
-                    __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, (lds_void*)(base + (2 + h) * HALF_BYTES + i * 8192), 16, 0, 0);
-                }
-        }
-    };
-
-    // ---- fragment read offsets (bytes inside a half-tile) ----
-    const int swr = (l15 >> 1) & 7;
-    int foff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * 128 + (((ks * 4 + lg) ^ swr) << 4);
-    const int a_half = wr, b_half = wc >> 1, b_row0 = (wc & 1) * 64;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int kt_all = (p.K + T256_BK - 1) / T256_BK;
-    const int nt = SPLIT ? ((kt_all - kt0) < k_tiles_per_split ? (kt_all - kt0) : k_tiles_per_split) : kt_all;   // last slice may be shorter
-    issue_tile(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own DMA of tile t has landed
-        __builtin_amdgcn_s_barrier();                               // everyone's has; everyone left tile t-1
-        asm volatile("" ::: "memory");                              // keep the LDS reads of tile t below the barrier
-        if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
-        const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
-        const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES + b_row0 * 128;
-        bf16x8 af[4][2], bf0[2][2], bf1[2][2];
-        // phase 0: B cols 0..31, A rows 0..63 -> quadrant (0,0)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf0[j][ks], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // phase 1: B cols 32..63 -> quadrant (0,1)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = *(const bf16x8*)(cB + (32 + j * 16) * 128 + foff[ks]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf1[j][ks], acc[i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // phase 2: A rows 64..127 -> quadrant (1,1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + (64 + i * 16) * 128 + foff[ks]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf1[j][ks], acc[4 + i][2 + j], 0, 0, 0);
-        // phase 3: quadrant (1,0) from registers
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf0[j][ks], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    }
-    __syncthreads();   // all LDS reads of the last tile done before the staging area is reused
-
-    // ---- epilogue: 4 passes of 32 rows through per-wave fp32 staging; coalesced stores ----
-    float* wst = (float*)smem + wave * 32 * T256_STG;
-    constexpr int WN_OUT = GU ? 32 : 64;
-    constexpr int NJ = GU ? 2 : 4;
-    const int ncol0 = n0 + wc * WN_OUT;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 2 && MODE != 3 && MODE != 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = ncol0 + j * 16 + l15;
-            bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
-        }
-    }
-    constexpr int LPR = WN_OUT / 4, RPI = 64 / LPR;
-    const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
-    // MODE 3: one fp32 slab per K-slice; MODE 4: two planes (gate, up) per K-slice, ldc = columns of the tail region
-    float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc
-                : (MODE == 4) ? (float*)p.C + (int64_t)blockIdx.y * 2 * M * p.ldc : nullptr;
-    constexpr int PASSES = (MODE == 4) ? 2 : 1;
-#pragma unroll
-    for (int pl = 0; pl < PASSES; ++pl) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v;
-                    if (MODE == 4) {
-                        v = acc[2 * q + ii][j + 2 * pl][r];
-                    } else if (GU) {
-                        v = silu_f(acc[2 * q + ii][j][r]) * acc[2 * q + ii][j + 2][r];
-                    } else {
-                        v = acc[2 * q + ii][j][r] + bv[j];
-                        if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
-                        if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
-                    }
-                    wst[(ii * 16 + lg * 4 + r) * T256_STG + j * 16 + l15] = v;
-                }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rr = it * RPI + rr0;
-            const int gm = m0 + wr * 128 + q * 32 + rr, gc = ncol0 + c4;
-            if (gm < M && gc < N) {
-                f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
-                if (MODE == 3) {
-                    *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
-                } else if (MODE == 4) {
-                    *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
-                } else {
-                    if (p.residual != nullptr) {
-                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
-                        v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
-                    }
-                    if constexpr (MODE == 1) {
-                        *(f32x4*)((float*)p.C + (int64_t)gm * p.ldc + gc) = v;
-                    } else {
-                        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-                        *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-    }
-    }
-}
 
 // tail round of a gate/up GEMM: out[m][col0 + c] = bf16(silu(sum_s gate_s[m][c]) * sum_s up_s[m][c]); slab = [splits][2][M][tc] fp32
 __global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int splits, bf16_t* __restrict__ out, int64_t ldc, int M, int tc, int col0) {
@@ -292,27 +69,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
-// tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
-template <int MODE, int EPI>
-static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
-    const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
-    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, bn);
-    if (n_tiles < 0) n_tiles = tiles_m * tiles_n;
-    const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
-    static bool attr_set = false;
-    if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    const int kt = cdiv(a.K, T256_BK);
-    if (per <= 0) per = kt / splits;
-    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
-    VILA_LAUNCH_CHECK();
-    return 0;
-}
+int g_gemm256_sched = 0;      // tuning hook (vila_gemm_force_sched): 0 = default schedule of each layout, 1 / 2 / 9 = gemm256_kernel.h SCHED
+extern "C" void vila_gemm_force_sched(int sched) { g_gemm256_sched = sched; }
+int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       // gemm256_cm.hip
+int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
+int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s);
 
 bool gemm256_supported(const GemmArgs& a) {
-    return a.K % 8 == 0 && a.K >= 2 * T256_BK && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31);
+    if (a.a_cm && (a.M % 8 != 0 || a.lda % 8 != 0)) return false;
+    if (a.b_cm && (a.N % 8 != 0 || a.ldw % 8 != 0)) return false;
+    const int64_t ea = a.a_cm ? (int64_t)64 * a.lda + a.M : (int64_t)a.M * a.lda;      // largest 32-bit element offset the DMA lanes form
+    const int64_t eb = a.b_cm ? (int64_t)64 * a.ldw + a.N : (int64_t)a.N * a.ldw;
+    // a CC operand is read in 16-B chunks along K (K % 8 == 0); a CM operand in whole k-rows (any K)
+    if ((!a.a_cm || !a.b_cm) && a.K % 8 != 0) return false;
+    return a.K >= 2 * T256_BK && ea < (1ll << 31) && eb < (1ll << 31);
 }
 
 // Gate/up with an under-filled LAST round (S = 769: 592 tiles = 2 full rounds of 256 + 80): the full rounds run fused as usual, the
@@ -344,6 +114,8 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
+    if (a.a_cm || a.b_cm) return launch_gemm256_cm(a, s);
+    if (g_gemm256_sched != 0 && a.epi == EPI_NONE && !a.out_f32) return launch_gemm256_sched(a, g_gemm256_sched, s);
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
     if (a.out_f32) return launch256_t<1, EPI_NONE>(a, s);
     switch (a.epi) {
@@ -361,7 +133,8 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
                  "gemm256 split-K: %d K tiles cannot be cut into %d non-empty slices", kt, splits);
     GemmArgs b = a;
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
-    VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
+    if (a.a_cm || a.b_cm) VILA_TRY(launch_gemm256_cm_splitk(b, splits, slab, per, s));
+    else VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,

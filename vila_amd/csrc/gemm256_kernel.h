@@ -1,0 +1,344 @@
+// 256x256x64 bf16 MFMA GEMM kernel template (see gemm256.hip for the design notes); shared by gemm256.hip (forward layouts) and
+// gemm256_cm.hip (contraction-major operands for dgrad / wgrad, schedule variants).
+//
+// Operand storage:
+//   CC ("contraction-contiguous", the forward layout): X[rows][K], K contiguous  — nn.Linear weights [out,in] and activations [tok,ch]
+//   CM ("contraction-major"):                          X[K][rows], rows contiguous — what dgrad / wgrad meet when they consume the SAME
+//       tensors in place: dX = dY . W reads W[N,K] with the contraction over its ROW index; dW = dY^T . X reads dY[T,N] and X[T,K]
+//       with the contraction over the token index.  No transposed copies are made: the LDS image of a CM half-tile is [64 k][128 rows]
+//       and the MFMA fragments (8 consecutive k per lane) come out of `ds_read_b64_tr_b16` (two reads per fragment), the same hardware
+//       transpose the attention kernels use for V.
+//   LDS images are lane-linear for the LDS-DMA; bank conflicts are removed by permuting the per-lane SOURCE address and applying the
+//   same involution on the reads (guide rule 21): CC: 16-B slot ^= (row>>1)&7;  CM: 32-B pair ^= (k&3) | ((k>>3)&1)<<2, which puts the
+//   eight k-rows a 32-lane tr-read cycle touches on eight different 32-B bank groups.
+//
+// SCHED (how the 8 LDS-DMA instructions per thread and K-tile are issued):
+//   0  one tile ahead: top of tile t {vmcnt(0); barrier; issue all of tile t+1}                                  (round-1 kernel)
+//   1  two tiles ahead, refill-after-use: top of tile t {vmcnt(8); barrier}; a barrier in front of phases 1,2,3; the pieces of tile
+//      t+2 are issued into the buffer tile t is being read from as soon as every wave has finished with them
+//      (phase 1: A rows 0-63 of both halves; phase 2: both B halves; phase 3: A rows 64-127).  The wait never drains the queue.
+//   2  as 1 but one extra barrier only (before phase 3) and all 8 pieces of tile t+2 issued there
+//   9  ablation: schedule 0 without any DMA inside the loop (wrong results; bounds what hiding the loads completely would buy)
+#pragma once
+#include "kernels.h"
+
+#define T256_BK 64
+#define T256_STG 68
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
+
+extern __device__ unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised), defined in gemm256.hip
+
+// MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
+//       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)
+// tile0 = first tile id of this launch (a GEMM may be issued as "full rounds" + "split tail"), col0 = first output column of the slab
+template <int MODE, int EPI, bool ACM, bool BCM, int SCHED>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
+    constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
+    constexpr bool GU = (MODE == 2 || MODE == 4);
+    constexpr bool SPLIT = (MODE == 3 || MODE == 4);
+    constexpr int BN_OUT = GU ? 128 : 256;
+    static_assert(!(GU && (ACM || BCM)), "gate/up fusion only for the forward layouts");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int id = xcd_remap(blockIdx.x, gridDim.x) + tile0;
+    const int tm = id % tiles_m, tn = id / tiles_m;
+    const int m0 = tm * 256, n0 = tn * BN_OUT;
+    const int M = p.M, N = p.N;
+
+    // ---- DMA source offsets ----
+    // CC: thread's chunk c = tid + 512*i of a half-tile: row = c >> 3 (+64 i), LDS slot = c & 7 holds global k-chunk (c&7) ^ ((row>>1)&7)
+    // CM: chunk c = tid + 512*i: k = c >> 4 (+32 i), LDS slot s = c & 15 holds the 8 rows of global chunk (((s>>1) ^ g(k)) << 1) | (s&1)
+    uint32_t aoff[2][2], boff[2][2];                   // [half][round] element offsets (CC: row start + k chunk; CM: k row + row chunk)
+    bool b_up[2][2];
+    const int srow = tid >> 3;
+    const int kch = (tid & 7) ^ ((srow >> 1) & 7);
+    const int cm_k = tid >> 4;                         // + 32 i
+    const int cm_g = (cm_k & 3) | (((cm_k >> 3) & 1) << 2);       // invariant under k += 32
+    const int cm_ch = ((((tid & 15) >> 1) ^ cm_g) << 1) | (tid & 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (ACM) {
+                int gm = m0 + h * 128 + cm_ch * 8; gm = gm + 8 <= M ? gm : (M >= 8 ? M - 8 : 0);      // rows beyond M: any valid rows (masked at the store)
+                aoff[h][i] = (uint32_t)(cm_k + 32 * i) * (uint32_t)p.lda + gm;
+            } else {
+                int gm = m0 + h * 128 + srow + 64 * i; gm = gm < M ? gm : M - 1;
+                aoff[h][i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
+            }
+            b_up[h][i] = false;
+            if constexpr (BCM) {
+                int gn = n0 + h * 128 + cm_ch * 8; gn = gn + 8 <= N ? gn : (N >= 8 ? N - 8 : 0);
+                boff[h][i] = (uint32_t)(cm_k + 32 * i) * (uint32_t)p.ldw + gn;
+            } else {
+                const int rb = h * 128 + srow + 64 * i;    // row of the 256-row B tile; wave column = rb >> 6
+                int gn;
+                if (GU) { gn = n0 + (rb >> 6) * 32 + (rb & 31); b_up[h][i] = (rb & 32) != 0; }
+                else { gn = n0 + rb; }
+                gn = gn < N ? gn : N - 1;
+                boff[h][i] = (uint32_t)gn * (uint32_t)p.ldw + kch * 8;
+            }
+        }
+    const int lds_lane_base = __builtin_amdgcn_readfirstlane(wave * 1024);   // wave-uniform: 64 lanes x 16 B per DMA
+    const int kt0 = SPLIT ? blockIdx.y * k_tiles_per_split : 0;
+
+    // one piece = one LDS-DMA per thread (8 KB): which in {A, B}, half h, round i
+    auto issue_piece = [&](int t, int buf, bool is_b, int h, int i) {
+        const int k0 = (kt0 + t) * T256_BK;
+        char* dst = smem + buf * BUF_BYTES + lds_lane_base + ((is_b ? 2 : 0) + h) * HALF_BYTES + i * 8192;
+        const bf16_t* src;
+        if (!is_b) {
+            if constexpr (ACM) {
+                const bool kin = k0 + cm_k + 32 * i < p.K;
+                src = kin ? p.A + aoff[h][i] + (int64_t)k0 * p.lda : (const bf16_t*)g_zero_chunk;
+            } else {
+                const bool kin = k0 + kch * 8 < p.K;
+                src = kin ? p.A + aoff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
+            }
+        } else {
+            if constexpr (BCM) {
+                const bool kin = k0 + cm_k + 32 * i < p.K;
+                src = kin ? p.W + boff[h][i] + (int64_t)k0 * p.ldw : (const bf16_t*)g_zero_chunk;
+            } else {
+                const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
+                const bool kin = k0 + kch * 8 < p.K;
+                src = kin ? wsrc + boff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
+            }
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+    };
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { issue_piece(t, buf, false, h, i); issue_piece(t, buf, true, h, i); }
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile) ----
+    const int swr = (l15 >> 1) & 7;
+    int foff[2];                                       // CC: row l15 of a 16-row fragment, k-step ks
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * 128 + (((ks * 4 + lg) ^ swr) << 4);
+    // CM: k row = ks*32 + lg*8 + (l15>>2) (+4 for the second read), 32-B pair P ^ g with g = (l15>>2) | (lg&1)<<2, 8-B column (l15&3)
+    const int cm_rg = (l15 >> 2) | ((lg & 1) << 2);
+    const int cm_base = (lg * 8 + (l15 >> 2)) * 256 + (l15 & 3) * 8;
+    const int a_half = wr, b_half = wc >> 1, b_row0 = (wc & 1) * 64;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment f (16 rows at row16 = f) of a half-tile at `base`, k-step ks
+    auto frag_cc = [&](const char* base, int row0, int ks) -> bf16x8 { return *(const bf16x8*)(base + row0 * 128 + foff[ks]); };
+    auto frag_cm = [&](const char* base, int row0, int ks) -> bf16x8 {
+        const char* q = base + cm_base + ks * 32 * 256 + ((((row0 >> 4) ^ cm_rg) & 7) << 5);
+        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+        const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 256));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto fragA = [&](const char* base, int row0, int ks) -> bf16x8 { if constexpr (ACM) return frag_cm(base, row0, ks); else return frag_cc(base, row0, ks); };
+    auto fragB = [&](const char* base, int row0, int ks) -> bf16x8 { if constexpr (BCM) return frag_cm(base, row0, ks); else return frag_cc(base, row0, ks); };
+
+    const int kt_all = (p.K + T256_BK - 1) / T256_BK;
+    const int nt = SPLIT ? ((kt_all - kt0) < k_tiles_per_split ? (kt_all - kt0) : k_tiles_per_split) : kt_all;   // last slice may be shorter
+    constexpr bool DEEP = (SCHED == 1 || SCHED == 2);
+    issue_tile(0, 0);
+    if (DEEP && nt > 1) issue_tile(1, 1);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (DEEP) {
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile t landed; tile t+1's 8 pieces may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own DMA of tile t has landed
+        }
+        __builtin_amdgcn_s_barrier();                               // everyone's has; everyone left tile t-1
+        asm volatile("" ::: "memory");                              // keep the LDS reads of tile t below the barrier
+        if (SCHED == 0 && t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+        const bool more = DEEP && (t + 2 < nt);
+        const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
+        const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES;
+        // CC half-tiles are [128 rows][64 k]: the wave's B rows start at b_row0; CM half-tiles are [64 k][128 rows]: row index = column
+        bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+        // phase 0: B cols 0..31, A rows 0..63 -> quadrant (0,0)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = fragB(cB, b_row0 + j * 16, ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, i * 16, ks);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf0[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // phase 1: B cols 32..63 -> quadrant (0,1)
+        if (SCHED == 1 && !ACM) {                                   // (a CM image of A is cut along k, not rows: nothing is free yet)
+            __builtin_amdgcn_s_barrier();                           // every wave has read A rows 0-63: refill them for tile t+2
+            asm volatile("" ::: "memory");
+            if (more) { issue_piece(t + 2, buf, false, 0, 0); issue_piece(t + 2, buf, false, 1, 0); }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = fragB(cB, b_row0 + 32 + j * 16, ks);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf1[j][ks], acc[i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // phase 2: A rows 64..127 -> quadrant (1,1)
+        if (SCHED == 1) {
+            __builtin_amdgcn_s_barrier();                           // both B halves are in registers everywhere: refill them
+            asm volatile("" ::: "memory");
+            if (more) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) issue_piece(t + 2, buf, true, h, i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, 64 + i * 16, ks);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf1[j][ks], acc[4 + i][2 + j], 0, 0, 0);
+        // phase 3: quadrant (1,0) from registers
+        if (DEEP) {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();                           // the whole buffer has been consumed
+            asm volatile("" ::: "memory");
+            if (more) {
+                if (SCHED == 1) {
+                    issue_piece(t + 2, buf, false, 0, 1); issue_piece(t + 2, buf, false, 1, 1);
+                    if (ACM) { issue_piece(t + 2, buf, false, 0, 0); issue_piece(t + 2, buf, false, 1, 0); }
+                } else {
+                    issue_tile(t + 2, buf);
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf0[j][ks], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // all LDS reads of the last tile done before the staging area is reused
+
+    // ---- epilogue: 4 passes of 32 rows through per-wave fp32 staging; coalesced stores ----
+    float* wst = (float*)smem + wave * 32 * T256_STG;
+    constexpr int WN_OUT = GU ? 32 : 64;
+    constexpr int NJ = GU ? 2 : 4;
+    const int ncol0 = n0 + wc * WN_OUT;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 2 && MODE != 3 && MODE != 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = ncol0 + j * 16 + l15;
+            bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
+        }
+    }
+    constexpr int LPR = WN_OUT / 4, RPI = 64 / LPR;
+    const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
+    // MODE 3: one fp32 slab per K-slice; MODE 4: two planes (gate, up) per K-slice, ldc = columns of the tail region
+    float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc
+                : (MODE == 4) ? (float*)p.C + (int64_t)blockIdx.y * 2 * M * p.ldc : nullptr;
+    constexpr int PASSES = (MODE == 4) ? 2 : 1;
+#pragma unroll
+    for (int pl = 0; pl < PASSES; ++pl) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v;
+                    if (MODE == 4) {
+                        v = acc[2 * q + ii][j + 2 * pl][r];
+                    } else if (GU) {
+                        v = silu_f(acc[2 * q + ii][j][r]) * acc[2 * q + ii][j + 2][r];
+                    } else {
+                        v = acc[2 * q + ii][j][r] + bv[j];
+                        if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
+                        if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                    }
+                    wst[(ii * 16 + lg * 4 + r) * T256_STG + j * 16 + l15] = v;
+                }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + rr0;
+            const int gm = m0 + wr * 128 + q * 32 + rr, gc = ncol0 + c4;
+            if (gm < M && gc < N) {
+                f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
+                if (MODE == 3) {
+                    *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
+                } else if (MODE == 4) {
+                    *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
+                } else {
+                    if (p.residual != nullptr) {
+                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
+                        v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+                    }
+                    if constexpr (MODE == 1) {
+                        *(f32x4*)((float*)p.C + (int64_t)gm * p.ldc + gc) = v;
+                    } else {
+                        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+                        *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    }
+}
+
+// tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
+template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0>
+static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
+    const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
+    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, bn);
+    if (n_tiles < 0) n_tiles = tiles_m * tiles_n;
+    const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
+    static bool attr_set = false;
+    if (!attr_set) {
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int kt = cdiv(a.K, T256_BK);
+    if (per <= 0) per = kt / splits;
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}

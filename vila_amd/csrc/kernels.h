@@ -16,6 +16,9 @@ struct GemmArgs {
     void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
     int M = 0, N = 0, K = 0; int epi = EPI_NONE;
     float* ws = nullptr; size_t ws_bytes = 0;   // optional fp32 workspace: enables split-K for under-filled grids
+    // operand storage (gemm256_kernel.h): 0 = contraction-contiguous X[rows][K] (forward layout), 1 = contraction-major X[K][rows]
+    // (dgrad reads W[N,K] with b_cm; wgrad reads dY[T,N] and X[T,K] with a_cm and b_cm); lda / ldw are the STORED leading dimensions
+    int a_cm = 0, b_cm = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 

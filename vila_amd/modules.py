@@ -296,8 +296,9 @@ class HipQwen2ForCausalLM(_HipModule):
     def new_cache(self, max_ctx: int, n_slots: int = 1):
         c = self.lcfg
         shape = (c.num_hidden_layers, n_slots, c.num_key_value_heads, max_ctx, c.head_dim)
-        k = torch.zeros(shape, device=self.device, dtype=self.dtype)
-        v = torch.zeros(shape, device=self.device, dtype=self.dtype)
+        with torch.inference_mode(False):        # caches are reused across calls (generate() keeps `_own_cache`)
+            k = torch.zeros(shape, device=self.device, dtype=self.dtype)
+            v = torch.zeros(shape, device=self.device, dtype=self.dtype)
         cs = _lib.VilaKvCache(k.data_ptr(), v.data_ptr(), max_ctx, n_slots)
         return SimpleNamespace(k=k, v=v, c=cs, max_ctx=max_ctx, n_slots=n_slots)
 
@@ -399,14 +400,17 @@ class HipQwen2ForCausalLM(_HipModule):
         lib = _lib.load()
         w = self._struct()
         st = SimpleNamespace(key=key, cache=cache)
-        st.pos = torch.zeros(1, device=dev, dtype=torch.int32)
-        st.token = torch.zeros(1, device=dev, dtype=torch.int64)
-        st.out_ids = torch.zeros(max(max_new_tokens, 1), device=dev, dtype=torch.int64)
-        st.n_out = torch.zeros(1, device=dev, dtype=torch.int32)
-        st.logits = torch.zeros(self.lcfg.vocab_size, device=dev, dtype=torch.float32)
+        # the session outlives the call that creates it: built outside inference mode even when the first generate() runs under
+        # torch.inference_mode() (llava_arch.py:823), or a later no_grad caller could not update `pos` / `token` in place
+        with torch.inference_mode(False):
+            st.pos = torch.zeros(1, device=dev, dtype=torch.int32)
+            st.token = torch.zeros(1, device=dev, dtype=torch.int64)
+            st.out_ids = torch.zeros(max(max_new_tokens, 1), device=dev, dtype=torch.int64)
+            st.n_out = torch.zeros(1, device=dev, dtype=torch.int32)
+            st.logits = torch.zeros(self.lcfg.vocab_size, device=dev, dtype=torch.float32)
+            st.ws = torch.empty((lib.vila_llm_decode_workspace_bytes(C.byref(w.shape), cache.max_ctx),), device=dev, dtype=torch.uint8)
         st.c = _lib.VilaDecodeState(st.pos.data_ptr(), st.token.data_ptr(), st.out_ids.data_ptr(), st.n_out.data_ptr(),
                                     max(max_new_tokens, 1), st.logits.data_ptr())
-        st.ws = torch.empty((lib.vila_llm_decode_workspace_bytes(C.byref(w.shape), cache.max_ctx),), device=dev, dtype=torch.uint8)
         st.graph = None
         st.stream = torch.cuda.Stream(device=dev)
         self._decode = st

@@ -55,6 +55,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_t(a: torch.Tensor, w: torch.Tensor, a_cm: bool = False, b_cm: bool = False, bias: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = A . B^T (+bias)(+residual) with operands read as they lie: a_cm -> `a` is stored [K, M], b_cm -> `w` is stored [K, N]
+    (vila_gemm_bf16_t).  dgrad: gemm_t(dy, W, b_cm=True);  wgrad: gemm_t(dy, x, a_cm=True, b_cm=True)."""
+    _need(a, name="a"); _need(w, name="w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if a_cm else a.shape
+    N, Kw = (w.shape[1], w.shape[0]) if b_cm else w.shape
+    if K != Kw:
+        raise ValueError(f"gemm_t: contraction widths differ ({K} vs {Kw})")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    if residual is not None:
+        _need(residual, name="residual"); assert residual.shape == (M, N) and residual.stride(1) == 1
+    check(_lib.load().vila_gemm_bf16_t(a.data_ptr(), a.stride(0), int(a_cm), w.data_ptr(), w.stride(0), int(b_cm), _p(bias), _p(residual),
+                                       residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K,
+                                       _p(ws), ws.numel() * ws.element_size() if ws is not None else 0, _stream()), "vila_gemm_bf16_t")
+    return out
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
     _need(x, name="x")
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
