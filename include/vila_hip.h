@@ -220,6 +220,10 @@ int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
 /* torch.optim.AdamW semantics on flat buffers: fp32 master/m/v, bf16 grad in (times grad_scale), bf16 param out */
 int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);
+/* the same update from a kernel that allocates <= 32 VGPRs per lane, so that it can be co-resident with a 256x256 GEMM block on a side
+ * stream (per-bucket optimizer overlapped with the backward of the layers below); results identical to vila_adamw_step */
+int vila_adamw_step_lean(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);
 int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
 
 

@@ -292,3 +292,50 @@ def test_embed_and_copy_rows(ops):
     ops.copy_rows(table, dst, src_row, dst_row, 3)
     assert torch.equal(dst[9], table[5]) and torch.equal(dst[0], table[6]) and torch.equal(dst[4], table[900])
     assert float(dst[1].float().abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward GEMMs on the forward tensors as they lie (contraction-major operands, vila_gemm_bf16_t)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,N,K", [(3076, 3584, 3584), (1538, 4608, 3584), (1000, 1032, 1496), (777, 520, 1032), (128, 128, 128), (3076, 18944, 3584)])
+def test_gemm_t_dgrad_and_wgrad_match_fp32(ops, T, N, K):
+    """dX = dY . W (W read as [contraction N][K]) and dW = dY^T . X (both read as [contraction T][rows]) against fp32 matmuls of the
+    same bf16 tensors — no transposed copies anywhere.  Covers M / N tails of the 256x256 tiles, ragged contraction lengths (T = 777,
+    3076: zero-filled k-rows) and the residual epilogue.  Tolerance: rel-L2 <= 4e-3 (one bf16 rounding of the output)."""
+    x = randn_bf16(T, K, seed=11)
+    w = randn_bf16(N, K, seed=12, scale=K ** -0.5)
+    dy = randn_bf16(T, N, seed=13)
+    res = randn_bf16(T, K, seed=14)
+    dx = ops.gemm_t(dy, w, b_cm=True)
+    ref_dx = dy.float() @ w.float()
+    assert rel_l2(dx, ref_dx) < 4e-3, f"dgrad rel={rel_l2(dx, ref_dx):.3e}"
+    dx = ops.gemm_t(dy, w, b_cm=True, residual=res)
+    assert rel_l2(dx, ref_dx + res.float()) < 4e-3
+    dw = torch.full((N, K), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_t(dy, x, a_cm=True, b_cm=True, out=dw)
+    ref_dw = dy.float().t() @ x.float()
+    assert rel_l2(dw, ref_dw) < 4e-3, f"wgrad rel={rel_l2(dw, ref_dw):.3e}"
+    # transpose-detecting: a swapped layout flag cannot pass on a non-symmetric problem (shape check or values)
+    if N != K:
+        with pytest.raises(ValueError):
+            ops.gemm_t(dy, w, b_cm=False)
+
+
+def test_gemm_t_splitk_and_a_cm_only(ops):
+    """Under-filled grids with a workspace are sliced over K (the lm_head dgrad: 1024 x 3584 outputs, contraction 152064 ... here 19008);
+    the a_cm-only combination (A^T . W^T with W in the forward layout) is covered as well."""
+    ws = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    dy = randn_bf16(520, 19008, seed=21, scale=0.1)
+    w = randn_bf16(19008, 1032, seed=22)
+    out = ops.gemm_t(dy, w, b_cm=True, ws=ws)
+    assert rel_l2(out, dy.float() @ w.float()) < 4e-3
+    a = randn_bf16(2048, 520, seed=23)            # stored [K=2048][M=520]
+    b = randn_bf16(264, 2048, seed=24, scale=2048 ** -0.5)
+    out = ops.gemm_t(a, b, a_cm=True)
+    assert rel_l2(out, a.float().t() @ b.float().t()) < 4e-3
+
+
+def test_gemm_t_rejects_what_the_kernel_cannot_read(ops):
+    dy, w = randn_bf16(256, 260, seed=1), randn_bf16(260, 516, seed=2)      # contraction-major rows must be a multiple of 8 (516 is not)
+    with pytest.raises(ValueError):
+        ops.gemm_t(dy, w, b_cm=True)

@@ -1,0 +1,120 @@
+// Standalone GEMM micro-benchmark + spot-check for libvila_hip.so (no PyTorch: a gpurun call with it costs seconds, not minutes).
+//   build:  hipcc -O2 -std=c++17 tools/gemm_bench.cpp -o tools/gemm_bench -Lvila_amd/lib -lvila_hip -Wl,-rpath,'$ORIGIN/../vila_amd/lib'
+//   run:    tools/gemm_bench [fwd|bwd|all]
+// For every shape and DMA schedule (vila_gemm_force_sched): HIP-event timing on the null stream (random uniform [-1,1) bf16 data —
+// the guide's rule 25: never quote zero-filled operands), TFLOP/s, and the max error of 384 sampled outputs against a double-precision
+// dot product on the host, relative to sqrt(K) (the scale of the sum).  Layout flags: a_cm / b_cm = operand stored [K][rows].
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../include/vila_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint32_t rnd32() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 32); }
+static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Mat { std::vector<uint16_t> h; uint16_t* d = nullptr; int64_t rows, cols; };
+static Mat make(int64_t rows, int64_t cols, float scale) {
+    Mat m; m.rows = rows; m.cols = cols; m.h.resize((size_t)rows * cols);
+    for (auto& x : m.h) x = f2bf(((float)(rnd32() >> 8) / 8388608.0f - 1.0f) * scale);
+    CK(hipMalloc(&m.d, m.h.size() * 2));
+    CK(hipMemcpy(m.d, m.h.data(), m.h.size() * 2, hipMemcpyHostToDevice));
+    return m;
+}
+
+struct Case { const char* name; int M, N, K, a_cm, b_cm, residual; };
+
+static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, size_t ws_bytes) {
+    const float sc = 1.0f;
+    // stored shapes: CC [rows][K]; CM [K][rows]
+    Mat A = c.a_cm ? make(c.K, c.M, sc) : make(c.M, c.K, sc);
+    Mat W = c.b_cm ? make(c.K, c.N, sc) : make(c.N, c.K, sc);
+    Mat R = make(c.residual ? c.M : 1, c.residual ? c.N : 8, sc);
+    uint16_t* C; CK(hipMalloc(&C, (size_t)c.M * c.N * 2));
+    std::vector<uint16_t> hc((size_t)c.M * c.N);
+    const int64_t lda = c.a_cm ? c.M : c.K, ldw = c.b_cm ? c.N : c.K;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int sched : scheds) {
+        if (sched == 9 && (c.a_cm || c.b_cm)) continue;
+        vila_gemm_force_sched(sched);
+        auto call = [&]() {
+            int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, W.d, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
+            if (rc != 0) { fprintf(stderr, "  %s sched %d: rc=%d %s\n", c.name, sched, rc, vila_last_error()); exit(3); }
+        };
+        if (!c.a_cm && !c.b_cm) vila_gemm_force_tile(4);          // forward layout: pin the 256x256 kernel so the schedules are comparable
+        CK(hipMemset(C, 0xff, (size_t)c.M * c.N * 2));
+        for (int i = 0; i < 3; ++i) call();
+        CK(hipDeviceSynchronize());
+        const int iters = 20;
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) call();
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters, tf = 2.0 * c.M * c.N * c.K / (us * 1e-6) / 1e12;
+        double worst = 0.0;
+        if (sched != 9) {
+            CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+            for (int s = 0; s < 384; ++s) {
+                int m = rnd32() % c.M, n = rnd32() % c.N;
+                if (s < 8) { m = (s & 1) ? c.M - 1 : 0; n = (s & 2) ? c.N - 1 : 0; }             // corners: row / column tails
+                if (s >= 8 && s < 16) { m = c.M - 1 - (rnd32() % 8); n = c.N - 1 - (rnd32() % 8); }
+                double acc = 0.0;
+                for (int k = 0; k < c.K; ++k) {
+                    const float a = c.a_cm ? bf2f(A.h[(size_t)k * c.M + m]) : bf2f(A.h[(size_t)m * c.K + k]);
+                    const float b = c.b_cm ? bf2f(W.h[(size_t)k * c.N + n]) : bf2f(W.h[(size_t)n * c.K + k]);
+                    acc += (double)a * b;
+                }
+                if (c.residual) acc += bf2f(R.h[(size_t)m * c.N + n]);
+                const double got = bf2f(hc[(size_t)m * c.N + n]);
+                const double err = fabs(got - acc) / (sqrt((double)c.K) * sc * sc * 0.33 + fabs(acc));
+                if (err > worst) worst = err;
+            }
+        }
+        printf("%-34s M=%6d N=%6d K=%6d cm=%d%d res=%d sched=%d : %9.1f us %8.1f TF/s   err %.2e %s\n", c.name, c.M, c.N, c.K, c.a_cm, c.b_cm,
+               c.residual, sched, us, tf, worst, (sched != 9 && worst > 8e-3) ? "  <-- MISMATCH" : "");
+        fflush(stdout);
+    }
+    vila_gemm_force_tile(0);
+    vila_gemm_force_sched(0);
+    CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "all";
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("%s, %d CUs\n", prop.name, prop.multiProcessorCount);
+    void* ws = nullptr; const size_t ws_bytes = (size_t)512 << 20; CK(hipMalloc(&ws, ws_bytes));
+    const int T = 3076;
+    std::vector<Case> fwd = {
+        {"fwd qkv (SFT)", T, 4608, 3584, 0, 0, 0}, {"fwd o_proj+res (SFT)", T, 3584, 3584, 0, 0, 1}, {"fwd gate (SFT)", T, 18944, 3584, 0, 0, 0},
+        {"fwd down+res (SFT)", T, 3584, 18944, 0, 0, 1}, {"square 4096", 4096, 4096, 4096, 0, 0, 0}, {"square 8192", 8192, 8192, 8192, 0, 0, 0},
+        {"lm_head rows (SFT)", 1024, 152064, 3584, 0, 0, 0},
+    };
+    std::vector<Case> bwd = {
+        {"dgrad qkv   dX=dY.W", T, 3584, 4608, 0, 1, 0}, {"dgrad o     dX=dY.W", T, 3584, 3584, 0, 1, 0}, {"dgrad gate  dX=dY.W", T, 3584, 18944, 0, 1, 0},
+        {"dgrad up +res", T, 3584, 18944, 0, 1, 1}, {"dgrad down  dX=dY.W", T, 18944, 3584, 0, 1, 0},
+        {"wgrad qkv   dW=dY^T.X", 4608, 3584, T, 1, 1, 0}, {"wgrad o     dW=dY^T.X", 3584, 3584, T, 1, 1, 0}, {"wgrad gate  dW=dY^T.X", 18944, 3584, T, 1, 1, 0},
+        {"wgrad down  dW=dY^T.X", 3584, 18944, T, 1, 1, 0}, {"wgrad lm_head", 152064, 3584, 1024, 1, 1, 0}, {"dgrad lm_head (split-K)", 1024, 3584, 152064, 0, 1, 0},
+        {"a_cm only (coverage)", 4096, 4096, 4096, 1, 0, 0}, {"ViT dgrad fc2 (split-K)", 4096, 4304, 1152, 0, 1, 0}, {"ViT wgrad fc1 (split-K)", 4304, 1152, 4096, 1, 1, 0},
+        {"ragged: M tail, K tail", 1000, 1032, 1496, 0, 1, 0}, {"ragged wgrad", 1032, 520, 777, 1, 1, 1},
+    };
+    std::vector<Case> lay = {
+        {"layouts 4096^3 cc", 4096, 4096, 4096, 0, 0, 0}, {"layouts 4096^3 a_cm", 4096, 4096, 4096, 1, 0, 0}, {"layouts 4096^3 b_cm", 4096, 4096, 4096, 0, 1, 0},
+        {"layouts 4096^3 both", 4096, 4096, 4096, 1, 1, 0},
+        {"wgrad gate as a_cm + X^T", 18944, 3584, 3136, 1, 0, 0}, {"wgrad gate both cm", 18944, 3584, 3076, 1, 1, 0}, {"wgrad gate cc (old path)", 18944, 3584, 3136, 0, 0, 0},
+        {"dgrad gate b_cm", 3076, 3584, 18944, 0, 1, 0}, {"dgrad gate cc (old path)", 3076, 3584, 18944, 0, 0, 0},
+        {"dgrad down b_cm", 3076, 18944, 3584, 0, 1, 0}, {"dgrad down cc (old path)", 3076, 18944, 3584, 0, 0, 0},
+    };
+    if (!strcmp(what, "lay")) for (auto& c : lay) run_case(c, {0, 1}, ws, ws_bytes);
+    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 1, 2, 9}, ws, ws_bytes);
+    if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 1}, ws, ws_bytes);     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
+    return 0;
+}

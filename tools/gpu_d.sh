@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 300 python -m pytest tests/test_gpu_train.py -m gpu -q -k "adamw" 2>&1 | tail -3
+for cfg in "0 0 1 1" "0 0 1 0" "0 0 0 0" "1 1 1 1" "0 0 1 1"; do
+  set -- $cfg
+  VILA_SFT_CM=$1 VILA_SFT_SIDE=$2 VILA_SFT_OPT_STREAM=$3 VILA_SFT_LEAN_ADAMW=$4 timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cm side opt lean = $cfg ->', d['ms_per_step'], 'ms  loss', d['loss'])"
+done 2>&1 | tee gpurun_out/r2d_sft_variants.log

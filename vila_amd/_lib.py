@@ -119,6 +119,8 @@ PROTOTYPES = {
                                    c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
+    "vila_adamw_step_lean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                                     c_float, c_void_p]),
     "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "vila_gemv_w4_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_void_p]),

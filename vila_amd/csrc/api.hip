@@ -508,6 +508,11 @@ extern "C" int vila_adamw_step(float* master, float* m, float* v, const void* gr
                                float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream) {
     return launch_adamw(master, m, v, B(grad), B(param), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
 }
+// same update, <= 32 VGPRs per lane: meant for a side stream, co-resident with the matrix kernels (see adamw_lean_kernel)
+extern "C" int vila_adamw_step_lean(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream) {
+    return launch_adamw_lean(master, m, v, B(grad), B(param), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
+}
 extern "C" int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream) { return launch_sumsq(B(x), n, out, S(stream)); }
 
 // dynamic_s2: merge_chessboard + area interpolation + concat + split_chessboard in one gather

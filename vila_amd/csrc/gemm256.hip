@@ -22,7 +22,6 @@
 // round trip of a K-tile costs as much as its 64 MFMAs, so an "empty" tile is not cheaper than a full one.)
 #include "gemm256_kernel.h"
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised)
 
 // tail round of a gate/up GEMM: out[m][col0 + c] = bf16(silu(sum_s gate_s[m][c]) * sum_s up_s[m][c]); slab = [splits][2][M][tc] fp32
 __global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int splits, bf16_t* __restrict__ out, int64_t ldc, int M, int tc, int col0) {

@@ -1,16 +1,23 @@
 // Instantiations of the 256x256 kernel for contraction-major operands (dgrad / wgrad without transposed copies) and for the DMA
 // schedule variants (gemm256_kernel.h SCHED), kept in their own translation unit so the two files compile in parallel.
+//
+// Measured on MI355X (tools/gemm_bench, uniform [-1,1) operands, profiles/r02_gemm_bench_cm_sched.log), TF/s for SCHED 0 / 1 / 2:
+//   forward layout  T=3076: qkv 880 / 834 / 856, gate 878 / 864 / 902, down+res 764 / 744 / 727; 4096^3 986 / 979 / 991; 8192^3 1048 / 1055 / 1052
+//                   -> the deeper DMA pipelines change nothing there (kept behind vila_gemm_force_sched for A/B runs); SCHED 9 (no DMA
+//                      in the loop at all) reaches 1130-1490: the loads cost 28-42 %, but as issue/LDS-write contention, not as latency
+//   dgrad (b_cm)    qkv 646 / 629 / 711, o 630 / 604 / 704, gate 653 / 625 / 739, down 790 / 781 / 861
+//   wgrad (a_cm+b_cm) qkv 804 / 820 / 910, o 673 / 680 / 753, gate 722 / 707 / 808, down 747 / 733 / 814
+//                   -> contraction-major sources touch 64 different rows per K-tile (longer, more variable DMA latency): the
+//                      two-tiles-ahead schedule with ONE extra barrier (SCHED 2) is worth +9-13 %; it is the default for these layouts
 #include "gemm256_kernel.h"
 
 extern int g_gemm256_sched;
 
 template <bool ACM, bool BCM>
 static int launch_cm_t(const GemmArgs& a, int sched, hipStream_t s) {
-    switch (sched) {
-        case 1: return launch256_t<0, EPI_NONE, ACM, BCM, 1>(a, s);
-        case 2: return launch256_t<0, EPI_NONE, ACM, BCM, 2>(a, s);
-        default: return launch256_t<0, EPI_NONE, ACM, BCM, 0>(a, s);
-    }
+    // vila_gemm_force_sched: 0 (default) and 2 = SCHED 2; 1 = the one-tile-ahead schedule (SCHED 0) for A/B runs
+    if (sched == 1) return launch256_t<0, EPI_NONE, ACM, BCM, 0>(a, s);
+    return launch256_t<0, EPI_NONE, ACM, BCM, 2>(a, s);
 }
 
 // bf16 out (+ bias / residual), no activation: dX = dY . W (b_cm) and dW = dY^T . X (a_cm, b_cm)
@@ -23,9 +30,9 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s) {
 
 int launch_gemm256_cm_splitk(const GemmArgs& b, int splits, float* slab, int per, hipStream_t s) {
     (void)slab;
-    if (b.a_cm && b.b_cm) return launch256_t<3, EPI_NONE, true, true, 0>(b, s, splits, 0, -1, 0, per);
-    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 0>(b, s, splits, 0, -1, 0, per);
-    return launch256_t<3, EPI_NONE, true, false, 0>(b, s, splits, 0, -1, 0, per);
+    if (b.a_cm && b.b_cm) return launch256_t<3, EPI_NONE, true, true, 2>(b, s, splits, 0, -1, 0, per);
+    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 2>(b, s, splits, 0, -1, 0, per);
+    return launch256_t<3, EPI_NONE, true, false, 2>(b, s, splits, 0, -1, 0, per);
 }
 
 // forward layout with another DMA schedule (tuning / A-B measurement through vila_gemm_force_sched)

@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
-extern __device__ unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised), defined in gemm256.hip
+static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised); one per translation unit (no RDC)
 
 // MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
 //       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)

@@ -29,4 +29,6 @@ int launch_depth_to_space(const bf16_t* dy, bf16_t* dx, int B, int g, int C, int
 int launch_rope_bwd(bf16_t* dqkv, const float* cs, const float* sn, int S, int nq, int nkv, int hd, hipStream_t s);
 int launch_adamw(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, int step, float grad_scale, hipStream_t s);
+int launch_adamw_lean(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
+                      float wd, int step, float grad_scale, hipStream_t s);
 int launch_sumsq(const bf16_t* x, int64_t n, float* out, hipStream_t s);

@@ -633,6 +633,63 @@ int launch_adamw(float* master, float* m, float* v, const bf16_t* grad, bf16_t* 
     VILA_LAUNCH_CHECK();
     return 0;
 }
+// "Lean" AdamW for the optimizer stream of the SFT step: 2 parameters per lane, every array addressed through a buffer descriptor (base
+// in SGPRs, ONE 32-bit VGPR offset) -> 29 VGPRs.  A 256x256 GEMM block keeps two ~240-VGPR waves on every SIMD (480 of the 512-entry
+// register file); only a kernel that allocates <= 32 registers per lane can be co-resident with it, and then the optimizer's 28 B per
+// parameter stream from HBM while the matrix cores work on the next layer.  (The 4-wide kernel above needs 55 VGPRs: it waits for the
+// GEMM blocks to drain.)  nt cache policy (aux = 2) on every access, as above.
+__global__ __launch_bounds__(256) void adamw_lean_kernel(float* master, float* m, float* v, const uint32_t* grad, uint32_t* param, unsigned n2,
+                                                         float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float grad_scale,
+                                                         int odd_tail) {
+    if (odd_tail && blockIdx.x == 0 && threadIdx.x == 0) {           // element 2*n2 of an odd-length buffer
+        const int64_t t = (int64_t)n2 * 2;
+        float p = master[t], mi = m[t], vi = v[t];
+        adamw_one(p, mi, vi, bf2f(((const bf16_t*)grad)[t]) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        m[t] = mi; v[t] = vi; master[t] = p; ((bf16_t*)param)[t] = f2bf(p);
+    }
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(master, 0, n2 * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(m, 0, n2 * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(v, 0, n2 * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)grad, 0, n2 * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(param, 0, n2 * 4u, 0x00020000);
+    const unsigned stride = gridDim.x * blockDim.x;
+#pragma clang loop unroll(disable)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const u32x2 pw = __builtin_amdgcn_raw_buffer_load_b64(rp, i * 8u, 0, 2);
+        const u32x2 mw = __builtin_amdgcn_raw_buffer_load_b64(rm, i * 8u, 0, 2);
+        const u32x2 vw = __builtin_amdgcn_raw_buffer_load_b64(rv, i * 8u, 0, 2);
+        const unsigned g2 = __builtin_amdgcn_raw_buffer_load_b32(rg, i * 4u, 0, 2);
+        float p0 = __uint_as_float(pw[0]), m0 = __uint_as_float(mw[0]), v0 = __uint_as_float(vw[0]);
+        adamw_one(p0, m0, v0, lo_bf(g2) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        asm volatile("" : "+v"(p0), "+v"(m0), "+v"(v0));            // finish element 0 before element 1 starts: halves the live temporaries
+        float p1 = __uint_as_float(pw[1]), m1 = __uint_as_float(mw[1]), v1 = __uint_as_float(vw[1]);
+        adamw_one(p1, m1, v1, hi_bf(g2) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        const u32x2 po = {__float_as_uint(p0), __float_as_uint(p1)}, mo = {__float_as_uint(m0), __float_as_uint(m1)}, vo = {__float_as_uint(v0), __float_as_uint(v1)};
+        __builtin_amdgcn_raw_buffer_store_b64(mo, rm, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(vo, rv, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(po, rp, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(pack2bf(p0, p1), rq, i * 4u, 0, 2);
+    }
+}
+int launch_adamw_lean(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
+                      float wd, int step, float grad_scale, hipStream_t s) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    VILA_REQUIRE(((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) % 8 == 0 && ((uintptr_t)grad | (uintptr_t)param) % 4 == 0, "adamw_lean: buffers must be 8-B (fp32) / 4-B (bf16) aligned");
+    const int64_t chunk = (int64_t)1 << 28;                          // pairs per launch: 2 GiB of fp32 state per descriptor
+    int64_t done = 0;
+    const int64_t n2 = n >> 1;
+    do {
+        const int64_t c = (n2 - done) < chunk ? (n2 - done) : chunk;
+        const int last = (done + c >= n2) ? 1 : 0;
+        int grid = (int)((c + 255) / 256 < 1024 ? (c + 255) / 256 : 1024);
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(adamw_lean_kernel, dim3(grid), dim3(256), 0, s, master + 2 * done, m + 2 * done, v + 2 * done, (const uint32_t*)(grad + 2 * done),
+                           (uint32_t*)(param + 2 * done), (unsigned)c, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, (last && (n & 1)) ? 1 : 0);
+        VILA_LAUNCH_CHECK();
+        done += c;
+    } while (done < n2);
+    return 0;
+}
 // sum of squares of a bf16 buffer into a fp32 scalar (global grad-norm for clipping)
 __global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float scratch[4];

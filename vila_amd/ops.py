@@ -323,7 +323,12 @@ def attn_bwd(q, k, v, o, do, lse, causal: bool, dq, dk, dv, scale: Optional[floa
                                   float(scale if scale is not None else D ** -0.5), lse.data_ptr(), delta.data_ptr(), _stream()), "attn_bwd")
 
 
-def adamw_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0) -> None:
+def adamw_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0, lean: bool = False) -> None:
+    """torch.optim.AdamW update on flat buffers.  lean: the <= 32-VGPR kernel that fits beside a resident 256x256 GEMM block (side streams)."""
+    if lean:
+        check(_L().vila_adamw_step_lean(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), master.numel(), lr, beta1,
+                                        beta2, eps, wd, step, grad_scale, _stream()), "adamw_lean")
+        return
     check(_L().vila_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), master.numel(), lr, beta1, beta2,
                                eps, wd, step, grad_scale, _stream()), "adamw")
 

@@ -119,19 +119,31 @@ class GradReducer:
     backward has been enqueued (DDP-style overlap; RCCL runs on its own stream, ordered after the compute stream at call time).
     With no process group (single GPU) it only records the order — which the CPU/gloo test checks."""
 
-    def __init__(self, flat: FlatParams, group=None):
+    def __init__(self, flat: FlatParams, group=None, force: Optional[bool] = None):
         self.flat = flat
         self.group = group
         self.handles = []
         self.log: List[Tuple[str, int, int]] = []
+        import os
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        # force: issue the collectives even in a world of one (exercises the RCCL call path, its stream ordering and wait() on a
+        # 1-GPU box: bench.py sets it under VILA_BENCH_FORCE_DIST)
+        self.force = bool(os.environ.get("VILA_BENCH_FORCE_DIST")) if force is None else force
 
-    def ready(self, prefix: str) -> None:
+    def active(self) -> bool:
+        return self.dist is not None and (self.dist.get_world_size(self.group) > 1 or self.force)
+
+    def ready(self, prefix: str):
+        """Announce that every gradient under `prefix` is final; returns the async work handle (None without an exchange).  The
+        collective is ordered after the CURRENT stream, so call it inside the stream context that produced / waited for the grads."""
         a, b = self.flat.span(prefix)
         self.log.append((prefix, a, b))
-        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
-            self.handles.append(self.dist.all_reduce(self.flat.grads[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if not self.active():
+            return None
+        h = self.dist.all_reduce(self.flat.grads[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+        return h
 
     def wait(self) -> None:
         for h in self.handles:
@@ -143,23 +155,51 @@ class GradReducer:
         be = self.dist.get_backend(self.group) if self.dist is not None else "none"
         nb = len(self.log)
         return (f"{nb} buckets (one per layer, reverse order), SUM all-reduce of flat bf16 grad slices, backend={be}, world={w}"
-                + ("" if w > 1 else " (single rank: no exchange issued)"))
+                + ("" if w > 1 else (" (collectives issued in a world of one)" if self.active() else " (single rank: no exchange issued)")))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # linear layer helpers: y = x W^T (+b);  dx = dy W ; dW = dy^T x ; db = colsum(dy)
 # ----------------------------------------------------------------------------------------------------------------------
+def _cm_ok(T: int, N: int, K: int) -> bool:
+    """Shapes the 256x256 contraction-major kernels take (gemm256_supported): rows % 8 == 0, contraction >= 128."""
+    return T >= 128 and N >= 128 and N % 8 == 0 and K % 8 == 0
+
+
 def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor] = None,
-               need_dx: bool = True, dx_residual: Optional[torch.Tensor] = None, dy_t: Optional[torch.Tensor] = None):
-    """x2 [M,K], w [N,K], dy2 [M,N]  ->  writes gw [N,K] (and gb [N]); returns dx [M,K] (+ dx_residual)."""
+               need_dx: bool = True, dx_residual: Optional[torch.Tensor] = None, dy_t: Optional[torch.Tensor] = None,
+               cm: bool = False, side: Optional["torch.cuda.Stream"] = None, ws: Optional[torch.Tensor] = None):
+    """x2 [M,K], w [N,K], dy2 [M,N]  ->  writes gw [N,K] (and gb [N]); returns dx [M,K] (+ dx_residual).
+    cm: read W, dY and X as they lie (vila_gemm_bf16_t: contraction-major operands through the LDS transpose reads) instead of making
+    transposed copies.  side: stream for the weight-gradient GEMM — dgrad and wgrad only share inputs, so the two run concurrently
+    and the partial last round of one kernel's 256x256 tiles is filled by the other's."""
+    w2 = w.view(w.shape[0], -1)
+    gw2 = gw.view(w.shape[0], -1) if gw.dim() != 2 else gw
+    M, K = x2.shape
+    N = w2.shape[0]
+    if cm and _cm_ok(M, N, K):
+        def wgrad():
+            ops.gemm_t(dy2, x2, a_cm=True, b_cm=True, out=gw2, ws=ws)            # dW = dY^T X
+            if gb is not None:
+                ops.colsum(dy2, gb)
+        if side is not None:
+            side.wait_event(torch.cuda.current_stream().record_event())             # dY and X are final on the compute stream
+            with torch.cuda.stream(side):
+                wgrad()
+            dy2.record_stream(side); x2.record_stream(side)
+        else:
+            wgrad()
+        if not need_dx:
+            return None
+        return ops.gemm_t(dy2, w2, b_cm=True, residual=dx_residual, ws=ws if side is None else None)       # dX = dY W (+ residual)
     dyt = dy_t if dy_t is not None else ops.transpose(dy2)           # [N, Mp]
     xt = ops.transpose(x2)                                           # [K, Mp]
-    ops.gemm(dyt, xt, out=gw.view(w.shape[0], -1) if gw.dim() != 2 else gw)      # dW = dY^T X
+    ops.gemm(dyt, xt, out=gw2)                                       # dW = dY^T X
     if gb is not None:
         ops.colsum(dy2, gb)
     if not need_dx:
         return None
-    wt = ops.transpose(w.view(w.shape[0], -1))                       # [K, N]
+    wt = ops.transpose(w2)                                           # [K, N]
     return ops.gemm(dy2, wt, residual=dx_residual)                   # dX = dY W (+ residual)
 
 
@@ -176,6 +216,39 @@ class SFTTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.group = group
+        dev = model.device
+        on_gpu = torch.device(dev).type == "cuda"
+        # side: weight-gradient GEMMs of the decoder layers (concurrent with the dgrad chain on the compute stream)
+        # opt : per-bucket gradient exchange + AdamW, as soon as a layer's gradients are final — the optimizer streams 28 B per
+        #       parameter at HBM rate and the exchange runs on xGMI while the matrix cores work on the layers below
+        import os
+        flag = lambda name, default: os.environ.get(name, default) not in ("0", "", "false")
+        self.side = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_SIDE", "1")) else None
+        self.opt = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_OPT_STREAM", "1")) else None
+        self.lean_adamw = flag("VILA_SFT_LEAN_ADAMW", "1")      # <= 32-VGPR optimizer kernel: co-resident with the GEMM blocks
+        self.cm = flag("VILA_SFT_CM", "1")  # dgrad / wgrad on the tensors as they lie (no transposed copies) where the shapes allow
+        self.ws = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if on_gpu else None      # split-K slabs (lm_head dgrad)
+        self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
+
+    def _ready(self, prefix: str) -> None:
+        """Gradients under `prefix` are final once the compute stream and the wgrad stream reach this point: hand the bucket to the
+        optimizer stream (exchange, then AdamW on that slice) and carry on with the layers below."""
+        if self.opt is None:
+            self.reducer.ready(prefix)
+            return
+        main = torch.cuda.current_stream()
+        self.opt.wait_event(main.record_event())
+        if self.side is not None:
+            self.opt.wait_event(self.side.record_event())
+        with torch.cuda.stream(self.opt):
+            h = self.reducer.ready(prefix)
+            if self._bucket_step:
+                if h is not None:
+                    h.wait()                                        # the optimizer stream waits for this bucket's all-reduce only
+                f = self.flat
+                a, b = f.span(prefix)
+                ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
+                               self.eps, self.wd, f.step_count + 1, 1.0, lean=self.lean_adamw)
 
     # ------------------------------------------------------------------ ViT ------------------------------------------------
     def _vit_fwd(self, pixels: torch.Tensor):
@@ -247,7 +320,7 @@ class SFTTrainer:
             dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"))
             dxi = ops.norm_bwd(s.x_in, P(l + "layer_norm1.weight"), dh1, G(l + "layer_norm1.weight"), G(l + "layer_norm1.bias"), v.layer_norm_eps, False)
             dx = ops.add(dx_mid, dxi)
-            self.reducer.ready(l)
+            self._ready(l)
         # patch embedding: weight (unpadded), bias, position embedding (sum over images)
         Kc = v.num_channels * v.patch_size * v.patch_size
         gw = torch.empty((D, saved.patches.shape[1]), device=dx.device, dtype=torch.bfloat16)
@@ -256,7 +329,7 @@ class SFTTrainer:
         ops.colsum(dx, G(pre + "embeddings.patch_embedding.bias"))
         ops.colsum(dx, G(pre + "embeddings.position_embedding.weight"), period=N)
         # unused parameters (27th layer, post_layernorm) keep zero gradients (hidden_states[-2]: vision_encoder.py:44-52)
-        self.reducer.ready(pre + "embeddings.")
+        self._ready(pre + "embeddings.")
 
     # ------------------------------------------------------------------ projector ----------------------------------------
     def _proj_fwd(self, feats: torch.Tensor):
@@ -295,7 +368,7 @@ class SFTTrainer:
         dz1 = ops.act_bwd(s.z1, dh1, 2)
         dyn = linear_bwd(s.yn, P(pre + "2.weight"), dz1, G(pre + "2.weight"), G(pre + "2.bias"))
         dy = ops.norm_bwd(s.y.view(B * T, -1), P(pre + "1.weight"), dyn, G(pre + "1.weight"), G(pre + "1.bias"), 1e-5, False)
-        self.reducer.ready("mm_projector.")
+        self._ready("mm_projector.")
         return ops.depth_to_space(dy.view(B, T, -1), s.g, s.k)
 
     # ------------------------------------------------------------------ LLM ----------------------------------------------
@@ -333,22 +406,23 @@ class SFTTrainer:
         for i in reversed(range(c.num_hidden_layers)):
             l = f"llm.model.layers.{i}."
             s = saved.layers[i]
-            dact = linear_bwd(s.act, P(l + "mlp.down_proj.weight"), dx, G(l + "mlp.down_proj.weight"))
+            kw = dict(cm=self.cm, side=self.side)
+            dact = linear_bwd(s.act, P(l + "mlp.down_proj.weight"), dx, G(l + "mlp.down_proj.weight"), **kw)
             dg, du = ops.silu_mul_bwd(s.g, s.u, dact)
-            dh2 = linear_bwd(s.h2, P(l + "mlp.gate_proj.weight"), dg, G(l + "mlp.gate_proj.weight"))
-            dh2 = linear_bwd(s.h2, P(l + "mlp.up_proj.weight"), du, G(l + "mlp.up_proj.weight"), dx_residual=dh2)
+            dh2 = linear_bwd(s.h2, P(l + "mlp.gate_proj.weight"), dg, G(l + "mlp.gate_proj.weight"), **kw)
+            dh2 = linear_bwd(s.h2, P(l + "mlp.up_proj.weight"), du, G(l + "mlp.up_proj.weight"), dx_residual=dh2, **kw)
             dxm = ops.norm_bwd(s.x_mid, P(l + "post_attention_layernorm.weight"), dh2, G(l + "post_attention_layernorm.weight"), None, c.rms_norm_eps, True)
             dx_mid = ops.add(dx, dxm)
-            da = linear_bwd(s.a.view(T, nq * hd), P(l + "self_attn.o_proj.weight"), dx_mid, G(l + "self_attn.o_proj.weight"))
+            da = linear_bwd(s.a.view(T, nq * hd), P(l + "self_attn.o_proj.weight"), dx_mid, G(l + "self_attn.o_proj.weight"), **kw)
             dqkv = torch.empty_like(s.qkv)
             q3, d3 = s.qkv.view(T, nq + 2 * nkv, hd), dqkv.view(T, nq + 2 * nkv, hd)
             ops.attn_bwd(q3[:, :nq], q3[:, nq:nq + nkv], q3[:, nq + nkv:], s.a, da.view(T, nq, hd), s.lse, True,
                          d3[:, :nq], d3[:, nq:nq + nkv], d3[:, nq + nkv:], cu_seqlens=saved.cu, max_seqlen=saved.max_seqlen)
             ops.rope_bwd_(dqkv, saved.cs, saved.sn, nq, nkv, hd)
-            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"))
+            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"), **kw)
             dxi = ops.norm_bwd(s.x_in, P(l + "input_layernorm.weight"), dh1, G(l + "input_layernorm.weight"), None, c.rms_norm_eps, True)
             dx = ops.add(dx_mid, dxi)
-            self.reducer.ready(l)
+            self._ready(l)
         return dx
 
     # ------------------------------------------------------------------ the step -------------------------------------------
@@ -362,6 +436,9 @@ class SFTTrainer:
                                       "single-scale tower (cfg.dynamic_s2 = False)")
         dev = model.device
         P, G = flat.param, flat.grad
+        for st in (self.opt, self.side):             # the previous step's optimizer / exchange / wgrad work reads grads, writes params
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
         flat.grads.zero_()
         self.reducer.log.clear()
         c = cfg.llm
@@ -424,12 +501,12 @@ class SFTTrainer:
             logits = ops.gemm(hv, head, out_f32=True)                                    # [n_valid, V] fp32 only
             dlog = ops.ce_loss(logits, tgt[valid].contiguous(), loss, 1.0 / max(n_items, 1))
             del logits
-            dhv = linear_bwd(hv, head, dlog, G(head_name))
+            dhv = linear_bwd(hv, head, dlog, G(head_name), cm=self.cm, ws=self.ws)
             ops.copy_rows(dhv, dhn, None, rows32, n_valid)
         if not c.tie_word_embeddings:
-            self.reducer.ready("llm.lm_head.")
+            self._ready("llm.lm_head.")
         dx = ops.norm_bwd(saved.x_out, P("llm.model.norm.weight"), dhn, G("llm.model.norm.weight"), None, c.rms_norm_eps, True)
-        self.reducer.ready("llm.model.norm.")
+        self._ready("llm.model.norm.")
         dx0 = self._llm_bwd(dx, saved)
         # ---- embedding rows (text + "\n") and media rows ----
         ge = G("llm.model.embed_tokens.weight")
@@ -440,19 +517,27 @@ class SFTTrainer:
             dnl = torch.empty((n_nl, H), device=dev, dtype=torch.bfloat16)
             ops.copy_rows(dx0, dnl, nl_dst, None, n_nl)
             ops.scatter_add_rows(dnl, ge, nl_src)
-        self.reducer.ready("llm.model.embed_tokens.")
+        self._ready("llm.model.embed_tokens.")
         if n_img:
             full = n_feat == n_img * Tm
             dproj = (torch.empty if full else torch.zeros)((n_img * Tm, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
             ops.copy_rows(dx0, dproj, feat_dst, feat_src, n_feat)
             dfeats = self._proj_bwd(dproj.view(n_img, Tm, H), proj_saved)
             self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
-        self.reducer.wait()
+        for st in (self.side, self.opt):
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
+        if not self._bucket_step:
+            self.reducer.wait()
+        else:
+            self.reducer.handles = []               # every handle was waited for on the optimizer stream
         return loss[0]
 
     def optimizer_step(self) -> None:
         f = self.flat
         f.step_count += 1
+        if self._bucket_step:                        # AdamW already ran bucket by bucket inside forward_backward
+            return
         scale = 1.0
         if self.max_grad_norm is not None:
             norm = float(ops.sumsq(f.grads).sqrt())
@@ -471,8 +556,13 @@ class SFTTrainer:
     def step(self, input_ids, images, labels, attention_mask=None) -> float:
         n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
         n_global = self.global_num_items(n_local)
-        loss = self.forward_backward(input_ids, images, labels, attention_mask, n_global)
-        self.optimizer_step()
+        # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
+        self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
+        try:
+            loss = self.forward_backward(input_ids, images, labels, attention_mask, n_global)
+            self.optimizer_step()
+        finally:
+            self._bucket_step = False
         return loss
 
 
