@@ -52,6 +52,23 @@ size_t vila_vit_workspace_bytes(const VilaVitShape* s, int n_images);
 int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int n_images, void* out,
                      void* workspace, size_t workspace_bytes, vila_stream_t stream);
 
+/* W8A8 vision tower (BASELINE configs[4]; the reference's quantised numbers come from the external TinyChat
+ * backend, README.md:87 — no code in-tree, so the format is defined here): the q/k/v (fused), out_proj, fc1 and fc2 linears of every
+ * encoder layer run int8 x int8 -> int32 on the matrix cores with per-output-channel weight scales (w = wq * ws[n], symmetric,
+ * ws[n] = max|W[n,:]| / 127) and per-token dynamic activation scales; everything else as vila_vit_forward (same call contract). */
+typedef struct {
+    const void *wqkv_q, *wo_q, *fc1_q, *fc2_q;        /* int8 [3*hidden][hidden], [hidden][hidden], [inter][hidden], [hidden][inter] */
+    const float *wqkv_s, *wo_s, *fc1_s, *fc2_s;       /* fp32 per output row */
+} VilaVitLayerW8;
+size_t vila_vit_w8a8_workspace_bytes(const VilaVitShape* s, int n_images);
+int vila_vit_forward_w8a8(const VilaVitWeights* w, const VilaVitLayerW8* qlayers /*[host]*/, const void* pixels, int n_images, void* out,
+                          void* workspace, size_t workspace_bytes, vila_stream_t stream);
+/* operator level: per-token dynamic int8 quantisation (scale[r] = max|x_r| / 127) and the W8A8 GEMM
+ * C[M,N] = epi((Aq . Wq^T) * sx[m] * sw[n] + bias[n]) (+ residual), epi in {VILA_EPI_NONE, VILA_EPI_GELU_TANH}; K %% 16 == 0 */
+int vila_quant_rows_i8(const void* x_bf16, void* q_i8, float* scale, int rows, int cols, vila_stream_t stream);
+int vila_gemm_w8a8(const void* Aq, int64_t lda, const void* Wq, int64_t ldw, const float* sx, const float* sw, const void* bias,
+                   const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, vila_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * mm_projector — replaces MultimodalProjector.forward (llava/model/multimodal_projector/base_projector.py:248-252)
  * for mlp_downsample (:145-153), mlp_downsample_2x2_fix (:155-162), mlp_downsample_3x3_fix (:163-174), including the
@@ -141,6 +158,24 @@ size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx);
 int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx);
 int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
                          void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
+/* generate(do_sample=True): what HF GenerationMixin.sample does after the forward — logits / temperature -> TopK -> TopP -> softmax ->
+ * multinomial (server.py:101-102,185-187 sets temperature 0.2 / top_p 0.9; GenerationConfig's default top_k = 50 applies).  The whole
+ * choice runs on the device (three short launches) so that a sampled step replays from a hipGraph; the uniform number is
+ * splitmix64(seed, position of the token).  top_k must be in 1..64.  Parity with torch.multinomial is distributional, not bitwise. */
+typedef struct {
+    float temperature;   /* > 0 */
+    int top_k;           /* 1..64 */
+    float top_p;         /* (0, 1] */
+    uint64_t seed;
+} VilaSampling;
+size_t vila_sample_workspace_bytes(void);
+/* logits [n] fp32 -> *out; counter: device scalar mixed into the RNG (nullable); dist_out (nullable): [64] probabilities actually sampled
+ * from followed by [64] int32 token ids (descending probability, -1 = unused slot) */
+int vila_sample_f32(const float* logits, int n, const VilaSampling* sp, const int32_t* counter, int64_t* out, void* workspace,
+                    float* dist_out, vila_stream_t stream);
+int vila_llm_decode_step_sample(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
+                                void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream);
 
 /* hipGraph helpers: capture whatever is enqueued on `stream` between begin/end, replay it later. */
 int vila_graph_begin(vila_stream_t stream);

@@ -103,6 +103,44 @@ def vision_tower_forward(pixels, w, vcfg, return_all: bool = False):
 
 
 # ----------------------------------------------------------------------------------------------
+# SURVEY §8f row 3 (BASELINE configs[4]): W8A8 vision tower.  The reference's quantised numbers come from the EXTERNAL TinyChat backend
+# (README.md:87; nothing in-tree): parity unpinned against the reference.  This is the dequantise-then-fp32 oracle of the SAME scheme the
+# HIP path implements: per-output-channel symmetric int8 weights (given already dequantised in `w`), per-token dynamic symmetric int8
+# activations in front of each of the four linears of a layer.
+# ----------------------------------------------------------------------------------------------
+def fake_quant_rows(x: torch.Tensor) -> torch.Tensor:
+    """x -> dequant(quant(x)) with scale = max|row| / 127, round-half-even, clamp to [-127, 127]."""
+    s = (x.abs().amax(-1, keepdim=True) / 127.0)
+    s = torch.where(s > 0, s, torch.ones_like(s))
+    return torch.round(x / s).clamp(-127, 127) * s
+
+
+def vision_tower_forward_w8a8(pixels, w, vcfg):
+    """vision_tower_forward with the inputs of q/k/v, out_proj, fc1 and fc2 fake-quantised per token (weights in `w` are the dequantised
+    int8 weights).  Activations between kernels are rounded to bf16 where the HIP path stores bf16, so the integer grids line up."""
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(siglip_embeddings(pixels, w, vcfg))
+    H = vcfg.num_attention_heads
+    n_used = vcfg.select_layer if vcfg.select_layer >= 0 else vcfg.num_hidden_layers + 1 + vcfg.select_layer
+    for i in range(n_used):
+        l = f"{VT}encoder.layers.{i}."
+        h = bf(F.layer_norm(x, (x.shape[-1],), w[l + "layer_norm1.weight"], w[l + "layer_norm1.bias"], vcfg.layer_norm_eps))
+        hq = fake_quant_rows(h)
+        B, N, D = hq.shape
+        hd = D // H
+        q = bf(F.linear(hq, w[l + "self_attn.q_proj.weight"], w[l + "self_attn.q_proj.bias"])).view(B, N, H, hd).transpose(1, 2)
+        k = bf(F.linear(hq, w[l + "self_attn.k_proj.weight"], w[l + "self_attn.k_proj.bias"])).view(B, N, H, hd).transpose(1, 2)
+        v = bf(F.linear(hq, w[l + "self_attn.v_proj.weight"], w[l + "self_attn.v_proj.bias"])).view(B, N, H, hd).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(2, 3)) * hd ** -0.5, -1) @ v
+        a = bf(a.transpose(1, 2).reshape(B, N, D))
+        x = bf(x + F.linear(fake_quant_rows(a), w[l + "self_attn.out_proj.weight"], w[l + "self_attn.out_proj.bias"]))
+        h = bf(F.layer_norm(x, (D,), w[l + "layer_norm2.weight"], w[l + "layer_norm2.bias"], vcfg.layer_norm_eps))
+        f = bf(F.gelu(F.linear(fake_quant_rows(h), w[l + "mlp.fc1.weight"], w[l + "mlp.fc1.bias"]), approximate="tanh"))
+        x = bf(x + F.linear(fake_quant_rows(f), w[l + "mlp.fc2.weight"], w[l + "mlp.fc2.bias"]))
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
 # a5: DownSampleBlock.flat_square / flat_square_2x2 / flat_square_3x3 + MultimodalProjector.forward
 #     (llava/model/multimodal_projector/base_projector.py:58-71, 84-97, 110-123, 145-174, 248-252)
 # ----------------------------------------------------------------------------------------------

@@ -40,8 +40,9 @@ class _Model:
         self.tok = tok
         self.calls = []
 
-    def generate(self, input_ids, media, max_new_tokens, eos_token_id):
+    def generate(self, input_ids, media, max_new_tokens, eos_token_id, **sampling):
         self.calls.append((input_ids, media, max_new_tokens, eos_token_id))
+        self.sampling = sampling
         reply = self.tok("a red square").input_ids + [1, 99]       # EOS then a token that must be dropped
         return torch.tensor([reply])
 
@@ -98,8 +99,12 @@ def test_chat_completions_endpoint_schema_and_errors():
     assert "".join(json.loads(e[6:])["choices"][0]["delta"]["content"] for e in events[:-1]).strip() == "a red square"
     r = client.post("/chat/completions", json=dict(body, model="other"))
     assert r.status_code == 500 and "configured to use the model" in r.json()["error"]
-    r = client.post("/chat/completions", json=dict(body, temperature=0.7))
-    assert r.status_code == 500 and "greedy" in r.json()["error"]
+    # temperature > 0 samples (server.py:185-187): do_sample with the request's temperature / top_p reaches generate()
+    r = client.post("/chat/completions", json=dict(body, temperature=0.7, top_p=0.8))
+    assert r.status_code == 200 and m.sampling["do_sample"] is True
+    assert abs(m.sampling["temperature"] - 0.7) < 1e-6 and abs(m.sampling["top_p"] - 0.8) < 1e-6 and m.sampling["top_k"] == 50
+    r = client.post("/chat/completions", json=body)
+    assert r.status_code == 200 and m.sampling == {}                  # temperature 0 (the shim's default) stays greedy
 
 
 def test_prompt_split_matches_extract_media():

@@ -27,6 +27,10 @@ class VilaVitWeights(C.Structure):
                 ("layers", C.POINTER(VilaVitLayer))]
 
 
+class VilaVitLayerW8(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wqkv_q", "wo_q", "fc1_q", "fc2_q", "wqkv_s", "wo_s", "fc1_s", "fc2_s")]
+
+
 class VilaProjWeights(C.Structure):
     _fields_ = [("kind", c_int), ("in_dim", c_int), ("out_dim", c_int)] + \
                [(n, c_void_p) for n in ("ln1_w", "ln1_b", "fc1_w", "fc1_b", "ln2_w", "ln2_b", "fc2_w", "fc2_b", "fc3_w", "fc3_b")]
@@ -54,6 +58,10 @@ class VilaKvCache(C.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int), ("n_slots", c_int)]
 
 
+class VilaSampling(C.Structure):
+    _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", C.c_uint64)]
+
+
 class VilaDecodeState(C.Structure):
     _fields_ = [("pos", c_void_p), ("token", c_void_p), ("out_ids", c_void_p), ("n_out", c_void_p),
                 ("max_out", c_int), ("logits", c_void_p)]
@@ -65,6 +73,11 @@ PROTOTYPES = {
     "vila_abi_version": (c_int, []),
     "vila_vit_workspace_bytes": (c_size_t, [C.POINTER(VilaVitShape), c_int]),
     "vila_vit_forward": (c_int, [C.POINTER(VilaVitWeights), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vila_vit_w8a8_workspace_bytes": (c_size_t, [C.POINTER(VilaVitShape), c_int]),
+    "vila_vit_forward_w8a8": (c_int, [C.POINTER(VilaVitWeights), C.POINTER(VilaVitLayerW8), c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vila_quant_rows_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vila_gemm_w8a8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                               c_int, c_int, c_int, c_int, c_void_p]),
     "vila_proj_workspace_bytes": (c_size_t, [C.POINTER(VilaProjWeights), c_int, c_int]),
     "vila_proj_out_tokens": (c_int, [c_int, c_int]),
     "vila_proj_forward": (c_int, [C.POINTER(VilaProjWeights), c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -78,6 +91,10 @@ PROTOTYPES = {
     "vila_llm_decode_launches": (c_int, [C.POINTER(VilaLlmShape), c_int]),
     "vila_llm_decode_step": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeState),
                                      c_void_p, c_size_t, c_void_p]),
+    "vila_sample_workspace_bytes": (c_size_t, []),
+    "vila_sample_f32": (c_int, [c_void_p, c_int, C.POINTER(VilaSampling), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vila_llm_decode_step_sample": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeState),
+                                            c_void_p, c_size_t, C.POINTER(VilaSampling), c_void_p]),
     "vila_graph_begin": (c_int, [c_void_p]),
     "vila_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "vila_graph_launch": (c_int, [c_void_p, c_void_p]),

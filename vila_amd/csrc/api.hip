@@ -113,6 +113,70 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
     return 0;
 }
 
+// W8A8 vision tower (SURVEY.md §8f row 3 / BASELINE configs[4]): the four linears of every encoder layer run int8 x int8 on the matrix
+// cores (per-output-channel weight scales, per-token dynamic activation scales); patch embedding, LayerNorms, attention, biases,
+// residual stream stay bf16.  Same call contract as vila_vit_forward.
+extern "C" size_t vila_vit_w8a8_workspace_bytes(const VilaVitShape* s, int n_images) {
+    const size_t g = s->image / s->patch, M = (size_t)n_images * g * g, F = s->inter, D = s->hidden;
+    return vila_vit_workspace_bytes(s, n_images) + align_up(M * (F > D ? F : D), 256) + align_up(M * 4, 256) + 1024;
+}
+extern "C" int vila_vit_forward_w8a8(const VilaVitWeights* w, const VilaVitLayerW8* ql, const void* pixels, int n_images, void* out,
+                                     void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    const VilaVitShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    VILA_REQUIRE(n_images > 0 && ql != nullptr, "vit_w8a8: n_images must be positive and the int8 layers given");
+    VILA_REQUIRE(sh.image % sh.patch == 0 && sh.hidden % sh.heads == 0, "vit_w8a8: bad shape");
+    VILA_REQUIRE(sh.hidden % 16 == 0 && sh.inter % 16 == 0, "vit_w8a8: hidden (%d) and intermediate (%d) sizes must be multiples of 16", sh.hidden, sh.inter);
+    VILA_REQUIRE(workspace_bytes >= vila_vit_w8a8_workspace_bytes(&sh, n_images), "vit_w8a8: workspace too small");
+    const int g = sh.image / sh.patch, N = g * g, M = n_images * N, D = sh.hidden, F = sh.inter, hd = D / sh.heads;
+    const int Kc = sh.channels * sh.patch * sh.patch, Kp = vit_kp(&sh);
+    Arena a(workspace, workspace_bytes);
+    bf16_t* patches = a.take<bf16_t>((size_t)M * Kp);
+    bf16_t* wpad = a.take<bf16_t>((size_t)D * Kp);
+    bf16_t* x = a.take<bf16_t>((size_t)M * D);
+    bf16_t* h = a.take<bf16_t>((size_t)M * D);
+    bf16_t* qkv = a.take<bf16_t>((size_t)M * 3 * D);
+    bf16_t* f = a.take<bf16_t>((size_t)M * F);
+    int8_t* xq = a.take<int8_t>((size_t)M * (F > D ? F : D));
+    float* sx = a.take<float>((size_t)M);
+    VILA_REQUIRE(a.ok(), "vit_w8a8: workspace arena overflow");
+    VILA_TRY(launch_im2col(B(pixels), patches, n_images, sh.channels, sh.image, sh.image, sh.patch, Kp, s));
+    VILA_TRY(launch_pad_rows(B(w->patch_w), wpad, D, Kc, Kp, s));
+    bf16_t* x0 = (sh.n_layers_run == 0) ? B(out) : x;
+    VILA_TRY(gemm(patches, Kp, wpad, Kp, w->patch_b, B(w->pos_emb), D, x0, D, M, D, Kp, EPI_NONE, s, nullptr, 0, nullptr, 0, N));
+    for (int l = 0; l < sh.n_layers_run; ++l) {
+        const VilaVitLayer& L = w->layers[l];
+        const VilaVitLayerW8& Q = ql[l];
+        bf16_t* xo = (l == sh.n_layers_run - 1) ? B(out) : x;
+        VILA_TRY(launch_layernorm(x, B(L.ln1_w), B(L.ln1_b), h, M, D, sh.ln_eps, s));
+        VILA_TRY(launch_quant_rows_i8(h, xq, sx, M, D, s));
+        VILA_TRY(launch_gemm_i8(xq, D, (const int8_t*)Q.wqkv_q, D, sx, Q.wqkv_s, B(L.bq), nullptr, 0, qkv, 3 * D, M, 3 * D, D, EPI_NONE, s));
+        AttnArgs at{};
+        at.q = qkv; at.k = qkv + D; at.v = qkv + 2 * D; at.o = h;
+        at.q_tok_stride = at.k_tok_stride = at.v_tok_stride = 3 * D; at.o_tok_stride = D;
+        at.q_head_stride = at.k_head_stride = at.v_head_stride = at.o_head_stride = hd;
+        at.cu_seqlens = nullptr; at.n_seq = n_images; at.total_tokens = M; at.max_seqlen = N;
+        at.n_q_heads = at.n_kv_heads = sh.heads; at.head_dim = hd; at.causal = 0; at.scale = 1.0f / sqrtf((float)hd);
+        at.lse = nullptr;
+        VILA_TRY(launch_attn_fwd(at, s));
+        VILA_TRY(launch_quant_rows_i8(h, xq, sx, M, D, s));
+        VILA_TRY(launch_gemm_i8(xq, D, (const int8_t*)Q.wo_q, D, sx, Q.wo_s, B(L.bo), x, D, x, D, M, D, D, EPI_NONE, s));            // x += out_proj(attn)
+        VILA_TRY(launch_layernorm(x, B(L.ln2_w), B(L.ln2_b), h, M, D, sh.ln_eps, s));
+        VILA_TRY(launch_quant_rows_i8(h, xq, sx, M, D, s));
+        VILA_TRY(launch_gemm_i8(xq, D, (const int8_t*)Q.fc1_q, D, sx, Q.fc1_s, B(L.fc1_b), nullptr, 0, f, F, M, F, D, EPI_GELU_TANH, s));
+        VILA_TRY(launch_quant_rows_i8(f, xq, sx, M, F, s));
+        VILA_TRY(launch_gemm_i8(xq, F, (const int8_t*)Q.fc2_q, F, sx, Q.fc2_s, B(L.fc2_b), x, D, xo, D, M, D, F, EPI_NONE, s));      // x += fc2(gelu(fc1))
+    }
+    return 0;
+}
+extern "C" int vila_quant_rows_i8(const void* x, void* q, float* scale, int rows, int cols, vila_stream_t stream) {
+    return launch_quant_rows_i8(B(x), (int8_t*)q, scale, rows, cols, S(stream));
+}
+extern "C" int vila_gemm_w8a8(const void* Aq, int64_t lda, const void* Wq, int64_t ldw, const float* sx, const float* sw, const void* bias,
+                              const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epi, vila_stream_t stream) {
+    return launch_gemm_i8((const int8_t*)Aq, lda, (const int8_t*)Wq, ldw, sx, sw, B(bias), B(residual), ldr, B(C), ldc, M, N, K, epi, S(stream));
+}
+
 // =================================================================================================
 // Projector
 // =================================================================================================
@@ -288,7 +352,7 @@ static inline int dec_splits(int max_ctx) { return cdiv(max_ctx, 64); }
 // kernel launches of one vila_llm_decode_step: prologue + per layer {qkv, attention (1 launch up to 2048 cached positions, else
 // split-KV + merge), o_proj, gate/up, down} + lm_head + argmax x2 + advance
 extern "C" int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx) {
-    return 1 + s->n_layers * (max_ctx <= 2048 ? 5 : 6) + 4;
+    return 1 + s->n_layers * (max_ctx <= 2048 ? 5 : 6) + 4;      // a sampled step: + 1 (three selection launches instead of two argmax stages)
 }
 extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx) {
     const size_t H = s->hidden, F = s->inter, QS = (size_t)s->q_heads * s->head_dim;
@@ -298,11 +362,30 @@ extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max
     b += align_up(ns * QS * 4, 256) + align_up(ns * s->q_heads * 2 * 4, 256);
     b += 2 * align_up(256 * 4, 256) + align_up((size_t)s->head_dim * 4, 256);
     b += align_up(QS * 2, 256);
+    b += align_up(sample_workspace_bytes(), 256);
     return b + 4096;
 }
 
+static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
+                            const VilaSampling* sp, vila_stream_t stream);
 extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
                                     void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    return decode_step_impl(w, cache, st, workspace, workspace_bytes, nullptr, stream);
+}
+// the same step with a stochastic pick (temperature / top-k / top-p) instead of argmax: generate(do_sample=True)
+extern "C" int vila_llm_decode_step_sample(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
+                                           void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream) {
+    VILA_REQUIRE(sp != nullptr, "llm_decode_sample: sampling parameters are NULL");
+    return decode_step_impl(w, cache, st, workspace, workspace_bytes, sp, stream);
+}
+extern "C" size_t vila_sample_workspace_bytes(void) { return sample_workspace_bytes(); }
+extern "C" int vila_sample_f32(const float* logits, int n, const VilaSampling* sp, const int32_t* counter, int64_t* out, void* workspace,
+                               float* dist_out, vila_stream_t stream) {
+    VILA_REQUIRE(sp != nullptr && logits != nullptr && out != nullptr && workspace != nullptr, "sample: NULL argument");
+    return launch_sample(logits, n, sp->temperature, sp->top_k, sp->top_p, sp->seed, counter, out, workspace, dist_out, S(stream));
+}
+static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
+                            const VilaSampling* sp, vila_stream_t stream) {
     const VilaLlmShape& sh = w->shape;
     hipStream_t s = S(stream);
     VILA_REQUIRE(cache != nullptr && st != nullptr, "llm_decode: cache/state is NULL");
@@ -320,6 +403,7 @@ extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* 
     int* ti = a.take<int>(256);
     float* rope_cs = a.take<float>(hd);
     bf16_t* ao = a.take<bf16_t>(QS);
+    void* smp_ws = a.take<char>(sample_workspace_bytes());
     VILA_REQUIRE(a.ok(), "llm_decode: workspace arena overflow");
 
     VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
@@ -353,7 +437,8 @@ extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* 
     GemvArgs lm{};
     lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
     VILA_TRY(launch_gemv(lm, s));
-    VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
+    if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, st->pos, st->token, smp_ws, nullptr, s));
+    else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
     VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
     return 0;
 }

@@ -39,6 +39,10 @@ int launch_rope_kv(bf16_t* qkv, const float* cs, const float* sn, const int32_t*
 int launch_embed_gather(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int H, int64_t vocab, hipStream_t s);
 int launch_copy_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_row, const int32_t* dst_row, int n, int H, hipStream_t s);
 int launch_argmax(const float* logits, int V, int64_t* out, float* tmpv, int* tmpi, hipStream_t s);
+// stochastic token choice (sample.hip): temperature -> top-k (1..64) -> top-p -> draw; counter = device scalar mixed into the RNG
+size_t sample_workspace_bytes();
+int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const int32_t* counter, int64_t* out,
+                  void* workspace, float* prob_out, hipStream_t s);
 // dynamic_s2 merge (s2.hip): tower output -> projector input, desc = device [n_blocks][6] {tile_base, bh, bw, i, j, single}
 int launch_s2_merge(const bf16_t* feats, bf16_t* out, const int32_t* desc, int n_blocks, int g, int C, int n_scales, const int* splits,
                     hipStream_t s);
@@ -46,6 +50,11 @@ int launch_s2_merge(const bf16_t* feats, bf16_t* out, const int32_t* desc, int n
 // video token assembly (video.hip): temporal / spatial mean pooling + start / end token rows per pooled frame
 int launch_video_pool(const bf16_t* feats, bf16_t* out, int nt, int nl, int C, int pt, int ph, int pw, const bf16_t* start_rows, int n_start,
                       const bf16_t* end_rows, int n_end, hipStream_t s);
+
+// ---- W8A8 (gemm_i8.hip): Y = epi((Xq . Wq^T) * sx[m] * sw[n] + bias) (+ residual), int8 operands, int32 accumulate, bf16 out ----
+int launch_gemm_i8(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const float* sx, const float* sw, const bf16_t* bias,
+                   const bf16_t* residual, int64_t ldr, bf16_t* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s);
+int launch_quant_rows_i8(const bf16_t* x, int8_t* q, float* scale, int rows, int cols, hipStream_t s);
 
 // ---- attention (attn.hip) ----
 struct AttnArgs {

@@ -1,0 +1,128 @@
+// Stochastic next-token choice for generate(do_sample=True) — the reference's server default (server.py:101-102,185-187: temperature 0.2,
+// top_p 0.9, do_sample = temperature > 0; HF GenerationConfig's default top_k = 50 stays in force).  HF order of operations
+// (GenerationMixin._get_logits_processor + sample): logits / temperature -> TopK (keep the k largest) -> TopP (ascending cumulative
+// softmax, drop while cum <= 1 - top_p, keep at least one) -> softmax over what is left -> multinomial.
+//
+// Everything stays on the device so that a sampled decode step replays from a hipGraph like the greedy one:
+//   stage 1  256 blocks: each sorts its slice of the vocabulary (bitonic, LDS) and emits its 64 best (value, index) pairs
+//   stage 2  16 blocks : 1024 candidates each -> 64 best;   stage 3  1 block: 1024 -> the global top 64 (descending), then ONE wave applies
+//            temperature / top-k / top-p and draws from the renormalised set with a counter-based uniform: splitmix64(seed, *counter) —
+//            `counter` is the device-resident position of the token, so every replay of the captured step draws a fresh number.
+// top_k is limited to 1..64 (64 candidates survive the selection); the draw cannot match torch.multinomial's generator bit for bit —
+// parity for this op is distributional (tests/test_gpu_sampling.py).
+#include "kernels.h"
+
+#define SMP_CAND 64
+#define SMP_S1_BLOCKS 256
+#define SMP_S2_BLOCKS 16
+
+// order-preserving key: larger float -> larger key; ties broken towards the LOWER index (index stored inverted in the low bits)
+__device__ __forceinline__ uint64_t smp_key(float v, int idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(0x7fffffff - idx);
+}
+__device__ __forceinline__ float smp_val(uint64_t k) {
+    uint32_t u = (uint32_t)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int smp_idx(uint64_t k) { return 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu); }
+
+// descending bitonic sort of 1024 keys in LDS by 256 threads
+__device__ void smp_sort1024(uint64_t* keys) {
+    for (int size = 2; size <= 1024; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < 512; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    __syncthreads();
+}
+
+// stage 1 / 2: candidates in, SMP_CAND best per block out.  in_vals == nullptr: read raw logits [n] (index = position);
+// otherwise read (key) candidates produced by the previous stage.
+__global__ __launch_bounds__(256) void smp_select_kernel(const float* __restrict__ logits, const uint64_t* __restrict__ in_keys, int n, int per_block,
+                                                         uint64_t* __restrict__ out_keys) {
+    __shared__ uint64_t keys[1024];
+    const int base = blockIdx.x * per_block;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int g = base + i;
+        uint64_t k = 0;                                             // below every real key
+        if (i < per_block && g < n) k = (in_keys != nullptr) ? in_keys[g] : smp_key(logits[g], g);
+        keys[i] = k;
+    }
+    smp_sort1024(keys);
+    if (threadIdx.x < SMP_CAND) out_keys[blockIdx.x * SMP_CAND + threadIdx.x] = keys[threadIdx.x];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// stage 3: global top-64, then temperature / top-k / top-p / draw by wave 0
+__global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restrict__ in_keys, int n_in, float inv_temperature, int top_k, float top_p,
+                                                        uint64_t seed, const int32_t* __restrict__ counter, int64_t* __restrict__ out, float* __restrict__ prob_out) {
+    __shared__ uint64_t keys[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) keys[i] = i < n_in ? in_keys[i] : 0;
+    smp_sort1024(keys);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const uint64_t k = keys[lane];
+    const bool real = k != 0 && lane < top_k;                      // TopK: the k most likely survive
+    const float z = smp_val(k) * inv_temperature, zmax = smp_val(keys[0]) * inv_temperature;
+    const float e = real ? __expf(z - zmax) : 0.f;
+    const float total = wave_sum(e);
+    const float p = e / total;                                      // softmax over the top-k set (descending order by construction)
+    // exclusive prefix sum over the wave (descending probabilities)
+    float incl = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const float before = incl - p;                                  // probability mass of strictly more likely tokens
+    const bool keep = real && (lane == 0 || before < top_p);        // TopP (HF keeps the token that crosses the threshold; at least one)
+    const float pk = keep ? p : 0.f;
+    const float kept_total = wave_sum(pk);
+    float cum = pk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(cum, o, 64);
+        if (lane >= o) cum += t;
+    }
+    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)(uint32_t)(counter != nullptr ? *counter : 0)));
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * kept_total;      // uniform in [0, kept_total)
+    const unsigned long long hit = __ballot(keep && cum > u);
+    const int pick = hit ? __ffsll((long long)hit) - 1 : 0;
+    if (lane == pick) *out = (int64_t)smp_idx(k);
+    if (prob_out != nullptr) prob_out[lane] = pk / kept_total;     // optional: the distribution that was sampled (tests)
+    if (prob_out != nullptr) ((int*)(prob_out + 64))[lane] = real ? smp_idx(k) : -1;
+}
+
+size_t sample_workspace_bytes() { return (size_t)(SMP_S1_BLOCKS + SMP_S2_BLOCKS) * SMP_CAND * sizeof(uint64_t) + 256; }
+
+int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const int32_t* counter, int64_t* out,
+                  void* workspace, float* prob_out, hipStream_t s) {
+    VILA_REQUIRE(n > 0 && temperature > 0.f, "sample: temperature must be positive (got %g); use greedy search for temperature 0", (double)temperature);
+    VILA_REQUIRE(top_k >= 1 && top_k <= SMP_CAND, "sample: top_k must be in 1..%d (got %d): the on-device selection keeps %d candidates", SMP_CAND, top_k, SMP_CAND);
+    VILA_REQUIRE(top_p > 0.f && top_p <= 1.f, "sample: top_p must be in (0, 1] (got %g)", (double)top_p);
+    const int per1 = cdiv(n, SMP_S1_BLOCKS);
+    VILA_REQUIRE(per1 <= 1024, "sample: vocabulary of %d exceeds %d x 1024 entries", n, SMP_S1_BLOCKS);
+    uint64_t* c1 = (uint64_t*)workspace;
+    uint64_t* c2 = c1 + SMP_S1_BLOCKS * SMP_CAND;
+    hipLaunchKernelGGL(smp_select_kernel, dim3(SMP_S1_BLOCKS), dim3(256), 0, s, logits, (const uint64_t*)nullptr, n, per1, c1);
+    VILA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smp_select_kernel, dim3(SMP_S2_BLOCKS), dim3(256), 0, s, (const float*)nullptr, (const uint64_t*)c1, SMP_S1_BLOCKS * SMP_CAND, 1024, c2);
+    VILA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smp_final_kernel, dim3(1), dim3(256), 0, s, (const uint64_t*)c2, SMP_S2_BLOCKS * SMP_CAND, 1.0f / temperature, top_k, top_p, seed, counter, out, prob_out);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}

@@ -178,6 +178,13 @@ class HipSiglipVisionTower(_HipModule):
             self._cstruct = (w, layers)
         return self._cstruct[0]
 
+    def quantize_w8(self):
+        """W8A8 (BASELINE configs[4]): build int8 per-channel copies of the encoder linears; forward() then runs
+        `vila_vit_forward_w8a8` (int8 x int8 matrix-core GEMMs with per-token dynamic activation scales)."""
+        from .quant import W8VitWeights
+        self._w8 = W8VitWeights(self)
+        return self._w8
+
     @torch.no_grad()
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         if isinstance(images, list):
@@ -190,8 +197,14 @@ class HipSiglipVisionTower(_HipModule):
         Bn = x.shape[0]
         lib = _lib.load()
         w = self._struct()
-        ws = self._workspace(lib.vila_vit_workspace_bytes(C.byref(w.shape), Bn), x.device)
         out = torch.empty((Bn, v.num_patches, v.hidden_size), device=x.device, dtype=self.dtype)
+        w8 = getattr(self, "_w8", None)
+        if w8 is not None:
+            ws = self._workspace(lib.vila_vit_w8a8_workspace_bytes(C.byref(w.shape), Bn), x.device)
+            check(lib.vila_vit_forward_w8a8(C.byref(w), w8.ptr, x.data_ptr(), Bn, out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+                  "vila_vit_forward_w8a8")
+            return out.to(images.dtype) if images.dtype in (torch.float16, torch.bfloat16) else out
+        ws = self._workspace(lib.vila_vit_workspace_bytes(C.byref(w.shape), Bn), x.device)
         check(lib.vila_vit_forward(C.byref(w), x.data_ptr(), Bn, out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "vila_vit_forward")
         return out.to(images.dtype) if images.dtype in (torch.float16, torch.bfloat16) else out
 
@@ -389,10 +402,11 @@ class HipQwen2ForCausalLM(_HipModule):
         return CausalLMOutput(loss=loss, logits=logits, past_key_values=None)
 
     # ---- greedy generate ---------------------------------------------------------------------------------------
-    def _decode_session(self, cache, max_new_tokens: int):
-        """Device-resident decode state + workspace (+ captured hipGraph) reused across generate() calls."""
+    def _decode_session(self, cache, max_new_tokens: int, sampling=None):
+        """Device-resident decode state + workspace (+ captured hipGraph) reused across generate() calls.
+        sampling: None (greedy) or (temperature, top_k, top_p, seed) — baked into the captured graph, hence part of the key."""
         key = (cache.k.data_ptr(), max_new_tokens, self.model.embed_tokens.weight.data_ptr(),
-               _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr())
+               _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr(), sampling)
         if self._decode is not None and self._decode.key == key:
             return self._decode
         self._invalidate()          # another cache / length / weight storage: drop the old session and its graph
@@ -400,6 +414,8 @@ class HipQwen2ForCausalLM(_HipModule):
         lib = _lib.load()
         w = self._struct()
         st = SimpleNamespace(key=key, cache=cache)
+        st.sampling = None if sampling is None else _lib.VilaSampling(float(sampling[0]), int(sampling[1]), float(sampling[2]),
+                                                                      int(sampling[3]) & 0xFFFFFFFFFFFFFFFF)
         # the session outlives the call that creates it: built outside inference mode even when the first generate() runs under
         # torch.inference_mode() (llava_arch.py:823), or a later no_grad caller could not update `pos` / `token` in place
         with torch.inference_mode(False):
@@ -427,24 +443,64 @@ class HipQwen2ForCausalLM(_HipModule):
     def decode_step(self, cache, st) -> None:
         lib = _lib.load()
         w4 = getattr(self, "_w4", None)
+        sp = getattr(st, "sampling", None)
         if w4 is not None:
+            if sp is not None:
+                raise NotImplementedError("do_sample with the W4A16 decode step is not implemented")
             check(lib.vila_llm_decode_step_w4(C.byref(self._struct()), w4.ptr, C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(),
                                               st.ws.numel(), ops._stream()), "vila_llm_decode_step_w4")
+            return
+        if sp is not None:
+            check(lib.vila_llm_decode_step_sample(C.byref(self._struct()), C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
+                                                  C.byref(sp), ops._stream()), "vila_llm_decode_step_sample")
             return
         check(lib.vila_llm_decode_step(C.byref(self._struct()), C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
                                        ops._stream()), "vila_llm_decode_step")
 
     @torch.no_grad()
-    def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 32,
-                 eos_token_id=None, do_sample: bool = False, use_graph: bool = True, return_logits: bool = False,
-                 forced_ids: Optional[torch.Tensor] = None, cache=None, max_length: Optional[int] = None, **kw):
-        """Greedy search on `inputs_embeds` [1,S,H] (HF semantics: returns ONLY the new tokens, [1, n_new]).
-        The whole step (28 layers + lm_head + argmax + position advance) is one hipGraph replay; the host only polls
-        for EOS every 16 tokens.  forced_ids = teacher forcing for margin-aware parity tests."""
+    def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: Optional[int] = None,
+                 eos_token_id=None, do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, seed: Optional[int] = None, pad_token_id: Optional[int] = None, generation_config=None,
+                 use_graph: bool = True, return_logits: bool = False, forced_ids: Optional[torch.Tensor] = None, cache=None,
+                 max_length: Optional[int] = None, **kw):
+        """`llm.generate(inputs_embeds=, attention_mask=, **generation_kwargs)` as called at llava_arch.py:833 (HF semantics: returns ONLY the
+        new tokens, [B, n_new]).  Greedy search or sampling (do_sample: temperature / top_k <= 64 / top_p, HF order, on the device); explicit
+        keyword arguments override `generation_config` (HF GenerationConfig-like: do_sample, temperature, top_k, top_p, max_new_tokens,
+        eos_token_id, pad_token_id).  The whole step (28 layers + lm_head + token choice + position advance) is one hipGraph replay; the host
+        polls for EOS every 16 tokens.  A padded batch (B > 1) is served one sequence at a time through the same cache and graph (each row
+        costs a batch-1 decode: weights are streamed once per row and token) and right-padded with pad_token_id like HF.
+        forced_ids = teacher forcing for margin-aware parity tests."""
+        gc = generation_config
+        pick = lambda v, name, default: v if v is not None else (getattr(gc, name, None) if gc is not None and getattr(gc, name, None) is not None else default)
+        do_sample = bool(pick(do_sample, "do_sample", False))
+        temperature, top_k, top_p = float(pick(temperature, "temperature", 1.0)), int(pick(top_k, "top_k", 50)), float(pick(top_p, "top_p", 1.0))
+        max_new_tokens = int(pick(max_new_tokens, "max_new_tokens", 32))
+        eos_token_id = pick(eos_token_id, "eos_token_id", None)
+        pad_token_id = pick(pad_token_id, "pad_token_id", None)
+        if do_sample and temperature <= 0:
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float, otherwise your next token scores will be invalid.")
+        if do_sample and not (1 <= top_k <= 64):
+            raise NotImplementedError(f"do_sample: top_k must be in 1..64 (got {top_k}); HF's default 50 is what the reference's server uses")
+        if inputs_embeds.shape[0] > 1:
+            rows = []
+            for b in range(inputs_embeds.shape[0]):
+                m = None if attention_mask is None else attention_mask[b:b + 1]
+                rows.append(self.generate(inputs_embeds[b:b + 1], m, max_new_tokens, eos_token_id, do_sample, temperature, top_k, top_p,
+                                          None if seed is None else seed + b, pad_token_id, None, use_graph, False, None, cache, max_length)[0])
+            eos1 = eos_token_id[0] if isinstance(eos_token_id, (list, tuple)) else eos_token_id
+            pad = pad_token_id if pad_token_id is not None else (eos1 if eos1 is not None else self.lcfg.eos_token_id)
+            n = max(int(r.numel()) for r in rows)
+            out = torch.full((len(rows), n), int(pad), dtype=torch.int64, device=rows[0].device)
+            for b, r in enumerate(rows):
+                out[b, : r.numel()] = r
+            return out
+        sampling = None
         if do_sample:
-            raise NotImplementedError("only greedy search (do_sample=False) is implemented")
+            if seed is None:
+                self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+                seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
+            sampling = (temperature, top_k, top_p, int(seed))
         ops._need(inputs_embeds, dtype=None, name="inputs_embeds")
-        assert inputs_embeds.shape[0] == 1, "batch-1 generation (reference benchmark setting, README.md:87)"
         x = inputs_embeds[0]
         if attention_mask is not None:
             x = x[attention_mask[0].bool()]
@@ -461,8 +517,11 @@ class HipQwen2ForCausalLM(_HipModule):
         pos = torch.arange(S, device=dev, dtype=torch.int32)
         last = torch.tensor([S - 1], device=dev, dtype=torch.int32)
         r = self.prefill_packed(x.to(self.dtype), pos, None, S, cache=cache, last_rows=last)
-        st = self._decode_session(cache, max_new_tokens)
-        first = ops.argmax(r.last_logits[0])
+        st = self._decode_session(cache, max_new_tokens, sampling)
+        # the sampler mixes a device counter into its random number: the decode steps use the position of the token they consume
+        # (S, S+1, ...); the first token, drawn from the prefill's logits, uses S - 1
+        first = (ops.argmax(r.last_logits[0]) if sampling is None else
+                 ops.sample(r.last_logits[0], temperature, top_k, top_p, sampling[3], counter=last))
         step_logits = [r.last_logits[0].clone()] if return_logits else None
         st.pos.fill_(S)
         st.n_out.zero_()
@@ -489,7 +548,7 @@ class HipQwen2ForCausalLM(_HipModule):
                 self.decode_step(cache, st)
                 if return_logits:
                     step_logits.append(st.logits.clone())
-                    ids.append(ops.argmax(st.logits))
+                    ids.append(ops.argmax(st.logits) if sampling is None else st.token.clone())
                 if forced_ids is not None and t + 1 < forced_ids.numel():
                     st.token.copy_(forced_ids[t + 1:t + 2].to(dev))
             if not return_logits:

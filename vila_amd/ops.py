@@ -159,6 +159,23 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sample(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, seed: int = 0,
+           counter: Optional[torch.Tensor] = None, return_dist: bool = False):
+    """HF sampling on the device (GenerationMixin.sample): logits / temperature -> TopK (1..64) -> TopP -> softmax -> draw with
+    splitmix64(seed, *counter).  -> token id [1] i64 (and, on request, the 64-slot distribution that was sampled + its token ids)."""
+    _need(logits, dtype=torch.float32, name="logits")
+    lib = _lib.load()
+    out = torch.empty((1,), device=logits.device, dtype=torch.int64)
+    ws = torch.empty((lib.vila_sample_workspace_bytes(),), device=logits.device, dtype=torch.uint8)
+    dist = torch.zeros((128,), device=logits.device, dtype=torch.float32) if return_dist else None
+    sp = _lib.VilaSampling(float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    import ctypes as C
+    check(lib.vila_sample_f32(logits.data_ptr(), logits.numel(), C.byref(sp), _p(counter), out.data_ptr(), ws.data_ptr(), _p(dist), _stream()), "sample")
+    if return_dist:
+        return out, dist[:64].clone(), dist[64:].view(torch.int32).clone()
+    return out
+
+
 def embed_tokens(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     _need(table, name="embed table")
     ids = ids.to(device=table.device, dtype=torch.int64).contiguous()
@@ -173,6 +190,29 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, src_row: Optional[torch.Tens
     for t in (src_row, dst_row):
         assert t is None or (t.dtype == torch.int32 and t.is_cuda)
     check(_lib.load().vila_copy_rows(src.data_ptr(), dst.data_ptr(), _p(src_row), _p(dst_row), n, src.shape[-1], _stream()), "copy_rows")
+
+
+def quant_rows_i8(x: torch.Tensor):
+    """bf16 [rows, cols] -> (int8 [rows, cols], fp32 scale [rows]): per-token dynamic symmetric quantisation (scale = max|row| / 127)."""
+    _need(x, name="x")
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    q = torch.empty(x2.shape, device=x.device, dtype=torch.int8)
+    sc = torch.empty((x2.shape[0],), device=x.device, dtype=torch.float32)
+    check(_lib.load().vila_quant_rows_i8(x2.data_ptr(), q.data_ptr(), sc.data_ptr(), x2.shape[0], x2.shape[1], _stream()), "quant_rows_i8")
+    return q, sc
+
+
+def gemm_w8a8(aq: torch.Tensor, sx: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, epi: int = EPI_NONE) -> torch.Tensor:
+    """out[M,N] bf16 = epi((aq[M,K] . wq[N,K]^T) * sx[m] * sw[n] + bias) (+ residual); int8 operands, int32 accumulate."""
+    assert aq.dtype == torch.int8 and wq.dtype == torch.int8 and aq.is_cuda and aq.stride(1) == 1 and wq.stride(1) == 1
+    M, K = aq.shape
+    N = wq.shape[0]
+    out = torch.empty((M, N), device=aq.device, dtype=torch.bfloat16)
+    check(_lib.load().vila_gemm_w8a8(aq.data_ptr(), aq.stride(0), wq.data_ptr(), wq.stride(0), sx.data_ptr(), sw.data_ptr(), _p(bias), _p(residual),
+                                     residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K, epi, _stream()),
+          "vila_gemm_w8a8")
+    return out
 
 
 def video_pool(feats: torch.Tensor, pool, start_rows: Optional[torch.Tensor] = None, end_rows: Optional[torch.Tensor] = None,

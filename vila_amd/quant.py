@@ -157,3 +157,55 @@ class W4Weights:
             out[p + "mlp.gate_proj.weight"], out[p + "mlp.up_proj.weight"] = g.cpu(), u.cpu()
             out[p + "mlp.down_proj.weight"] = m["down"].dequantized().cpu()
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# W8A8 vision tower (BASELINE configs[4]: "W8A8 vision tower"; TinyChat is external, README.md:87)
+# ----------------------------------------------------------------------------------------------------------------------
+def quantize_w8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """w [N, K] -> (int8 [N, K], fp32 scale [N]): symmetric per-OUTPUT-CHANNEL, scale = max|w_row| / 127, q = round(w / scale)."""
+    wf = w.float()
+    scale = (wf.abs().amax(-1) / 127.0).clamp_min(1e-12)
+    q = torch.round(wf / scale[:, None]).clamp(-127, 127).to(torch.int8)
+    return q.contiguous(), scale.contiguous()
+
+
+def dequantize_w8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q.float() * scale[:, None].float()
+
+
+class W8VitWeights:
+    """int8 copies (+ per-row scales) of the fused q/k/v, out_proj, fc1, fc2 weights of every encoder layer the tower runs, and the
+    host array of VilaVitLayerW8 the C-ABI takes.  Biases, LayerNorms, patch / position embeddings stay bf16 in the tower."""
+
+    def __init__(self, tower):
+        v = tower.vcfg
+        vm = tower.vision_tower.vision_model
+        n_run = v.num_used_layers
+        self.tensors = []
+        self.layers_c = (_lib.VilaVitLayerW8 * max(n_run, 1))()
+        for i in range(n_run):
+            l = getattr(vm.encoder.layers, str(i))
+            a = l.self_attn
+            wqkv = torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data], 0)
+            t = {}
+            for name, w in (("wqkv", wqkv), ("wo", a.out_proj.weight.data), ("fc1", l.mlp.fc1.weight.data), ("fc2", l.mlp.fc2.weight.data)):
+                t[name + "_q"], t[name + "_s"] = quantize_w8(w)
+            self.tensors.append(t)
+            L = self.layers_c[i]
+            for k, val in t.items():
+                setattr(L, k, val.data_ptr())
+        self.ptr = C.cast(self.layers_c, C.POINTER(_lib.VilaVitLayerW8))
+
+    def dequantized_state(self, prefix: str = "vision_tower.vision_tower.vision_model.") -> Dict[str, torch.Tensor]:
+        """fp32 weights equal to what the int8 GEMMs multiply by (for the CPU oracle): keys as in the reference's state_dict."""
+        out = {}
+        for i, t in enumerate(self.tensors):
+            l = f"{prefix}encoder.layers.{i}."
+            wqkv = dequantize_w8(t["wqkv_q"], t["wqkv_s"]).cpu()
+            d = wqkv.shape[0] // 3
+            out[l + "self_attn.q_proj.weight"], out[l + "self_attn.k_proj.weight"], out[l + "self_attn.v_proj.weight"] = wqkv[:d], wqkv[d:2 * d], wqkv[2 * d:]
+            out[l + "self_attn.out_proj.weight"] = dequantize_w8(t["wo_q"], t["wo_s"]).cpu()
+            out[l + "mlp.fc1.weight"] = dequantize_w8(t["fc1_q"], t["fc1_s"]).cpu()
+            out[l + "mlp.fc2.weight"] = dequantize_w8(t["fc2_q"], t["fc2_s"]).cpu()
+        return out

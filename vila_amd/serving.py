@@ -85,15 +85,20 @@ def encode_with_images(tokenizer, text: str, image_token_id: int) -> torch.Tenso
 
 
 def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_new_tokens: int = 128, system: Optional[str] = None,
-                     eos_token_id=None, device: Optional[str] = None) -> str:
-    """Text + images in, decoded reply out — the contract of `LlavaLlamaModel.generate_content` for image / text prompts."""
+                     eos_token_id=None, device: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 50,
+                     seed: Optional[int] = None) -> str:
+    """Text + images in, decoded reply out — the contract of `LlavaLlamaModel.generate_content` for image / text prompts.
+    temperature > 0 samples (server.py:185-187: do_sample = temperature > 0, with the request's top_p and HF's default top_k = 50)."""
     text, images = _split_prompt(prompt)
     cfg = model.cfg
     dev = device or str(model.device)
     ids = encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
     media = {"image": [preprocess_image(im, cfg.vision.image_size).to(device=dev, dtype=torch.bfloat16) for im in images]}
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
-    out = model.generate(input_ids=ids, media=media, max_new_tokens=max_new_tokens, eos_token_id=eos)
+    gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
+    if temperature and temperature > 0:
+        gen.update(do_sample=True, temperature=float(temperature), top_p=float(top_p), top_k=int(top_k), seed=seed)
+    out = model.generate(input_ids=ids, media=media, **gen)
     toks = out[0].tolist()
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
     for k, t in enumerate(toks):                       # HF returns the EOS as the last token; decode(skip_special_tokens) drops it
@@ -152,11 +157,10 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B"):
         try:
             if request.model != model_name:
                 raise ValueError(f"The endpoint is configured to use the model {model_name}, but the request model is {request.model}")
-            if (request.temperature or 0.0) > 0:
-                raise ValueError("only greedy decoding (temperature = 0) is implemented")
             parts, system = _prompt_of(request.messages)
             with torch.inference_mode():
-                text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system)
+                text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
+                                        temperature=request.temperature or 0.0, top_p=request.top_p if request.top_p is not None else 1.0)
             if request.stream:
                 def chunks() -> Iterator[str]:
                     for i, word in enumerate(re.findall(r"\S+\s*", text)):
