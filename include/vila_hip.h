@@ -263,6 +263,42 @@ int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The whole SFT forward + backward as ONE call — replaces what autograd does under the reference's
+ * patched `Trainer.training_step` (llava/train/transformer_normalize_monkey_patch.py:183-249): LlavaLlamaModel.forward
+ * (llava_llama.py:94-159) on a packed batch, loss = sum CE * loss_scale (loss_scale = 1 / GLOBAL num_items, :261-268), gradients of
+ * every parameter of the LLM, the mm_projector and the vision tower.
+ *   - weights / gradients: the inference structs; `*_grad` mirrors the weight struct with pointers to the bf16 gradient tensors of
+ *     the same shapes (q/k/v fused like the weights).  The caller ZEROES the gradient buffers before the call (embedding rows are
+ *     scatter-added; parameters the path never touches keep zero).  Every other gradient tensor is overwritten.
+ *   - VilaSftBatch: the integer work of `_embed` / `repack_multimodal_data` (llava_arch.py:412-490, 744-800) planned on the host
+ *     (vila_amd/host.py), all index arrays on the device
+ *   - workspace: saved activations + temporaries (vila_sft_workspace_bytes; about 4 GB per 769-token sample at NVILA-8B), no
+ *     re-computation
+ *   - cb: called on the HOST, on the calling thread, right after the last kernel that writes a gradient bucket has been enqueued on
+ *     `stream` (buckets in backward order: LM_HEAD (untied head only), FINAL_NORM, LLM_LAYER n-1..0, EMBED, PROJECTOR, VIT_LAYER n-1..0,
+ *     VIT_EMBED).  That is where a data-parallel caller records an event and starts the bucket's all-reduce / optimizer on its own
+ *     streams; nullable.
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { VILA_BUCKET_LM_HEAD = 0, VILA_BUCKET_FINAL_NORM = 1, VILA_BUCKET_LLM_LAYER = 2, VILA_BUCKET_EMBED = 3, VILA_BUCKET_PROJECTOR = 4,
+       VILA_BUCKET_VIT_LAYER = 5, VILA_BUCKET_VIT_EMBED = 6 };
+typedef void (*VilaGradReadyCb)(void* arg, int bucket, int index);
+typedef struct {
+    const void* pixels; int n_images;                 /* [n_images, C, image, image] bf16 */
+    int total_tokens;                                  /* T: tokens of the packed row */
+    const int32_t* txt_src; const int32_t* txt_dst; int n_txt;       /* embed_tokens row (token id) -> packed row */
+    const int32_t* feat_src; const int32_t* feat_dst; int n_feat;    /* mm_projector output row -> packed row */
+    const int32_t* nl_src; const int32_t* nl_dst; int n_nl;          /* the "\n" end token of every image (ids) -> packed row */
+    const int32_t* positions;                          /* [T] restarted per sample (llava_arch.py:751) */
+    const int32_t* cu_seqlens; int n_seq; int max_seqlen;            /* flash-attn varlen description (model/utils/packing.py:12-21) */
+    const int32_t* target_rows; const int64_t* targets; int n_targets;  /* packed rows that predict a label, and the labels */
+    float loss_scale;
+} VilaSftBatch;
+size_t vila_sft_workspace_bytes(const VilaVitWeights* vit, const VilaProjWeights* proj, const VilaLlmWeights* llm, const VilaSftBatch* batch);
+int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, const VilaProjWeights* proj, const VilaProjWeights* proj_grad,
+                     const VilaLlmWeights* llm, const VilaLlmWeights* llm_grad, const VilaSftBatch* batch, float* loss_out /* device */,
+                     void* workspace, size_t workspace_bytes, VilaGradReadyCb cb, void* cb_arg, vila_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * dynamic_s2 multi-scale path — replaces merge_features_for_dynamic_s2 + split_chessboard +
  * rearrange of LlavaMetaModel.encode_images (llava/model/llava_arch.py:298-379):
  *   feats [n_tiles, g*g, C] (tower output for every tile of every image, scales in ascending order per image)

@@ -182,43 +182,52 @@ def test_adamw_matches_torch(ops, n):
 # ---------------------------------------------------------------------------------------------------------------------
 # whole step vs autograd through the CPU oracle
 # ---------------------------------------------------------------------------------------------------------------------
-def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max=6e-2):
+def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max=6e-2, c_abi=(False,)):
     """One forward+backward of the HIP trainer vs fp32 autograd through the restated reference forward (packed branch of
-    llava_llama.py:125-134): loss <= 1e-2 relative, every gradient tensor cosine >= cos_min and rel-L2 <= rel_max."""
+    llava_llama.py:125-134): loss <= 1e-2 relative, every gradient tensor cosine >= cos_min and rel-L2 <= rel_max.
+    c_abi: which drivers to check against the ONE oracle run — False = the Python-orchestrated operator calls, True = the whole
+    forward + backward as one `vila_sft_fwd_bwd` call with the grad-ready callback."""
     from oracle import vila_oracle as O
     from vila_amd import synthetic
     from vila_amd.train import SFTTrainer, count_targets
     from vila_amd.vlm import build_model
     w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, seed).items()}
-    model = build_model(cfg, weights=w)
-    tr = SFTTrainer(model, optimizer_state=False)
     px = synthetic.make_pixels(cfg, n_images, seed).to(torch.bfloat16)
     n_items = count_targets(ids, labels, mask, cfg.image_token_id)
-    loss = tr.forward_backward(ids, [p.cuda() for p in px], labels, mask, n_items)
     wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
     ref = O.vlm_sft_loss([p.float() for p in px], ids, labels, mask, wr, cfg, num_items_in_batch=n_items, packed=True)
     ref.backward()
-    assert abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref)), (float(loss), float(ref))
-    grads = tr.flat.named_grads()
-    bad, worst = [], (1.0, 0.0)
-    for name, gref in ((k, v.grad) for k, v in wr.items()):
-        if name not in grads or gref is None:
-            continue
-        got = grads[name].float().cpu()
-        if float(gref.norm()) < 1e-6:
-            assert float(got.norm()) < 1e-3, name
-            continue
-        cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
-        rel = rel_l2(got, gref)
-        worst = (min(worst[0], cos), max(worst[1], rel))
-        if cos < cos_min or rel > rel_max:
-            bad.append((name, round(cos, 4), round(rel, 4)))
-    assert not bad, bad
-    return tr, float(loss), float(ref), worst
+    out = []
+    for use_c in c_abi:
+        model = build_model(cfg, weights=w)
+        tr = SFTTrainer(model, optimizer_state=False)
+        fb = tr.forward_backward_c if use_c else tr.forward_backward
+        loss = fb(ids, [p.cuda() for p in px], labels, mask, n_items)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref)), (use_c, float(loss), float(ref))
+        grads = tr.flat.named_grads()
+        bad, worst = [], (1.0, 0.0)
+        for name, gref in ((k, v.grad) for k, v in wr.items()):
+            if name not in grads or gref is None:
+                continue
+            got = grads[name].float().cpu()
+            if float(gref.norm()) < 1e-6:
+                assert float(got.norm()) < 1e-3, name
+                continue
+            cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
+            rel = rel_l2(got, gref)
+            worst = (min(worst[0], cos), max(worst[1], rel))
+            if cos < cos_min or rel > rel_max:
+                bad.append((name, round(cos, 4), round(rel, 4)))
+        assert not bad, (use_c, bad)
+        out.append((tr, float(loss), float(ref), worst))
+        del model
+    return out
 
 
 @pytest.mark.parametrize("proj", ["mlp_downsample", "mlp_downsample_3x3_fix"])
 def test_sft_forward_backward_matches_oracle_autograd(proj):
+    """Both drivers: the Python-orchestrated operator calls and ONE `vila_sft_fwd_bwd` call with the grad-ready callback."""
     from vila_amd import configs
     cfg = configs.tiny(proj, tied=(proj != "mlp_downsample"))
     g = torch.Generator().manual_seed(22)
@@ -228,10 +237,11 @@ def test_sft_forward_backward_matches_oracle_autograd(proj):
     ids[1, 0] = cfg.image_token_id; ids[1, 5] = cfg.image_token_id
     mask = torch.ones(2, L, dtype=torch.bool); mask[0, 11:] = False
     labels = torch.randint(0, 900, (2, L), generator=g); labels[:, :6] = -100
-    tr, _, _, _ = _sft_vs_oracle(cfg, 3, ids, labels, mask, 3)
-    # the gradient buckets were announced in backward order and cover the exchange
-    order = [p for p, _, _ in tr.reducer.log]
-    assert order[0] in ("llm.lm_head.", "llm.model.norm.") and order[-1].endswith("embeddings.")
+    res = _sft_vs_oracle(cfg, 3, ids, labels, mask, 3, c_abi=(False, True))
+    # the gradient buckets were announced in backward order and cover the exchange — identically by both drivers
+    orders = [[p for p, _, _ in tr.reducer.log] for tr, _, _, _ in res]
+    assert orders[0] == orders[1]
+    assert orders[0][0] in ("llm.lm_head.", "llm.model.norm.") and orders[0][-1].endswith("embeddings.")
 
 
 def test_sft_forward_backward_at_8b_widths_matches_oracle_autograd():
@@ -246,8 +256,9 @@ def test_sft_forward_backward_at_8b_widths_matches_oracle_autograd():
     labels = ids.clone()
     labels[:, : 1 + T - 256] = -100
     mask = torch.ones_like(ids, dtype=torch.bool)
-    tr, loss, ref, worst = _sft_vs_oracle(cfg, 17, ids, labels, mask, b)
-    print(f"8B-width SFT fwd+bwd: loss {loss:.5f} vs oracle {ref:.5f}; worst grad cosine {worst[0]:.4f}, worst rel-L2 {worst[1]:.4f}")
+    for use_c, (tr, loss, ref, worst) in zip((False, True), _sft_vs_oracle(cfg, 17, ids, labels, mask, b, c_abi=(False, True))):
+        print(f"8B-width SFT fwd+bwd ({'one vila_sft_fwd_bwd call' if use_c else 'python-orchestrated'}): loss {loss:.5f} vs oracle {ref:.5f}; "
+              f"worst grad cosine {worst[0]:.4f}, worst rel-L2 {worst[1]:.4f}")
 
 
 def test_sft_step_updates_parameters_and_lowers_loss():

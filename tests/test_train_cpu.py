@@ -110,3 +110,29 @@ def test_count_targets_matches_packed_labels():
     rp = host.repack(plan.mask, plan.labels)
     tgt = rp.labels[1:]
     assert count_targets(ids, labels, mask, cfg.image_token_id) == int((tgt != -100).sum())
+
+
+def test_optimizer_state_roundtrip_and_master_resync(tmp_path):
+    """A resume needs the fp32 master copy and the AdamW moments next to the three bf16 model folders; and loading weights behind a live
+    trainer must be followed by sync_master_from_params (or the next step would write the stale master over them)."""
+    from vila_amd import checkpoint
+    from vila_amd.train import SFTTrainer
+    m = _tiny_model()
+    tr = SFTTrainer(m, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    tr.flat.m.copy_(torch.randn(tr.flat.numel, generator=g)); tr.flat.v.copy_(torch.rand(tr.flat.numel, generator=g))
+    tr.flat.master.add_(torch.randn(tr.flat.numel, generator=g) * 1e-3)
+    tr.flat.step_count = 17
+    d = str(tmp_path / "ck")
+    checkpoint.save_pretrained(m, d)
+    checkpoint.save_optimizer(tr, d, max_shard_bytes=1 << 20)
+    m2 = _tiny_model()
+    tr2 = SFTTrainer(m2, lr=1e-3)
+    checkpoint.load_weights_into(m2, d)
+    tr2.flat.sync_master_from_params()
+    assert torch.equal(tr2.flat.master, tr2.flat.params.float())
+    checkpoint.load_optimizer(tr2, d)
+    assert tr2.flat.step_count == 17
+    for a, b in ((tr.flat.master, tr2.flat.master), (tr.flat.m, tr2.flat.m), (tr.flat.v, tr2.flat.v)):
+        assert torch.equal(a, b)
+    assert torch.equal(tr2.flat.params, tr.flat.master.to(torch.bfloat16))

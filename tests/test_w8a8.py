@@ -36,7 +36,11 @@ def test_gemm_w8a8_matches_integer_reference(M, N, K, epi):
     wq, sw = quantize_w8(w)
     # the quantiser itself: same grid as the host rule
     xs = (x.float().abs().amax(-1) / 127).clamp_min(1e-30)
-    assert torch.allclose(sx, xs, rtol=1e-6) and torch.equal(xq.cpu(), torch.round(x.float() / xs[:, None]).clamp(-127, 127).to(torch.int8).cpu())
+    assert torch.allclose(sx, xs, rtol=1e-6)
+    want = torch.round(x.float() / xs[:, None]).clamp(-127, 127)
+    diff = (xq.float() - want).abs()
+    # same grid; a quotient that lands within an ulp of k + 0.5 may round to the neighbour (two division routines): at most 1 step, rarely
+    assert float(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3, (float(diff.max()), float((diff > 0).float().mean()))
     acc = (xq.double().cpu() @ wq.double().cpu().t())
     ref = acc * sx.double().cpu()[:, None] * sw.double().cpu()[None, :] + bias.double().cpu()
     if epi == 1:

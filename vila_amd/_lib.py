@@ -67,6 +67,18 @@ class VilaDecodeState(C.Structure):
                 ("max_out", c_int), ("logits", c_void_p)]
 
 
+class VilaSftBatch(C.Structure):
+    _fields_ = [("pixels", c_void_p), ("n_images", c_int), ("total_tokens", c_int),
+                ("txt_src", c_void_p), ("txt_dst", c_void_p), ("n_txt", c_int),
+                ("feat_src", c_void_p), ("feat_dst", c_void_p), ("n_feat", c_int),
+                ("nl_src", c_void_p), ("nl_dst", c_void_p), ("n_nl", c_int),
+                ("positions", c_void_p), ("cu_seqlens", c_void_p), ("n_seq", c_int), ("max_seqlen", c_int),
+                ("target_rows", c_void_p), ("targets", c_void_p), ("n_targets", c_int), ("loss_scale", c_float)]
+
+
+GRAD_READY_CB = C.CFUNCTYPE(None, c_void_p, c_int, c_int)
+BUCKET_LM_HEAD, BUCKET_FINAL_NORM, BUCKET_LLM_LAYER, BUCKET_EMBED, BUCKET_PROJECTOR, BUCKET_VIT_LAYER, BUCKET_VIT_EMBED = range(7)
+
 # name -> (restype, argtypes); every symbol include/vila_hip.h declares
 PROTOTYPES = {
     "vila_last_error": (C.c_char_p, []),
@@ -144,6 +156,10 @@ PROTOTYPES = {
     "vila_llm_decode_step_w4": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),
                                         C.POINTER(VilaDecodeState), c_void_p, c_size_t, c_void_p]),
     "vila_video_pool_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "vila_sft_workspace_bytes": (c_size_t, [C.POINTER(VilaVitWeights), C.POINTER(VilaProjWeights), C.POINTER(VilaLlmWeights), C.POINTER(VilaSftBatch)]),
+    "vila_sft_fwd_bwd": (c_int, [C.POINTER(VilaVitWeights), C.POINTER(VilaVitWeights), C.POINTER(VilaProjWeights), C.POINTER(VilaProjWeights),
+                                 C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmWeights), C.POINTER(VilaSftBatch), c_void_p, c_void_p, c_size_t,
+                                 GRAD_READY_CB, c_void_p, c_void_p]),
     "vila_s2_merge_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
 }
 

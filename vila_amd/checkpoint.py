@@ -167,3 +167,56 @@ def load_pretrained(model_dir: str, device="cuda", dtype=torch.bfloat16):
     model = HipLlavaLlamaModel(cfg, device, dtype)
     load_weights_into(model, model_dir)
     return model
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# optimizer state (resume of an SFT run: the three model folders hold bf16 weights only)
+# ----------------------------------------------------------------------------------------------------------------------
+def save_optimizer(trainer, output_dir: str, max_shard_bytes: int = 4 << 30) -> None:
+    """<dir>/optimizer/: fp32 master copy, exp_avg, exp_avg_sq of the flat parameter buffer (sharded safetensors) + the step count and
+    the name -> (offset, numel, shape) index, so that a resume does not depend on the in-memory layout of this build."""
+    f = trainer.flat
+    if f.master is None:
+        raise ValueError("the trainer was built without optimizer state")
+    folder = os.path.join(output_dir, "optimizer")
+    os.makedirs(folder, exist_ok=True)
+    per = max(1, max_shard_bytes // 4)
+    files = []
+    for key, t in (("master", f.master), ("exp_avg", f.m), ("exp_avg_sq", f.v)):
+        for i, o in enumerate(range(0, f.numel, per)):
+            name = f"{key}-{i:05d}.safetensors"
+            save_file({key: t[o:o + per].detach().to("cpu").contiguous()}, os.path.join(folder, name), metadata={"format": "pt"})
+            files.append({"file": name, "key": key, "offset": o, "numel": int(min(per, f.numel - o))})
+    meta = {"step": int(f.step_count), "numel": int(f.numel), "files": files,
+            "index": {n: [int(o), int(k), list(shape)] for n, (o, k, shape) in f.index.items()},
+            "hyper": {"lr": trainer.lr, "betas": list(trainer.betas), "eps": trainer.eps, "weight_decay": trainer.wd}}
+    with open(os.path.join(folder, "optimizer.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
+def load_optimizer(trainer, model_dir: str) -> None:
+    """Inverse of save_optimizer.  Tensors are matched BY NAME through the saved index (a different flat layout is fine); the bf16
+    parameters are re-derived from the restored master copy, as an AdamW step would leave them."""
+    f = trainer.flat
+    folder = os.path.join(model_dir, "optimizer")
+    meta = json.load(open(os.path.join(folder, "optimizer.json")))
+    bufs = {"master": f.master, "exp_avg": f.m, "exp_avg_sq": f.v}
+    same_layout = meta["numel"] == f.numel and all(n in f.index and list(f.index[n][:2]) == v[:2] for n, v in meta["index"].items())
+    with torch.no_grad():
+        for ent in meta["files"]:
+            with safe_open(os.path.join(folder, ent["file"]), framework="pt", device="cpu") as fh:
+                chunk = fh.get_tensor(ent["key"])
+            o, k = ent["offset"], ent["numel"]
+            if same_layout:
+                bufs[ent["key"]][o:o + k].copy_(chunk)
+                continue
+            for n, (so, sk, _) in meta["index"].items():          # re-map tensor by tensor
+                lo, hi = max(so, o), min(so + sk, o + k)
+                if lo < hi and n in f.index:
+                    do = f.index[n][0]
+                    bufs[ent["key"]][do + (lo - so): do + (hi - so)].copy_(chunk[lo - o: hi - o])
+        missing = [n for n in f.index if n not in meta["index"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks tensors: {missing[:8]}")
+        f.params.copy_(f.master)
+    f.step_count = int(meta["step"])

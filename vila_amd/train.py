@@ -225,6 +225,7 @@ class SFTTrainer:
         flag = lambda name, default: os.environ.get(name, default) not in ("0", "", "false")
         self.side = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_SIDE", "1")) else None
         self.opt = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_OPT_STREAM", "1")) else None
+        self.use_c_abi = flag("VILA_SFT_C_ABI", "0")            # step(): forward+backward as ONE vila_sft_fwd_bwd call (else Python-orchestrated ops)
         self.lean_adamw = flag("VILA_SFT_LEAN_ADAMW", "1")      # <= 32-VGPR optimizer kernel: co-resident with the GEMM blocks
         self.cm = flag("VILA_SFT_CM", "1")  # dgrad / wgrad on the tensors as they lie (no transposed copies) where the shapes allow
         self.ws = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if on_gpu else None      # split-K slabs (lm_head dgrad)
@@ -425,6 +426,142 @@ class SFTTrainer:
             self._ready(l)
         return dx
 
+    # ------------------------------------------------------------------ one C-ABI call ------------------------------------
+    def _c_structs(self, ptr):
+        """(VilaVitWeights, VilaProjWeights, VilaLlmWeights) whose pointers come from `ptr(name)`: flat.param for the weights, flat.grad for
+        the mirror structs vila_sft_fwd_bwd writes the gradients through (same names, same shapes: SURVEY Appendix C)."""
+        import ctypes as C
+        from . import _lib
+        cfg, v, c = self.cfg, self.cfg.vision, self.cfg.llm
+        keep = []
+        pre = "vision_tower.vision_tower.vision_model."
+        n_run = v.num_used_layers
+        vl = (_lib.VilaVitLayer * max(n_run, 1))()
+        for i in range(n_run):
+            l, L = f"{pre}encoder.layers.{i}.", vl[i]
+            L.ln1_w, L.ln1_b = ptr(l + "layer_norm1.weight"), ptr(l + "layer_norm1.bias")
+            for k in ("q", "k", "v"):
+                setattr(L, "w" + k, ptr(l + f"self_attn.{k}_proj.weight")); setattr(L, "b" + k, ptr(l + f"self_attn.{k}_proj.bias"))
+            L.wo, L.bo = ptr(l + "self_attn.out_proj.weight"), ptr(l + "self_attn.out_proj.bias")
+            L.ln2_w, L.ln2_b = ptr(l + "layer_norm2.weight"), ptr(l + "layer_norm2.bias")
+            L.fc1_w, L.fc1_b, L.fc2_w, L.fc2_b = ptr(l + "mlp.fc1.weight"), ptr(l + "mlp.fc1.bias"), ptr(l + "mlp.fc2.weight"), ptr(l + "mlp.fc2.bias")
+        vw = _lib.VilaVitWeights()
+        vw.shape = _lib.VilaVitShape(v.hidden_size, v.intermediate_size, v.num_attention_heads, v.image_size, v.patch_size, v.num_channels, n_run, v.layer_norm_eps)
+        vw.patch_w, vw.patch_b, vw.pos_emb = ptr(pre + "embeddings.patch_embedding.weight"), ptr(pre + "embeddings.patch_embedding.bias"), ptr(pre + "embeddings.position_embedding.weight")
+        vw.layers = C.cast(vl, C.POINTER(_lib.VilaVitLayer))
+        pw = _lib.VilaProjWeights()
+        pw.kind = {"mlp_downsample": 0, "mlp_downsample_2x2_fix": 1, "mlp_downsample_3x3_fix": 2}[cfg.mm_projector_type]
+        pw.in_dim, pw.out_dim = cfg.mm_hidden_size, c.hidden_size
+        g = lambda i, n: ptr(f"mm_projector.layers.{i}.{n}")
+        pw.ln1_w, pw.ln1_b, pw.fc1_w, pw.fc1_b = g(1, "weight"), g(1, "bias"), g(2, "weight"), g(2, "bias")
+        if pw.kind == 2:
+            pw.ln2_w, pw.ln2_b, pw.fc2_w, pw.fc2_b, pw.fc3_w, pw.fc3_b = g(4, "weight"), g(4, "bias"), g(5, "weight"), g(5, "bias"), g(7, "weight"), g(7, "bias")
+        else:
+            pw.fc2_w, pw.fc2_b = g(4, "weight"), g(4, "bias")
+        ll = (_lib.VilaLlmLayer * c.num_hidden_layers)()
+        for i in range(c.num_hidden_layers):
+            l, L = f"llm.model.layers.{i}.", ll[i]
+            L.ln1_w, L.ln2_w = ptr(l + "input_layernorm.weight"), ptr(l + "post_attention_layernorm.weight")
+            for k in ("q", "k", "v"):
+                setattr(L, "w" + k, ptr(l + f"self_attn.{k}_proj.weight")); setattr(L, "b" + k, ptr(l + f"self_attn.{k}_proj.bias"))
+            L.wo = ptr(l + "self_attn.o_proj.weight")
+            L.w_gate, L.w_up, L.w_down = ptr(l + "mlp.gate_proj.weight"), ptr(l + "mlp.up_proj.weight"), ptr(l + "mlp.down_proj.weight")
+        lw = _lib.VilaLlmWeights()
+        lw.shape = _lib.VilaLlmShape(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim,
+                                     c.vocab_size, c.rms_norm_eps, c.rope_theta)
+        lw.embed, lw.norm_w = ptr("llm.model.embed_tokens.weight"), ptr("llm.model.norm.weight")
+        lw.lm_head = lw.embed if c.tie_word_embeddings else ptr("llm.lm_head.weight")
+        lw.layers = C.cast(ll, C.POINTER(_lib.VilaLlmLayer))
+        keep += [vl, ll]
+        return vw, pw, lw, keep
+
+    def forward_backward_c(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
+                           attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None) -> torch.Tensor:
+        """forward_backward through ONE C-ABI call (`vila_sft_fwd_bwd`): the host plans the splice / pack (integers only), the library
+        runs every forward and backward kernel and calls back per gradient bucket, where this class starts the exchange + AdamW on its
+        optimizer stream exactly as the Python-orchestrated path does."""
+        import ctypes as C
+        from . import _lib
+        from ._lib import check
+        model, cfg, flat = self.model, self.cfg, self.flat
+        if getattr(cfg, "dynamic_s2", False):
+            raise NotImplementedError("SFTTrainer: the dynamic_s2 merge (llava_arch.py:298-390) has no backward here")
+        dev = model.device
+        for st in (self.opt, self.side):
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
+        flat.grads.zero_()
+        self.reducer.log.clear()
+        c = cfg.llm
+        n_img = len(images)
+        Tm = cfg.tokens_per_tile
+        pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
+        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right",
+                           max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
+        rp = repack(plan.mask, plan.labels)
+        T = int(rp.rows.numel())
+        inv = torch.full((plan.B * plan.S,), -1, dtype=torch.int64)
+        inv[rp.rows] = torch.arange(T)
+        i32 = lambda t: t.to(torch.int32).contiguous().to(dev)
+        txt_src, txt_dst = i32(plan.txt_src), i32(inv[plan.txt_dst.long()])
+        src = plan.img_src.long()
+        dst_p = inv[plan.img_dst.long()]
+        is_nl = (src % (Tm + 1)) == Tm
+        feat_src, feat_dst, nl_dst = i32(((src // (Tm + 1)) * Tm + src % (Tm + 1))[~is_nl]), i32(dst_p[~is_nl]), i32(dst_p[is_nl])
+        nl_src = torch.full((int(nl_dst.numel()),), cfg.newline_token_id, dtype=torch.int32, device=dev)
+        tgt = torch.full((T,), IGNORE_INDEX, dtype=torch.int64)
+        tgt[:-1] = rp.labels[1:]
+        valid = torch.nonzero(tgt != IGNORE_INDEX, as_tuple=False).flatten()
+        n_valid = int(valid.numel())
+        n_items = n_valid if num_items_in_batch is None else int(num_items_in_batch)
+        rows32, tg = i32(valid), tgt[valid].contiguous().to(dev)
+        pos, cu = i32(rp.position_ids), i32(rp.cu_seqlens)
+        b = _lib.VilaSftBatch()
+        P = lambda t: t.data_ptr() if t is not None and t.numel() else None
+        b.pixels, b.n_images, b.total_tokens = P(pixels), n_img, T
+        b.txt_src, b.txt_dst, b.n_txt = P(txt_src), P(txt_dst), int(txt_src.numel())
+        b.feat_src, b.feat_dst, b.n_feat = P(feat_src), P(feat_dst), int(feat_dst.numel())
+        b.nl_src, b.nl_dst, b.n_nl = P(nl_src), P(nl_dst), int(nl_dst.numel())
+        b.positions, b.cu_seqlens, b.n_seq, b.max_seqlen = P(pos), P(cu), int(cu.numel()) - 1, int(rp.max_seqlen)
+        b.target_rows, b.targets, b.n_targets, b.loss_scale = P(rows32), P(tg), n_valid, 1.0 / max(n_items, 1)
+        if getattr(self, "_cw", None) is None:
+            self._cw = self._c_structs(lambda n: flat.param(n).data_ptr())
+            self._cg = self._c_structs(lambda n: flat.grad(n).data_ptr())
+        (vw, pw, lw, _), (vg, pg, lg, _) = self._cw, self._cg
+        lib = _lib.load()
+        need = int(lib.vila_sft_workspace_bytes(C.byref(vw), C.byref(pw), C.byref(lw), C.byref(b)))
+        if need == 0:
+            check(-1, "vila_sft_workspace_bytes")
+        if getattr(self, "_c_ws", None) is None or self._c_ws.numel() < need:
+            self._c_ws = None
+            self._c_ws = torch.empty((need,), device=dev, dtype=torch.uint8)
+        loss = torch.zeros((1,), device=dev, dtype=torch.float32)
+        pre_v = "vision_tower.vision_tower.vision_model."
+        names = {_lib.BUCKET_LM_HEAD: lambda i: "llm.lm_head.", _lib.BUCKET_FINAL_NORM: lambda i: "llm.model.norm.",
+                 _lib.BUCKET_LLM_LAYER: lambda i: f"llm.model.layers.{i}.", _lib.BUCKET_EMBED: lambda i: "llm.model.embed_tokens.",
+                 _lib.BUCKET_PROJECTOR: lambda i: "mm_projector.", _lib.BUCKET_VIT_LAYER: lambda i: f"{pre_v}encoder.layers.{i}.",
+                 _lib.BUCKET_VIT_EMBED: lambda i: pre_v + "embeddings."}
+        err = []
+
+        def on_ready(_arg, bucket, index):
+            try:
+                self._ready(names[bucket](index))
+            except BaseException as e:                      # an exception must not unwind through the C frame
+                err.append(e)
+        cb = _lib.GRAD_READY_CB(on_ready)
+        check(lib.vila_sft_fwd_bwd(C.byref(vw), C.byref(vg), C.byref(pw), C.byref(pg), C.byref(lw), C.byref(lg), C.byref(b), loss.data_ptr(),
+                                   self._c_ws.data_ptr(), self._c_ws.numel(), cb, None, ops._stream()), "vila_sft_fwd_bwd")
+        if err:
+            raise err[0]
+        for st in (self.side, self.opt):
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
+        if not self._bucket_step:
+            self.reducer.wait()
+        else:
+            self.reducer.handles = []
+        return loss[0]
+
     # ------------------------------------------------------------------ the step -------------------------------------------
     def forward_backward(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
                          attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None) -> torch.Tensor:
@@ -559,7 +696,8 @@ class SFTTrainer:
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
         try:
-            loss = self.forward_backward(input_ids, images, labels, attention_mask, n_global)
+            fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
+            loss = fb(input_ids, images, labels, attention_mask, n_global)
             self.optimizer_step()
         finally:
             self._bucket_step = False
