@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
         {"dgrad down b_cm", 3076, 18944, 3584, 0, 1, 0}, {"dgrad down cc (old path)", 3076, 18944, 3584, 0, 0, 0},
     };
     if (!strcmp(what, "lay")) for (auto& c : lay) run_case(c, {0, 1}, ws, ws_bytes);
-    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 1, 2, 9}, ws, ws_bytes);
+    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 10}, ws, ws_bytes);
     if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 1}, ws, ws_bytes);     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
     return 0;
 }

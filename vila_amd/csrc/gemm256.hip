@@ -68,7 +68,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
-int g_gemm256_sched = 0;      // tuning hook (vila_gemm_force_sched): 0 = default schedule of each layout, 1 / 2 / 9 = gemm256_kernel.h SCHED
+int g_gemm256_sched = 0;      // tuning hook (vila_gemm_force_sched): 0 = default schedule of each layout; 1 / 2 / 9 = gemm256_kernel.h SCHED, 10 = SCHED 0
 extern "C" void vila_gemm_force_sched(int sched) { g_gemm256_sched = sched; }
 int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       // gemm256_cm.hip
 int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
@@ -98,10 +98,10 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
         splits = cdiv(kt, per);
         const int tc = tail_tn * 128 < a.N - full_tn * 128 ? tail_tn * 128 : a.N - full_tn * 128;      // output columns of the tail
         if (splits >= 2 && (size_t)splits * 2 * a.M * tc * 4 <= a.ws_bytes && tc % 4 == 0) {
-            VILA_TRY((launch256_t<2, EPI_NONE>(a, s, 1, 0, full_tn * tiles_m)));
+            VILA_TRY((launch256_t<2, EPI_NONE, false, false, T256_CC_SCHED>(a, s, 1, 0, full_tn * tiles_m)));
             GemmArgs b = a;
             b.C = a.ws; b.ldc = tc;
-            VILA_TRY((launch256_t<4, EPI_NONE>(b, s, splits, full_tn * tiles_m, tail_tiles, full_tn * 128, per)));
+            VILA_TRY((launch256_t<4, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, full_tn * tiles_m, tail_tiles, full_tn * 128, per)));
             const int64_t total = (int64_t)a.M * (tc / 4);
             const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             hipLaunchKernelGGL(splitk_gu_reduce_kernel, dim3(grid), dim3(256), 0, s, a.ws, splits, (bf16_t*)a.C, a.ldc, a.M, tc, full_tn * 128);
@@ -109,18 +109,18 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
             return 0;
         }
     }
-    return launch256_t<2, EPI_NONE>(a, s);
+    return launch256_t<2, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
     if (a.a_cm || a.b_cm) return launch_gemm256_cm(a, s);
     if (g_gemm256_sched != 0 && a.epi == EPI_NONE && !a.out_f32) return launch_gemm256_sched(a, g_gemm256_sched, s);
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
-    if (a.out_f32) return launch256_t<1, EPI_NONE>(a, s);
+    if (a.out_f32) return launch256_t<1, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
     switch (a.epi) {
-        case EPI_NONE: return launch256_t<0, EPI_NONE>(a, s);
-        case EPI_GELU_TANH: return launch256_t<0, EPI_GELU_TANH>(a, s);
-        case EPI_GELU_ERF: return launch256_t<0, EPI_GELU_ERF>(a, s);
+        case EPI_NONE: return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
+        case EPI_GELU_TANH: return launch256_t<0, EPI_GELU_TANH, false, false, T256_CC_SCHED>(a, s);
+        case EPI_GELU_ERF: return launch256_t<0, EPI_GELU_ERF, false, false, T256_CC_SCHED>(a, s);
     }
     VILA_FAIL(-1, "gemm256: unsupported epilogue %d", a.epi);
 }
@@ -133,7 +133,7 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
     GemmArgs b = a;
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
     if (a.a_cm || a.b_cm) VILA_TRY(launch_gemm256_cm_splitk(b, splits, slab, per, s));
-    else VILA_TRY((launch256_t<3, EPI_NONE>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
+    else VILA_TRY((launch256_t<3, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,

@@ -41,6 +41,7 @@ int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s) {
         case 1: return launch256_t<0, EPI_NONE, false, false, 1>(a, s);
         case 2: return launch256_t<0, EPI_NONE, false, false, 2>(a, s);
         case 9: return launch256_t<0, EPI_NONE, false, false, 9>(a, s);
-        default: return launch256_t<0, EPI_NONE, false, false, 0>(a, s);
+        case 10: return launch256_t<0, EPI_NONE, false, false, 0>(a, s);     // round-1 schedule (one tile ahead, fragments read per phase)
+        default: return launch256_t<0, EPI_NONE, false, false, 3>(a, s);
     }
 }

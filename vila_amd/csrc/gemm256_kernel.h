@@ -30,6 +30,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
+constexpr int T256_CC_SCHED = 3;   // default schedule of the forward (contraction-contiguous) layout: register-pipelined fragments
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised); one per translation unit (no RDC)
 
 // MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
@@ -89,30 +90,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     const int lds_lane_base = __builtin_amdgcn_readfirstlane(wave * 1024);   // wave-uniform: 64 lanes x 16 B per DMA
     const int kt0 = SPLIT ? blockIdx.y * k_tiles_per_split : 0;
 
+    // K-tail source, pinned into an SGPR pair ONCE: left to itself the compiler re-loads the symbol's address from the GOT in front of every
+    // DMA (s_load + s_waitcnt lgkmcnt(0)), and that wait also drains every LDS fragment read in flight
+    const bf16_t* zero_src = (const bf16_t*)g_zero_chunk;
+    asm volatile("" : "+s"(zero_src));
+    // source pointer of one piece; tiles that lie entirely inside K (block-uniform test) take the plain address, a ragged LAST K-tile the per-lane
+    // select against the zero chunk
+    auto piece_src = [&](int k0, bool is_b, int h, int i) -> const bf16_t* {
+        const bool cm = is_b ? BCM : ACM;
+        const bf16_t* base = is_b ? ((GU && b_up[h][i]) ? p.W2 : p.W) : p.A;
+        const uint32_t off = is_b ? boff[h][i] : aoff[h][i];
+        const int64_t ld = is_b ? p.ldw : p.lda;
+        const bf16_t* src = cm ? base + off + (int64_t)k0 * ld : base + off + k0;
+        if (k0 + T256_BK > p.K) {
+            const bool kin = cm ? (k0 + cm_k + 32 * i < p.K) : (k0 + kch * 8 < p.K);
+            src = kin ? src : zero_src;
+        }
+        return src;
+    };
     // one piece = one LDS-DMA per thread (8 KB): which in {A, B}, half h, round i
     auto issue_piece = [&](int t, int buf, bool is_b, int h, int i) {
         const int k0 = (kt0 + t) * T256_BK;
         char* dst = smem + buf * BUF_BYTES + lds_lane_base + ((is_b ? 2 : 0) + h) * HALF_BYTES + i * 8192;
-        const bf16_t* src;
-        if (!is_b) {
-            if constexpr (ACM) {
-                const bool kin = k0 + cm_k + 32 * i < p.K;
-                src = kin ? p.A + aoff[h][i] + (int64_t)k0 * p.lda : (const bf16_t*)g_zero_chunk;
-            } else {
-                const bool kin = k0 + kch * 8 < p.K;
-                src = kin ? p.A + aoff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
-            }
-        } else {
-            if constexpr (BCM) {
-                const bool kin = k0 + cm_k + 32 * i < p.K;
-                src = kin ? p.W + boff[h][i] + (int64_t)k0 * p.ldw : (const bf16_t*)g_zero_chunk;
-            } else {
-                const bf16_t* wsrc = (GU && b_up[h][i]) ? p.W2 : p.W;
-                const bool kin = k0 + kch * 8 < p.K;
-                src = kin ? wsrc + boff[h][i] + k0 : (const bf16_t*)g_zero_chunk;
-            }
-        }
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)piece_src(k0, is_b, h, i), (lds_void*)dst, 16, 0, 0);
     };
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
@@ -150,6 +150,84 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 
     const int kt_all = (p.K + T256_BK - 1) / T256_BK;
     const int nt = SPLIT ? ((kt_all - kt0) < k_tiles_per_split ? (kt_all - kt0) : k_tiles_per_split) : kt_all;   // last slice may be shorter
+    if constexpr (SCHED == 3) {
+        // Register-pipelined fragments: every ds_read is issued one phase (16 MFMAs) before its first use, ONE barrier per K-tile.
+        //   quadrant order (A0,B0) (A0,B1) (A1,B0) (A1,B1); A1 / B1 of tile t are requested at the top of tile t, A0 / B0 of tile t+1 during
+        //   the last quadrant of tile t — after the tile's only barrier, which is also where tile t+1's DMA is waited for.
+        //   The 8 DMA pieces of tile t+2 are issued in one burst right after that barrier (threading them through the MFMA stream one
+        //   piece per 4 MFMAs via inline asm was measured too: no faster on any SFT shape, 8 % slower on K = 18944 — dropped).
+        static_assert(!(SCHED == 3 && (ACM || BCM)), "SCHED 3 is implemented for the forward layout");
+        bf16x8 A0[4][2], A1[4][2], B0[2][2], B1[2][2];
+        issue_tile(0, 0);
+        if (nt > 1) { issue_tile(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const char* cA = smem + a_half * HALF_BYTES;
+            const char* cB = smem + (2 + b_half) * HALF_BYTES;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) B0[j][ks] = frag_cc(cB, b_row0 + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A0[i][ks] = frag_cc(cA, i * 16, ks);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        // 16 MFMAs of one quadrant
+        auto quadrant = [&](bf16x8 (&A)[4][2], bf16x8 (&Bf)[2][2], int ai, int bj) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ai + i][bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], Bf[j][ks], acc[ai + i][bj + j], 0, 0, 0);
+        };
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
+            const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES;
+            // request B1, A1 of this tile, then quadrant (0,0) on the fragments that are already in registers
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) B1[j][ks] = frag_cc(cB, b_row0 + 32 + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A1[i][ks] = frag_cc(cA, 64 + i * 16, ks);
+            quadrant(A0, B0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);              // keep the quadrants in order: the first one must not wait for the new reads
+            quadrant(A0, B1, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            quadrant(A1, B0, 4, 0);
+            if (t + 1 < nt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of tile t+1 have landed
+                __builtin_amdgcn_s_barrier();                        // everyone's have; every wave has its fragments of tile t
+                asm volatile("" ::: "memory");
+                if (t + 2 < nt) issue_tile(t + 2, buf);
+                const char* nA = smem + (buf ^ 1) * BUF_BYTES + a_half * HALF_BYTES;
+                const char* nB = smem + (buf ^ 1) * BUF_BYTES + (2 + b_half) * HALF_BYTES;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) B0[j][ks] = frag_cc(nB, b_row0 + j * 16, ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) A0[i][ks] = frag_cc(nA, i * 16, ks);
+            }
+            quadrant(A1, B1, 4, 2);
+            // the A0 / B0 reads of the next tile were issued 16 MFMAs ago: retire them HERE (free), so that the compiler's wait-count
+            // bookkeeping carries no pending LDS read over the back edge (it would otherwise wait for ALL reads before the first MFMA)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     constexpr bool DEEP = (SCHED == 1 || SCHED == 2);
     issue_tile(0, 0);
     if (DEEP && nt > 1) issue_tile(1, 1);
@@ -248,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf0[j][ks], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+    }
     }
     __syncthreads();   // all LDS reads of the last tile done before the staging area is reused
 
