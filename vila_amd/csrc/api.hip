@@ -275,6 +275,9 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     bf16_t* taps = B(layer_hidden);
     if (taps) VILA_HIP(hipMemcpyAsync(taps, x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
 
+    // only last-row logits wanted (generation): the last layer is finished for those rows alone (see below)
+    const bool prune_last = final_hidden == nullptr && all_logits == nullptr && taps == nullptr && cache != nullptr && last_logits != nullptr &&
+                            last_rows != nullptr && n_last >= 1 && n_last <= 4 && H % 8 == 0 && F % 8 == 0 && QS == H;
     const int tail_rows = (T > 256 && T % 256 >= 1 && T % 256 <= 4 && H % 8 == 0 && F % 8 == 0) ? T % 256 : 0;
     const int Tg = T - tail_rows;     // rows of the gate/up and down GEMMs; the rest via GEMV
     for (int l = 0; l < sh.n_layers; ++l) {
@@ -304,6 +307,28 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
         at.scale = 1.0f / sqrtf((float)hd); at.lse = nullptr;
         VILA_REQUIRE(QS == H, "llm: q_heads*head_dim (%d) must equal hidden (%d) for the in-place attention buffer", QS, H);
         VILA_TRY(launch_attn_fwd(at, s));
+        if (l == sh.n_layers - 1 && prune_last) {
+            // Generation prefill: after the last layer's K / V are in the cache only the rows whose logits are asked for feed anything.
+            // Their o_proj, post-attention norm and MLP run as three decode GEMVs per row (weights stream once at HBM rate) instead of
+            // four GEMMs over all T rows: same arithmetic order per row as the decode step, which is parity-tested against this path.
+            VILA_TRY(launch_copy_rows(h, lastbuf, last_rows, nullptr, n_last, QS, s));             // attention output rows
+            VILA_TRY(launch_copy_rows(x, lastbuf + (size_t)n_last * H, last_rows, nullptr, n_last, H, s));   // residual rows
+            for (int r = 0; r < n_last; ++r) {
+                bf16_t* ar = lastbuf + (size_t)r * H;                       // attention row  -> later the row's final hidden state
+                bf16_t* xr = lastbuf + (size_t)(n_last + r) * H;            // residual row
+                bf16_t* fr = act + (size_t)r * F;                           // silu(gate) * up of the row
+                GemvArgs g0{};
+                g0.x = ar; g0.W = B(L.wo); g0.residual = xr; g0.y = xr; g0.N = H; g0.K = QS; g0.mode = 0;
+                VILA_TRY(launch_gemv(g0, s));
+                GemvArgs g1{};
+                g1.x = xr; g1.norm_w = B(L.ln2_w); g1.eps = sh.rms_eps; g1.W = B(L.w_gate); g1.W2 = B(L.w_up); g1.y = fr; g1.N = F; g1.K = H; g1.mode = 1;
+                VILA_TRY(launch_gemv(g1, s));
+                GemvArgs g2{};
+                g2.x = fr; g2.W = B(L.w_down); g2.residual = xr; g2.y = ar; g2.N = H; g2.K = F; g2.mode = 0;
+                VILA_TRY(launch_gemv(g2, s));
+            }
+            break;
+        }
         VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes));   // x += o_proj(attn)
         VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
         // MLP.  A prompt of 3 x 256 + 1 tokens (the benchmark's 769) would spend a whole extra row-tile round on ONE row in the two
@@ -331,7 +356,7 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     }
     if (n_last > 0 && last_logits != nullptr) {
         VILA_REQUIRE(last_rows != nullptr, "llm_prefill: last_rows is NULL");
-        VILA_TRY(launch_copy_rows(x, lastbuf, last_rows, nullptr, n_last, H, s));
+        if (!prune_last) VILA_TRY(launch_copy_rows(x, lastbuf, last_rows, nullptr, n_last, H, s));     // (pruned: lastbuf already holds the rows)
         if (n_last == 1) {
             GemvArgs g{};
             g.x = lastbuf; g.norm_w = B(w->norm_w); g.eps = sh.rms_eps; g.W = B(w->lm_head); g.y_f32 = last_logits;

@@ -7,7 +7,7 @@
 // (row maps, restarted positions, cu_seqlens, target rows) is planned on the host and handed in as index arrays (VilaSftBatch).
 // The same sequence of kernels as vila_amd/train.py (which remains the Python mirror): explicit backward, no autograd graph, saved
 // activations in the caller's workspace (no re-computation: 288 GB of HBM), dgrad / wgrad of the decoder and the head on the tensors as
-// they lie (contraction-major GEMM operands), the small ViT / projector GEMMs through transposed copies.
+// they lie (contraction-major GEMM operands; VILA_SFT_CM_VIT=0 sends the small ViT / projector GEMMs through transposed copies).
 // After the LAST kernel touching a gradient bucket has been enqueued the host callback `cb(arg, bucket, index)` runs on the calling
 // thread: that is where a caller records an event and starts the bucket's all-reduce / optimizer on its own streams (DDP-style overlap).
 // Buckets arrive in backward order: LM_HEAD (untied only), FINAL_NORM, LLM_LAYER n-1 .. 0, EMBED, PROJECTOR, VIT_LAYER n-1 .. 0, VIT_EMBED.
@@ -40,6 +40,8 @@ struct Ctx { hipStream_t s; Ws* w; bool dry; float* gws; size_t gws_bytes; };
 // VILA_SFT_DEBUG=1: name every launch on stderr before it is enqueued and wait for it (a device fault then points at its kernel)
 static bool sft_debug() { static int v = -1; if (v < 0) { const char* e = getenv("VILA_SFT_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
 #define SFT_TRACE(what) do { if (!c.dry && sft_debug()) { (void)hipStreamSynchronize(c.s); fprintf(stderr, "sft[%s:%d] off=%zu %s\n", __func__, __LINE__, c.w->off, what); fflush(stderr); } } while (0)
+// VILA_SFT_CM_VIT=0: tower / projector dgrad + wgrad through transposed copies (the round-1 path) instead of contraction-major operands
+static bool vit_cm() { static int v = -1; if (v < 0) { const char* e = getenv("VILA_SFT_CM_VIT"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
 #define RUN(call) do { if (!c.dry) { SFT_TRACE(#call); VILA_TRY(call); } } while (0)
 
 int gemm(Ctx& c, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const bf16_t* bias, const bf16_t* res, int64_t ldr, void* C, int64_t ldc,
@@ -303,17 +305,17 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     bf16_t* dz1 = nullptr;
     if (kdown == 2) {
         bf16_t* dh1 = a.take<bf16_t>((size_t)Mp_ * H);
-        VILA_TRY(linear_bwd(c, p_h1, B(pj->fc2_w), dproj, B((void*)pg->fc2_w), B((void*)pg->fc2_b), dh1, nullptr, Mp_, H, H, false));
+        VILA_TRY(linear_bwd(c, p_h1, B(pj->fc2_w), dproj, B((void*)pg->fc2_w), B((void*)pg->fc2_b), dh1, nullptr, Mp_, H, H, vit_cm(), true));
         dz1 = a.take<bf16_t>((size_t)Mp_ * H);
         RUN(launch_act_bwd(p_z1, dh1, dz1, (int64_t)Mp_ * H, 2, c.s));
     } else {
         const int C3 = 3 * D;
         bf16_t* dh2 = a.take<bf16_t>((size_t)Mp_ * H);
-        VILA_TRY(linear_bwd(c, p_h2, B(pj->fc3_w), dproj, B((void*)pg->fc3_w), B((void*)pg->fc3_b), dh2, nullptr, Mp_, H, H, false));
+        VILA_TRY(linear_bwd(c, p_h2, B(pj->fc3_w), dproj, B((void*)pg->fc3_w), B((void*)pg->fc3_b), dh2, nullptr, Mp_, H, H, vit_cm(), true));
         bf16_t* dz2 = a.take<bf16_t>((size_t)Mp_ * H);
         RUN(launch_act_bwd(p_z2, dh2, dz2, (int64_t)Mp_ * H, 2, c.s));
         bf16_t* dh1n = a.take<bf16_t>((size_t)Mp_ * C3);
-        VILA_TRY(linear_bwd(c, p_h1n, B(pj->fc2_w), dz2, B((void*)pg->fc2_w), B((void*)pg->fc2_b), dh1n, nullptr, Mp_, H, C3, false));
+        VILA_TRY(linear_bwd(c, p_h1n, B(pj->fc2_w), dz2, B((void*)pg->fc2_w), B((void*)pg->fc2_b), dh1n, nullptr, Mp_, H, C3, vit_cm(), true));
         bf16_t* dh1 = a.take<bf16_t>((size_t)Mp_ * C3);
         VILA_TRY(norm_bwd(c, p_h1, B(pj->ln2_w), dh1n, dh1, B((void*)pg->ln2_w), B((void*)pg->ln2_b), Mp_, C3, 1e-5f, 0));
         dz1 = a.take<bf16_t>((size_t)Mp_ * C3);
@@ -321,7 +323,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     }
     const int N1 = (kdown == 2) ? H : 3 * D;
     bf16_t* dyn = a.take<bf16_t>((size_t)Mp_ * C1);
-    VILA_TRY(linear_bwd(c, p_yn, B(pj->fc1_w), dz1, B((void*)pg->fc1_w), B((void*)pg->fc1_b), dyn, nullptr, Mp_, N1, C1, false));
+    VILA_TRY(linear_bwd(c, p_yn, B(pj->fc1_w), dz1, B((void*)pg->fc1_w), B((void*)pg->fc1_b), dyn, nullptr, Mp_, N1, C1, vit_cm(), true));
     bf16_t* dy = a.take<bf16_t>((size_t)Mp_ * C1);
     VILA_TRY(norm_bwd(c, p_y, B(pj->ln1_w), dyn, dy, B((void*)pg->ln1_w), B((void*)pg->ln1_b), Mp_, C1, 1e-5f, 0));
     ready(VILA_BUCKET_PROJECTOR, 0);
@@ -336,17 +338,17 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         VitSaved& s = vsv[l];
         const size_t layer_mark = a.mark();
         bf16_t* df = a.take<bf16_t>((size_t)Mv * Fv);
-        VILA_TRY(linear_bwd(c, s.f, B(L.fc2_w), dv, B((void*)G.fc2_w), B((void*)G.fc2_b), df, nullptr, Mv, D, Fv, false));
+        VILA_TRY(linear_bwd(c, s.f, B(L.fc2_w), dv, B((void*)G.fc2_w), B((void*)G.fc2_b), df, nullptr, Mv, D, Fv, vit_cm(), true));
         bf16_t* dz = a.take<bf16_t>((size_t)Mv * Fv);
         RUN(launch_act_bwd(s.z1, df, dz, (int64_t)Mv * Fv, 1, c.s));
         bf16_t* dh2 = a.take<bf16_t>((size_t)Mv * D);
-        VILA_TRY(linear_bwd(c, s.h2, B(L.fc1_w), dz, B((void*)G.fc1_w), B((void*)G.fc1_b), dh2, nullptr, Mv, Fv, D, false));
+        VILA_TRY(linear_bwd(c, s.h2, B(L.fc1_w), dz, B((void*)G.fc1_w), B((void*)G.fc1_b), dh2, nullptr, Mv, Fv, D, vit_cm(), true));
         bf16_t* dxm = a.take<bf16_t>((size_t)Mv * D);
         VILA_TRY(norm_bwd(c, s.x_mid, B(L.ln2_w), dh2, dxm, B((void*)G.ln2_w), B((void*)G.ln2_b), Mv, D, vs.ln_eps, 0));
         bf16_t* dx_mid = a.take<bf16_t>((size_t)Mv * D);
         RUN(launch_add(dv, dxm, dx_mid, (int64_t)Mv * D, c.s));
         bf16_t* da = a.take<bf16_t>((size_t)Mv * D);
-        VILA_TRY(linear_bwd(c, s.a, B(L.wo), dx_mid, B((void*)G.wo), B((void*)G.bo), da, nullptr, Mv, D, D, false));
+        VILA_TRY(linear_bwd(c, s.a, B(L.wo), dx_mid, B((void*)G.wo), B((void*)G.bo), da, nullptr, Mv, D, D, vit_cm(), true));
         bf16_t* dqkv = a.take<bf16_t>((size_t)Mv * 3 * D);
         float* delta = a.take<float>((size_t)vs.heads * Mv);
         AttnBwdArgs ab{};
@@ -358,7 +360,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         ab.n_q_heads = ab.n_kv_heads = vs.heads; ab.head_dim = hdv; ab.causal = 0; ab.scale = 1.0f / sqrtf((float)hdv); ab.lse = s.lse; ab.delta = delta;
         RUN(launch_attn_bwd(ab, c.s));
         bf16_t* dh1 = a.take<bf16_t>((size_t)Mv * D);
-        VILA_TRY(linear_bwd(c, s.h1, B(L.wq), dqkv, B((void*)G.wq), B((void*)G.bq), dh1, nullptr, Mv, 3 * D, D, false));
+        VILA_TRY(linear_bwd(c, s.h1, B(L.wq), dqkv, B((void*)G.wq), B((void*)G.bq), dh1, nullptr, Mv, 3 * D, D, vit_cm(), true));
         bf16_t* dxi = a.take<bf16_t>((size_t)Mv * D);
         VILA_TRY(norm_bwd(c, s.x_in, B(L.ln1_w), dh1, dxi, B((void*)G.ln1_w), B((void*)G.ln1_b), Mv, D, vs.ln_eps, 0));
         bf16_t* dnext = dv_pp[l & 1] != dv ? dv_pp[l & 1] : dv_pp[(l & 1) ^ 1];

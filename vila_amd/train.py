@@ -168,7 +168,8 @@ def _cm_ok(T: int, N: int, K: int) -> bool:
 
 def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor] = None,
                need_dx: bool = True, dx_residual: Optional[torch.Tensor] = None, dy_t: Optional[torch.Tensor] = None,
-               cm: bool = False, side: Optional["torch.cuda.Stream"] = None, ws: Optional[torch.Tensor] = None):
+               cm: bool = False, side: Optional["torch.cuda.Stream"] = None, ws: Optional[torch.Tensor] = None,
+               ws_side: Optional[torch.Tensor] = None):
     """x2 [M,K], w [N,K], dy2 [M,N]  ->  writes gw [N,K] (and gb [N]); returns dx [M,K] (+ dx_residual).
     cm: read W, dY and X as they lie (vila_gemm_bf16_t: contraction-major operands through the LDS transpose reads) instead of making
     transposed copies.  side: stream for the weight-gradient GEMM — dgrad and wgrad only share inputs, so the two run concurrently
@@ -179,7 +180,7 @@ def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.T
     N = w2.shape[0]
     if cm and _cm_ok(M, N, K):
         def wgrad():
-            ops.gemm_t(dy2, x2, a_cm=True, b_cm=True, out=gw2, ws=ws)            # dW = dY^T X
+            ops.gemm_t(dy2, x2, a_cm=True, b_cm=True, out=gw2, ws=ws_side if (side is not None and ws_side is not None) else ws)   # dW = dY^T X
             if gb is not None:
                 ops.colsum(dy2, gb)
         if side is not None:
@@ -191,7 +192,8 @@ def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.T
             wgrad()
         if not need_dx:
             return None
-        return ops.gemm_t(dy2, w2, b_cm=True, residual=dx_residual, ws=ws if side is None else None)       # dX = dY W (+ residual)
+        # split-K slabs are per stream: with a side stream the dgrad may slice K only when the wgrad has a workspace of its own
+        return ops.gemm_t(dy2, w2, b_cm=True, residual=dx_residual, ws=ws if (side is None or ws_side is not None) else None)   # dX = dY W (+ residual)
     dyt = dy_t if dy_t is not None else ops.transpose(dy2)           # [N, Mp]
     xt = ops.transpose(x2)                                           # [K, Mp]
     ops.gemm(dyt, xt, out=gw2)                                       # dW = dY^T X
@@ -229,6 +231,9 @@ class SFTTrainer:
         self.lean_adamw = flag("VILA_SFT_LEAN_ADAMW", "1")      # <= 32-VGPR optimizer kernel: co-resident with the GEMM blocks
         self.cm = flag("VILA_SFT_CM", "1")  # dgrad / wgrad on the tensors as they lie (no transposed copies) where the shapes allow
         self.ws = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if on_gpu else None      # split-K slabs (lm_head dgrad)
+        # the tower / projector GEMMs (M = 1024 per image, N = 1152): contraction-major too, K-sliced where their 256^2 tiles under-fill
+        self.cm_vit = self.cm and flag("VILA_SFT_CM_VIT", "1")
+        self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.cm_vit and self.side is not None) else None
         self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
 
     def _ready(self, prefix: str) -> None:
@@ -305,20 +310,21 @@ class SFTTrainer:
         P, G = self.flat.param, self.flat.grad
         pre = "vision_tower.vision_tower.vision_model."
         B, N, D, hd, H = saved.B, v.num_patches, v.hidden_size, v.head_dim, v.num_attention_heads
+        kw = dict(cm=self.cm_vit, side=self.side, ws=self.ws, ws_side=self.ws_side) if self.cm_vit else {}
         for i in reversed(range(v.num_used_layers)):
             l = f"{pre}encoder.layers.{i}."
             s = saved.layers[i]
-            df = linear_bwd(s.f, P(l + "mlp.fc2.weight"), dx, G(l + "mlp.fc2.weight"), G(l + "mlp.fc2.bias"))
+            df = linear_bwd(s.f, P(l + "mlp.fc2.weight"), dx, G(l + "mlp.fc2.weight"), G(l + "mlp.fc2.bias"), **kw)
             dz1 = ops.act_bwd(s.z1, df, 1)
-            dh2 = linear_bwd(s.h2, P(l + "mlp.fc1.weight"), dz1, G(l + "mlp.fc1.weight"), G(l + "mlp.fc1.bias"))
+            dh2 = linear_bwd(s.h2, P(l + "mlp.fc1.weight"), dz1, G(l + "mlp.fc1.weight"), G(l + "mlp.fc1.bias"), **kw)
             dxm = ops.norm_bwd(s.x_mid, P(l + "layer_norm2.weight"), dh2, G(l + "layer_norm2.weight"), G(l + "layer_norm2.bias"), v.layer_norm_eps, False)
             dx_mid = ops.add(dx, dxm)
-            da = linear_bwd(s.a.view(B * N, D), P(l + "self_attn.out_proj.weight"), dx_mid, G(l + "self_attn.out_proj.weight"), G(l + "self_attn.out_proj.bias"))
+            da = linear_bwd(s.a.view(B * N, D), P(l + "self_attn.out_proj.weight"), dx_mid, G(l + "self_attn.out_proj.weight"), G(l + "self_attn.out_proj.bias"), **kw)
             dqkv = torch.empty_like(s.qkv)
             q3, d3 = s.qkv.view(B * N, 3 * H, hd), dqkv.view(B * N, 3 * H, hd)
             ops.attn_bwd(q3[:, :H], q3[:, H:2 * H], q3[:, 2 * H:], s.a, da.view(B * N, H, hd), s.lse, False,
                          d3[:, :H], d3[:, H:2 * H], d3[:, 2 * H:], n_seq=B)
-            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"))
+            dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"), **kw)
             dxi = ops.norm_bwd(s.x_in, P(l + "layer_norm1.weight"), dh1, G(l + "layer_norm1.weight"), G(l + "layer_norm1.bias"), v.layer_norm_eps, False)
             dx = ops.add(dx_mid, dxi)
             self._ready(l)
@@ -359,15 +365,16 @@ class SFTTrainer:
         pre = "mm_projector.layers."
         B, T, _ = s.y.shape
         d = dout.reshape(B * T, -1)
+        kw = dict(cm=self.cm_vit, side=self.side, ws=self.ws, ws_side=self.ws_side) if self.cm_vit else {}
         if self.cfg.mm_projector_type == "mlp_downsample_3x3_fix":
-            dh2 = linear_bwd(s.h2, P(pre + "7.weight"), d, G(pre + "7.weight"), G(pre + "7.bias"))
+            dh2 = linear_bwd(s.h2, P(pre + "7.weight"), d, G(pre + "7.weight"), G(pre + "7.bias"), **kw)
             dz2 = ops.act_bwd(s.z2, dh2, 2)
-            dh1n = linear_bwd(s.h1n, P(pre + "5.weight"), dz2, G(pre + "5.weight"), G(pre + "5.bias"))
+            dh1n = linear_bwd(s.h1n, P(pre + "5.weight"), dz2, G(pre + "5.weight"), G(pre + "5.bias"), **kw)
             dh1 = ops.norm_bwd(s.h1, P(pre + "4.weight"), dh1n, G(pre + "4.weight"), G(pre + "4.bias"), 1e-5, False)
         else:
-            dh1 = linear_bwd(s.h1, P(pre + "4.weight"), d, G(pre + "4.weight"), G(pre + "4.bias"))
+            dh1 = linear_bwd(s.h1, P(pre + "4.weight"), d, G(pre + "4.weight"), G(pre + "4.bias"), **kw)
         dz1 = ops.act_bwd(s.z1, dh1, 2)
-        dyn = linear_bwd(s.yn, P(pre + "2.weight"), dz1, G(pre + "2.weight"), G(pre + "2.bias"))
+        dyn = linear_bwd(s.yn, P(pre + "2.weight"), dz1, G(pre + "2.weight"), G(pre + "2.bias"), **kw)
         dy = ops.norm_bwd(s.y.view(B * T, -1), P(pre + "1.weight"), dyn, G(pre + "1.weight"), G(pre + "1.bias"), 1e-5, False)
         self._ready("mm_projector.")
         return ops.depth_to_space(dy.view(B, T, -1), s.g, s.k)
