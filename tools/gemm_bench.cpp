@@ -1,6 +1,6 @@
 // Standalone GEMM micro-benchmark + spot-check for libvila_hip.so (no PyTorch: a gpurun call with it costs seconds, not minutes).
 //   build:  hipcc -O2 -std=c++17 tools/gemm_bench.cpp -o tools/gemm_bench -Lvila_amd/lib -lvila_hip -Wl,-rpath,'$ORIGIN/../vila_amd/lib'
-//   run:    tools/gemm_bench [fwd|bwd|all]
+//   run:    tools/gemm_bench [fwd|bwd|lay|pmc|pol|all]
 // For every shape and DMA schedule (vila_gemm_force_sched): HIP-event timing on the null stream (random uniform [-1,1) bf16 data —
 // the guide's rule 25: never quote zero-filled operands), TFLOP/s, and the max error of 384 sampled outputs against a double-precision
 // dot product on the host, relative to sqrt(K) (the scale of the sum).  Layout flags: a_cm / b_cm = operand stored [K][rows].
@@ -43,12 +43,15 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int sched : scheds) {
         if (sched == 9 && (c.a_cm || c.b_cm)) continue;
-        vila_gemm_force_sched(sched);
+        // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
+        const bool pol = sched >= 100;
+        vila_gemm_force_sched(pol ? 0 : sched);
+        vila_gemm_force_hybrid(pol ? sched == 101 : 1);
         auto call = [&]() {
             int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, W.d, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
             if (rc != 0) { fprintf(stderr, "  %s sched %d: rc=%d %s\n", c.name, sched, rc, vila_last_error()); exit(3); }
         };
-        if (!c.a_cm && !c.b_cm) vila_gemm_force_tile(4);          // forward layout: pin the 256x256 kernel so the schedules are comparable
+        vila_gemm_force_tile((!c.a_cm && !c.b_cm && !pol) ? 4 : 0);          // forward layout: pin the 256x256 kernel so the schedules are comparable
         CK(hipMemset(C, 0xff, (size_t)c.M * c.N * 2));
         for (int i = 0; i < 3; ++i) call();
         CK(hipDeviceSynchronize());
@@ -84,6 +87,7 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     }
     vila_gemm_force_tile(0);
     vila_gemm_force_sched(0);
+    vila_gemm_force_hybrid(1);
     CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
 }
 
@@ -113,8 +117,17 @@ int main(int argc, char** argv) {
         {"dgrad gate b_cm", 3076, 3584, 18944, 0, 1, 0}, {"dgrad gate cc (old path)", 3076, 3584, 18944, 0, 0, 0},
         {"dgrad down b_cm", 3076, 18944, 3584, 0, 1, 0}, {"dgrad down cc (old path)", 3076, 18944, 3584, 0, 0, 0},
     };
+    if (!strcmp(what, "pmc")) {        // counter runs (rocprofv3 --pmc): ONE shape per kernel name, so per-kernel sums are comparable
+        run_case(lay[0], {0, 5, 10}, ws, ws_bytes);
+        run_case(lay[2], {0, 5}, ws, ws_bytes);
+        run_case(lay[3], {0, 5}, ws, ws_bytes);
+    }
+    if (!strcmp(what, "pol")) {        // launch policies off / on, the SFT shapes they target
+        for (int i : {3, 1}) run_case(fwd[i], {100, 101, 100, 101}, ws, ws_bytes);
+        for (int i : {2, 3, 4, 7, 8, 6, 5}) run_case(bwd[i], {100, 101, 100, 101}, ws, ws_bytes);
+    }
     if (!strcmp(what, "lay")) for (auto& c : lay) run_case(c, {0, 1}, ws, ws_bytes);
-    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 10}, ws, ws_bytes);
-    if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 1}, ws, ws_bytes);     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
+    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {5, 6, 5, 6}, ws, ws_bytes);
+    if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 6, 0, 6}, ws, ws_bytes);     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
     return 0;
 }

@@ -213,6 +213,9 @@ int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
 static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 
+// Measured and rejected (tools/gemm_bench pol, profiles/r02_gemm_bench_policies.log): slicing K four ways for ONE under-filled round with a
+// long contraction (SFT down_proj forward / dgrad of gate and up: 182 tiles, 296 K-tiles -> 728 blocks = 2.84 rounds of a quarter of the
+// work).  The slabs (4 x 44 MB written and read) eat the gain: 488 -> 481, 522 -> 545, 559 -> 544 us.
 template <int EPI, bool OUT_F32>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
     int sel = g_force_tile;

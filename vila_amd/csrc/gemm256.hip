@@ -68,11 +68,75 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
+// tail tiles behind whole rounds: out tile (tm, tn) = bf16(sum_s slab[s][t][256][256] + bias + residual); slab slot t holds tile id tile0 + t
+// of the tm-fastest order (the kernel indexes its slab by id - tile0, after its own XCD remap)
+__global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(const float* __restrict__ slab, int splits, int n_tail, int tile0, int tiles_m,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int64_t ldr,
+                                                                 bf16_t* __restrict__ out, int64_t ldc, int M, int N, int res_mod) {
+    const int t = blockIdx.x >> 4, part = blockIdx.x & 15;                   // 16 blocks of 16 rows per tile
+    const int id = t + tile0;
+    const int m0 = (id % tiles_m) * 256, n0 = (id / tiles_m) * 256;
+    const int c = (threadIdx.x & 63) * 4;
+    for (int r = part * 16 + (threadIdx.x >> 6); r < part * 16 + 16; r += 4) {
+        const int gm = m0 + r, gc = n0 + c;
+        if (gm >= M || gc >= N) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < splits; ++sl) {
+            const f32x4 w = *(const f32x4*)(slab + ((int64_t)sl * n_tail + t) * 65536 + r * 256 + c);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        if (bias != nullptr) {
+            const u32x2 b = *(const u32x2*)(bias + gc);
+            v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
+        }
+        if (residual != nullptr) {
+            const u32x2 rv = *(const u32x2*)(residual + (int64_t)(res_mod > 0 ? gm % res_mod : gm) * ldr + gc);
+            v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+        }
+        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(out + (int64_t)gm * ldc + gc) = o;
+    }
+}
+
 int g_gemm256_sched = 0;      // tuning hook (vila_gemm_force_sched): 0 = default schedule of each layout; 1 / 2 / 9 = gemm256_kernel.h SCHED, 10 = SCHED 0
 extern "C" void vila_gemm_force_sched(int sched) { g_gemm256_sched = sched; }
 int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       // gemm256_cm.hip
 int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
 int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s);
+int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s);
+static int g_gemm256_hybrid = 1;   // tuning hook: 0 = never cut a GEMM into whole rounds + K-sliced tail
+extern "C" void vila_gemm_force_hybrid(int on) { g_gemm256_hybrid = on; }
+
+// Tile quantisation: T tiles on 256 CUs cost ceil(T / 256) rounds.  When the last round is short (wgrad of gate/up/down: 1036 tiles =
+// 4 rounds + 12 tiles, i.e. a fifth round for 1 % of the work) the whole rounds run as usual and the tail tiles are sliced over K so that
+// they fill the chip for a fraction of a tile time; their raw sums go to compact per-tile fp32 slabs and meet in a small reduce kernel
+// (bias / residual applied there).  Returns 1 when the GEMM was issued this way, 0 when the caller should launch it whole.
+static int try_hybrid(const GemmArgs& a, hipStream_t s) {
+    if (!g_gemm256_hybrid || a.ws == nullptr || a.epi != EPI_NONE || a.out_f32 || a.N % 4 != 0) return 0;
+    const int tiles_m = cdiv(a.M, 256), tiles = tiles_m * cdiv(a.N, 256), kt = cdiv(a.K, T256_BK);
+    const int full = (tiles / 256) * 256, tail = tiles - full;
+    if (full == 0 || tail == 0 || tail > 96 || kt < 16) return 0;      // a tail above ~1/3 of a round is cheaper left alone
+    int splits = 256 / tail;
+    if (splits > 8) splits = 8;
+    while (splits >= 2 && (cdiv(kt, splits) < 6 || (size_t)splits * tail * 65536 * 4 > a.ws_bytes)) --splits;
+    if (splits < 2) return 0;
+    const int per = cdiv(kt, splits);
+    splits = cdiv(kt, per);
+    const bool cm = a.a_cm || a.b_cm;
+    GemmArgs b = a;
+    b.C = a.ws; b.bias = nullptr; b.residual = nullptr;
+    if (cm) {
+        VILA_TRY(launch_gemm256_cm_range(a, 0, 1, 0, full, 0, s));
+        VILA_TRY(launch_gemm256_cm_range(b, 5, splits, full, tail, per, s));
+    } else {
+        VILA_TRY((launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s, 1, 0, full)));
+        VILA_TRY((launch256_t<5, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, full, tail, 0, per)));
+    }
+    hipLaunchKernelGGL(splitk_tail_reduce_kernel, dim3(tail * 16), dim3(256), 0, s, a.ws, splits, tail, full, tiles_m, a.bias, a.residual, a.ldr,
+                       (bf16_t*)a.C, a.ldc, a.M, a.N, a.res_mod);
+    VILA_LAUNCH_CHECK();
+    return 1;
+}
 
 bool gemm256_supported(const GemmArgs& a) {
     if (a.a_cm && (a.M % 8 != 0 || a.lda % 8 != 0)) return false;
@@ -113,6 +177,10 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
+    if (g_gemm256_sched == 0 && a.epi == EPI_NONE && !a.out_f32) {
+        const int h = try_hybrid(a, s);
+        if (h != 0) return h < 0 ? h : 0;
+    }
     if (a.a_cm || a.b_cm) return launch_gemm256_cm(a, s);
     if (g_gemm256_sched != 0 && a.epi == EPI_NONE && !a.out_f32) return launch_gemm256_sched(a, g_gemm256_sched, s);
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);

@@ -15,8 +15,12 @@ extern int g_gemm256_sched;
 
 template <bool ACM, bool BCM>
 static int launch_cm_t(const GemmArgs& a, int sched, hipStream_t s) {
-    // vila_gemm_force_sched: 0 (default) and 2 = SCHED 2; 1 = the one-tile-ahead schedule (SCHED 0) for A/B runs
+    // default: dgrad (only B contraction-major) runs the role-split schedule (SCHED 6: +3-6 % over SCHED 2); with a contraction-major A
+    // (wgrad) every fragment costs two transpose reads, the read/issue sections outgrow the other group's MFMA sections and the
+    // two-tiles-ahead lock-step schedule (SCHED 2) stays ahead by 8 %.  vila_gemm_force_sched: 1 = SCHED 0, 2 / 5 / 6 = that schedule.
     if (sched == 1) return launch256_t<0, EPI_NONE, ACM, BCM, 0>(a, s);
+    if (sched == 5) return launch256_t<0, EPI_NONE, ACM, BCM, 5>(a, s);
+    if (sched == 6 || (sched == 0 && !ACM)) return launch256_t<0, EPI_NONE, ACM, BCM, 6>(a, s);
     return launch256_t<0, EPI_NONE, ACM, BCM, 2>(a, s);
 }
 
@@ -31,8 +35,21 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s) {
 int launch_gemm256_cm_splitk(const GemmArgs& b, int splits, float* slab, int per, hipStream_t s) {
     (void)slab;
     if (b.a_cm && b.b_cm) return launch256_t<3, EPI_NONE, true, true, 2>(b, s, splits, 0, -1, 0, per);
-    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 2>(b, s, splits, 0, -1, 0, per);
+    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 6>(b, s, splits, 0, -1, 0, per);
     return launch256_t<3, EPI_NONE, true, false, 2>(b, s, splits, 0, -1, 0, per);
+}
+
+// a tile range of a contraction-major GEMM: mode 0 = finished bf16 tiles, mode 5 = K-sliced raw sums into compact per-tile slabs
+// (gemm256.hip try_hybrid: whole rounds + sliced tail)
+int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s) {
+    if (mode == 0) {
+        if (a.a_cm && a.b_cm) return launch256_t<0, EPI_NONE, true, true, 2>(a, s, 1, tile0, n_tiles);
+        if (a.b_cm) return launch256_t<0, EPI_NONE, false, true, 6>(a, s, 1, tile0, n_tiles);
+        return launch256_t<0, EPI_NONE, true, false, 2>(a, s, 1, tile0, n_tiles);
+    }
+    if (a.a_cm && a.b_cm) return launch256_t<5, EPI_NONE, true, true, 2>(a, s, splits, tile0, n_tiles, 0, per);
+    if (a.b_cm) return launch256_t<5, EPI_NONE, false, true, 6>(a, s, splits, tile0, n_tiles, 0, per);
+    return launch256_t<5, EPI_NONE, true, false, 2>(a, s, splits, tile0, n_tiles, 0, per);
 }
 
 // forward layout with another DMA schedule (tuning / A-B measurement through vila_gemm_force_sched)
@@ -40,8 +57,11 @@ int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s) {
     switch (sched) {
         case 1: return launch256_t<0, EPI_NONE, false, false, 1>(a, s);
         case 2: return launch256_t<0, EPI_NONE, false, false, 2>(a, s);
+        case 5: return launch256_t<0, EPI_NONE, false, false, 5>(a, s);
+        case 6: return launch256_t<0, EPI_NONE, false, false, 6>(a, s);
         case 9: return launch256_t<0, EPI_NONE, false, false, 9>(a, s);
+        case 3: return launch256_t<0, EPI_NONE, false, false, 3>(a, s);
         case 10: return launch256_t<0, EPI_NONE, false, false, 0>(a, s);     // round-1 schedule (one tile ahead, fragments read per phase)
-        default: return launch256_t<0, EPI_NONE, false, false, 3>(a, s);
+        default: return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
     }
 }

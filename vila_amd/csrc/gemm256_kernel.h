@@ -18,6 +18,8 @@
 //      t+2 are issued into the buffer tile t is being read from as soon as every wave has finished with them
 //      (phase 1: A rows 0-63 of both halves; phase 2: both B halves; phase 3: A rows 64-127).  The wait never drains the queue.
 //   2  as 1 but one extra barrier only (before phase 3) and all 8 pieces of tile t+2 issued there
+//   3  register-pipelined fragments, one barrier per tile (forward default)
+//   5  role-split 8-barrier schedule: the two wave groups run one barrier interval apart (see the K loop)
 //   9  ablation: schedule 0 without any DMA inside the loop (wrong results; bounds what hiding the loads completely would buy)
 #pragma once
 #include "kernels.h"
@@ -30,11 +32,12 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
-constexpr int T256_CC_SCHED = 3;   // default schedule of the forward (contraction-contiguous) layout: register-pipelined fragments
+constexpr int T256_CC_SCHED = 6;   // default schedule of the forward (contraction-contiguous) layout: role-split, two DMA pieces per phase
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised); one per translation unit (no RDC)
 
 // MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
 //       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)
+//       5 = split-K into COMPACT per-tile slabs [K-slice][tile of this launch][256][256] fp32 (the tail tiles behind whole rounds)
 // tile0 = first tile id of this launch (a GEMM may be issued as "full rounds" + "split tail"), col0 = first output column of the slab
 template <int MODE, int EPI, bool ACM, bool BCM, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
     constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
     constexpr bool GU = (MODE == 2 || MODE == 4);
-    constexpr bool SPLIT = (MODE == 3 || MODE == 4);
+    constexpr bool SPLIT = (MODE == 3 || MODE == 4 || MODE == 5);
     constexpr int BN_OUT = GU ? 128 : 256;
     static_assert(!(GU && (ACM || BCM)), "gate/up fusion only for the forward layouts");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,6 +230,105 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (SCHED == 5 || SCHED == 6) {
+        // Role-split schedule (the guide's 8-phase structure): the K-tile is four phases {fragment reads + LDS-DMA issue | barrier |
+        // 16 MFMAs | barrier}, and the two wave groups (wr = 0 / 1: ONE wave of each on every SIMD) run ONE barrier interval apart, so
+        // that while a SIMD's first wave is in its MFMA section (s_setprio 1) the second is issuing ds_reads / global_load_lds and vice
+        // versa.  In the lock-step schedules both waves of a SIMD issue their 8 LDS-DMA instructions (~64 issue cycles each) at the same
+        // moment and the matrix pipe idles for that long every K-tile (SCHED 9 ablation: +25-40 % with the DMA removed).
+        //
+        // Barrier arithmetic (group 1 executes one extra barrier before the loop, group 0 one after it: equal totals).  With barriers
+        // numbered globally, tile t, phase p:  group 0 reads/issues in interval 8t+2p+1 and multiplies in 8t+2p+2, group 1 one later.
+        //   WAR: the last B-fragment reads of tile t (phase 1) are retired by every wave before barrier 8t+5, the last A reads (phase 2)
+        //        before 8t+7  ->  the B halves of tile t's buffer are re-staged (tile t+2) in phase 3 of tile t (group 0: after 8t+6),
+        //        the A halves in phase 0 of tile t+1 (group 0: after 8t+8).
+        //   RAW: everything of tile t+1 is retired by the counted wait in phase 3 of tile t, in front of that phase's first barrier
+        //        (8t+7 / 8t+8); tile t+1's first reads follow barrier 8t+8 (group 0) / 8t+9 (group 1).  The wait leaves the 4 pieces
+        //        issued in the same phase (B halves of tile t+2) in flight: the queue is never drained inside the loop.
+        issue_tile(0, 0);
+        if (nt > 1) { issue_tile(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+        // SCHED 6 = SCHED 5 with (a) the fragment reads retired BEFORE the section's barrier (lgkmcnt(0) in front of it): the proof that
+        // every wave is done with a half-tile then comes one barrier earlier (B halves free after 8t+4, A halves after 8t+6), which lets
+        // (b) the 8 LDS-DMA pieces go out two per phase: B_lo / B_hi of tile t+2 in phases 2 / 3 of tile t, A_lo / A_hi in phases 0 / 1
+        // of tile t+1; the counted wait in phase 3 still leaves the 4 newest pieces in flight.
+        constexpr bool EARLY = (SCHED == 6);
+        auto enter_mfma = [&]() {                       // end of a read/issue section
+            __builtin_amdgcn_sched_barrier(0);
+            if (EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (EARLY) asm volatile("" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+        };
+        auto leave_mfma = [&]() {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfma16 = [&](bf16x8 (&A)[4][2], bf16x8 (&Bf)[2][2], int ai, int bj) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ai + i][bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], Bf[j][ks], acc[ai + i][bj + j], 0, 0, 0);
+        };
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
+            const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES;
+            // phase 0: B cols 0..31, A rows 0..63; the A halves of tile t+1 go into the other buffer (tile 1's came with the prologue)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = fragB(cB, b_row0 + j * 16, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, i * 16, ks);
+            if (t >= 1 && t + 1 < nt) {
+#pragma unroll
+                for (int h = 0; h < (EARLY ? 1 : 2); ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) issue_piece(t + 1, buf ^ 1, false, h, i);
+            }
+            enter_mfma(); mfma16(af, bf0, 0, 0); leave_mfma();
+            // phase 1: B cols 32..63
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bf1[j][ks] = fragB(cB, b_row0 + 32 + j * 16, ks);
+            if (EARLY && t >= 1 && t + 1 < nt) { issue_piece(t + 1, buf ^ 1, false, 1, 0); issue_piece(t + 1, buf ^ 1, false, 1, 1); }
+            enter_mfma(); mfma16(af, bf1, 0, 2); leave_mfma();
+            // phase 2: A rows 64..127
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, 64 + i * 16, ks);
+            if (EARLY && t + 2 < nt) { issue_piece(t + 2, buf, true, 0, 0); issue_piece(t + 2, buf, true, 0, 1); }
+            enter_mfma(); mfma16(af, bf1, 4, 2); leave_mfma();
+            // phase 3: no reads; the B halves of tile t+2 into THIS buffer, then the counted wait for tile t+1
+            if (t + 2 < nt) {
+#pragma unroll
+                for (int h = (EARLY ? 1 : 0); h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) issue_piece(t + 2, buf, true, h, i);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (t + 1 < nt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            enter_mfma(); mfma16(af, bf0, 4, 0); leave_mfma();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     } else {
     constexpr bool DEEP = (SCHED == 1 || SCHED == 2);
     issue_tile(0, 0);
@@ -336,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     constexpr int NJ = GU ? 2 : 4;
     const int ncol0 = n0 + wc * WN_OUT;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 2 && MODE != 3 && MODE != 4) {
+    if (MODE != 2 && MODE != 3 && MODE != 4 && MODE != 5) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = ncol0 + j * 16 + l15;
@@ -347,7 +449,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
     // MODE 3: one fp32 slab per K-slice; MODE 4: two planes (gate, up) per K-slice, ldc = columns of the tail region
     float* slab = (MODE == 3) ? (float*)p.C + (int64_t)blockIdx.y * M * p.ldc
-                : (MODE == 4) ? (float*)p.C + (int64_t)blockIdx.y * 2 * M * p.ldc : nullptr;
+                : (MODE == 4) ? (float*)p.C + (int64_t)blockIdx.y * 2 * M * p.ldc
+                : (MODE == 5) ? (float*)p.C + ((int64_t)blockIdx.y * gridDim.x + (id - tile0)) * 65536 : nullptr;
     constexpr int PASSES = (MODE == 4) ? 2 : 1;
 #pragma unroll
     for (int pl = 0; pl < PASSES; ++pl) {
@@ -383,6 +486,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                     *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
                 } else if (MODE == 4) {
                     *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
+                } else if (MODE == 5) {
+                    *(f32x4*)(slab + (gm - m0) * 256 + (gc - n0)) = v;
                 } else {
                     if (p.residual != nullptr) {
                         const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);

@@ -36,6 +36,8 @@ struct Ws {                       // bump allocator over the caller's workspace;
     void release(size_t m) { off = m; }      // temporaries of a finished backward layer: all work is stream-ordered, so the space is reusable
 };
 struct Ctx { hipStream_t s; Ws* w; bool dry; float* gws; size_t gws_bytes; };
+// fp32 slabs of the K-sliced GEMM launches (lm_head dgrad, tower shapes, tail tiles behind whole rounds)
+constexpr size_t kSlabBytes = (size_t)128 << 20;
 
 // VILA_SFT_DEBUG=1: name every launch on stderr before it is enqueued and wait for it (a device fault then points at its kernel)
 static bool sft_debug() { static int v = -1; if (v < 0) { const char* e = getenv("VILA_SFT_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
@@ -209,7 +211,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         VILA_TRY(gemm(c, s.h2, H, B(L.w_gate), H, nullptr, nullptr, 0, s.g, F, T, F, H));
         VILA_TRY(gemm(c, s.h2, H, B(L.w_up), H, nullptr, nullptr, 0, s.u, F, T, F, H));
         RUN(launch_silu_mul_fwd(s.g, s.u, s.act, (int64_t)T * F, c.s));
-        VILA_TRY(gemm(c, s.act, F, B(L.w_down), F, nullptr, s.x_mid, H, xo, H, T, H, F));
+        VILA_TRY(gemm(c, s.act, F, B(L.w_down), F, nullptr, s.x_mid, H, xo, H, T, H, F, EPI_NONE, 0, 0, 0, 0, true));
         x = xo;
     }
     bf16_t* x_out = x;
@@ -247,20 +249,20 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         LlmSaved& s = lsv[l];
         const size_t layer_mark = a.mark();
         bf16_t* dact = a.take<bf16_t>((size_t)T * F);
-        VILA_TRY(linear_bwd(c, s.act, B(L.w_down), dx, B((void*)G.w_down), nullptr, dact, nullptr, T, H, F, true));
+        VILA_TRY(linear_bwd(c, s.act, B(L.w_down), dx, B((void*)G.w_down), nullptr, dact, nullptr, T, H, F, true, true));
         bf16_t* dg = a.take<bf16_t>((size_t)T * F);
         bf16_t* du = a.take<bf16_t>((size_t)T * F);
         RUN(launch_silu_mul_bwd(s.g, s.u, dact, dg, du, (int64_t)T * F, c.s));
         bf16_t* dh2a = a.take<bf16_t>((size_t)T * H);
         bf16_t* dh2 = a.take<bf16_t>((size_t)T * H);
-        VILA_TRY(linear_bwd(c, s.h2, B(L.w_gate), dg, B((void*)G.w_gate), nullptr, dh2a, nullptr, T, F, H, true));
-        VILA_TRY(linear_bwd(c, s.h2, B(L.w_up), du, B((void*)G.w_up), nullptr, dh2, dh2a, T, F, H, true));
+        VILA_TRY(linear_bwd(c, s.h2, B(L.w_gate), dg, B((void*)G.w_gate), nullptr, dh2a, nullptr, T, F, H, true, true));
+        VILA_TRY(linear_bwd(c, s.h2, B(L.w_up), du, B((void*)G.w_up), nullptr, dh2, dh2a, T, F, H, true, true));
         bf16_t* dxm = a.take<bf16_t>((size_t)T * H);
         VILA_TRY(norm_bwd(c, s.x_mid, B(L.ln2_w), dh2, dxm, B((void*)G.ln2_w), nullptr, T, H, ls.rms_eps, 1));
         bf16_t* dx_mid = a.take<bf16_t>((size_t)T * H);
         RUN(launch_add(dx, dxm, dx_mid, (int64_t)T * H, c.s));
         bf16_t* da = a.take<bf16_t>((size_t)T * QS);
-        VILA_TRY(linear_bwd(c, s.a, B(L.wo), dx_mid, B((void*)G.wo), nullptr, da, nullptr, T, H, QS, true));
+        VILA_TRY(linear_bwd(c, s.a, B(L.wo), dx_mid, B((void*)G.wo), nullptr, da, nullptr, T, H, QS, true, true));
         bf16_t* dqkv = a.take<bf16_t>((size_t)T * QKV);
         float* delta = a.take<float>((size_t)ls.q_heads * T);
         AttnBwdArgs ab{};
@@ -273,7 +275,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         RUN(launch_attn_bwd(ab, c.s));
         RUN(launch_rope_bwd(dqkv, cs, sn, T, ls.q_heads, ls.kv_heads, hd, c.s));
         bf16_t* dh1 = a.take<bf16_t>((size_t)T * H);
-        VILA_TRY(linear_bwd(c, s.h1, B(L.wq), dqkv, B((void*)G.wq), B((void*)G.bq), dh1, nullptr, T, QKV, H, true));
+        VILA_TRY(linear_bwd(c, s.h1, B(L.wq), dqkv, B((void*)G.wq), B((void*)G.bq), dh1, nullptr, T, QKV, H, true, true));
         bf16_t* dxi = a.take<bf16_t>((size_t)T * H);
         VILA_TRY(norm_bwd(c, s.x_in, B(L.ln1_w), dh1, dxi, B((void*)G.ln1_w), nullptr, T, H, ls.rms_eps, 1));
         bf16_t* dnext = dx_pp[l & 1] != dx ? dx_pp[l & 1] : dx_pp[(l & 1) ^ 1];
@@ -392,7 +394,7 @@ extern "C" size_t vila_sft_workspace_bytes(const VilaVitWeights* vit, const Vila
     Ws w{(char*)4096, 0, true};
     Ctx c{nullptr, &w, true, nullptr, 0};
     if (run(vit, vit, proj, proj, llm, llm, batch, nullptr, c, nullptr, nullptr) != 0) return 0;
-    return w.peak + ((size_t)64 << 20) + 4096;               // + the split-K slab region of the under-filled GEMMs (lm_head dgrad)
+    return w.peak + kSlabBytes + 4096;                       // + the fp32 slab region of the K-sliced GEMM launches
 }
 
 extern "C" int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, const VilaProjWeights* proj, const VilaProjWeights* proj_grad,
@@ -402,7 +404,7 @@ extern "C" int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights*
     const size_t need = vila_sft_workspace_bytes(vit, proj, llm, batch);
     VILA_REQUIRE(need != 0, "sft: %s", vila_last_error());
     VILA_REQUIRE(workspace_bytes >= need, "sft: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-    const size_t slab = (size_t)64 << 20;
+    const size_t slab = kSlabBytes;
     if (sft_debug()) fprintf(stderr, "sft: workspace %p bytes %zu need %zu\n", workspace, workspace_bytes, need);
     Ws w{(char*)workspace + slab, 0, false};
     Ctx c{(hipStream_t)stream, &w, false, (float*)workspace, slab};

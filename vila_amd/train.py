@@ -230,10 +230,11 @@ class SFTTrainer:
         self.use_c_abi = flag("VILA_SFT_C_ABI", "0")            # step(): forward+backward as ONE vila_sft_fwd_bwd call (else Python-orchestrated ops)
         self.lean_adamw = flag("VILA_SFT_LEAN_ADAMW", "1")      # <= 32-VGPR optimizer kernel: co-resident with the GEMM blocks
         self.cm = flag("VILA_SFT_CM", "1")  # dgrad / wgrad on the tensors as they lie (no transposed copies) where the shapes allow
-        self.ws = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if on_gpu else None      # split-K slabs (lm_head dgrad)
+        # fp32 slabs for the K-sliced launches (lm_head dgrad, tower shapes, tail tiles behind whole rounds)
+        self.ws = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if on_gpu else None
         # the tower / projector GEMMs (M = 1024 per image, N = 1152): contraction-major too, K-sliced where their 256^2 tiles under-fill
         self.cm_vit = self.cm and flag("VILA_SFT_CM_VIT", "1")
-        self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.cm_vit and self.side is not None) else None
+        self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.side is not None) else None   # the side stream's own slabs
         self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
 
     def _ready(self, prefix: str) -> None:
@@ -400,7 +401,7 @@ class SFTTrainer:
             s.g = ops.gemm(s.h2, P(l + "mlp.gate_proj.weight"))
             s.u = ops.gemm(s.h2, P(l + "mlp.up_proj.weight"))
             s.act = ops.silu_mul(s.g, s.u)
-            x = ops.gemm(s.act, P(l + "mlp.down_proj.weight"), residual=s.x_mid)
+            x = ops.gemm(s.act, P(l + "mlp.down_proj.weight"), residual=s.x_mid, ws=self.ws)
             saved.layers.append(s)
         saved.x_out = x
         saved.hn = ops.rmsnorm(x, P("llm.model.norm.weight"), c.rms_norm_eps)
@@ -414,7 +415,7 @@ class SFTTrainer:
         for i in reversed(range(c.num_hidden_layers)):
             l = f"llm.model.layers.{i}."
             s = saved.layers[i]
-            kw = dict(cm=self.cm, side=self.side)
+            kw = dict(cm=self.cm, side=self.side, ws=self.ws, ws_side=self.ws_side)
             dact = linear_bwd(s.act, P(l + "mlp.down_proj.weight"), dx, G(l + "mlp.down_proj.weight"), **kw)
             dg, du = ops.silu_mul_bwd(s.g, s.u, dact)
             dh2 = linear_bwd(s.h2, P(l + "mlp.gate_proj.weight"), dg, G(l + "mlp.gate_proj.weight"), **kw)
