@@ -339,3 +339,67 @@ def test_gemm_t_rejects_what_the_kernel_cannot_read(ops):
     dy, w = randn_bf16(256, 260, seed=1), randn_bf16(260, 516, seed=2)      # contraction-major rows must be a multiple of 8 (516 is not)
     with pytest.raises(ValueError):
         ops.gemm_t(dy, w, b_cm=True)
+
+
+@pytest.mark.parametrize("sched", [1, 2, 3, 5, 6, 10])
+def test_gemm256_every_kept_schedule_matches_fp32(ops, sched):
+    """The K-loop schedules kept in gemm256_kernel.h (vila_gemm_force_sched): lock-step 0 (= 10) / 1 / 2 / 3 and the role-split 5 / 6 whose
+    two wave groups run one barrier interval apart.  Forward layout (256x256 kernel pinned) and both backward layouts, ragged M / N / K:
+    rows that are not a multiple of 256, a contraction of 23 K-tiles + a tail, odd K-tile counts (buffer parity at the loop end) and the
+    two-tile minimum.  Tolerance: one bf16 rounding of the output (rel-L2 <= 4e-3)."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.vila_gemm_force_sched(sched)
+        lib.vila_gemm_force_tile(4)
+        for (M, N, K) in [(1000, 1032, 1496), (769, 520, 128), (512, 512, 192), (300, 264, 4160)]:
+            a = randn_bf16(M, K, seed=31)
+            w = randn_bf16(N, K, seed=32, scale=K ** -0.5)
+            res = randn_bf16(M, N, seed=33)
+            out = ops.gemm(a, w, residual=res)
+            assert rel_l2(out, a.float() @ w.float().t() + res.float()) < 4e-3, (sched, M, N, K)
+        lib.vila_gemm_force_tile(0)
+        if sched in (1, 2, 5, 6):
+            for (T, N, K) in [(1000, 1032, 1496), (777, 520, 1032), (192, 256, 136)]:
+                x = randn_bf16(T, K, seed=34)
+                w = randn_bf16(N, K, seed=35, scale=K ** -0.5)
+                dy = randn_bf16(T, N, seed=36)
+                assert rel_l2(ops.gemm_t(dy, w, b_cm=True), dy.float() @ w.float()) < 4e-3, (sched, "dgrad", T, N, K)
+                assert rel_l2(ops.gemm_t(dy, x, a_cm=True, b_cm=True), dy.float().t() @ x.float()) < 4e-3, (sched, "wgrad", T, N, K)
+    finally:
+        lib.vila_gemm_force_sched(0)
+        lib.vila_gemm_force_tile(0)
+
+
+def test_gemm_whole_rounds_plus_sliced_tail_tiles(ops):
+    """Tile quantisation path (gemm256.hip try_hybrid): 17 x 16 = 272 tiles of 256^2 = one whole round + 16 tail tiles, which are sliced
+    over K into compact per-tile slabs and finished (bias-free, residual) by the tail reduce kernel.  Forward and both backward layouts,
+    with the policy on (workspace lent) and off (hook) giving the same result up to the summation order."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    ws = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    M, N, K = 4300, 4092, 1088                                 # 17 x 16 tiles, ragged last row tile and last column tile
+    a = randn_bf16(M, K, seed=41)
+    w = randn_bf16(N, K, seed=42, scale=K ** -0.5)
+    res = randn_bf16(M, N, seed=43)
+    ref = a.float() @ w.float().t() + res.float()
+    on = ops.gemm(a, w, residual=res, ws=ws)
+    assert rel_l2(on, ref) < 4e-3
+    try:
+        lib.vila_gemm_force_hybrid(0)
+        off = ops.gemm(a, w, residual=res, ws=ws)
+    finally:
+        lib.vila_gemm_force_hybrid(1)
+    assert rel_l2(off, ref) < 4e-3 and rel_l2(on, off.float()) < 4e-3
+    # wgrad: dW[N2, K2] = dY^T X with N2 x K2 = 4352 x 4096 outputs (272 tiles), contraction T = 1100 (ragged)
+    T = 1100
+    dy = randn_bf16(T, 4352, seed=44, scale=T ** -0.5)
+    x = randn_bf16(T, 4096, seed=45)
+    dw = ops.gemm_t(dy, x, a_cm=True, b_cm=True, ws=ws)
+    assert rel_l2(dw, dy.float().t() @ x.float()) < 4e-3
+    # dgrad with residual: dX[4300, 4096] = dY[4300, 1088] . W[1088, 4096]
+    dyy = randn_bf16(4300, 1088, seed=46, scale=1088 ** -0.5)
+    ww = randn_bf16(1088, 4096, seed=47)
+    r2 = randn_bf16(4300, 4096, seed=48)
+    dx = ops.gemm_t(dyy, ww, b_cm=True, residual=r2, ws=ws)
+    assert rel_l2(dx, dyy.float() @ ww.float() + r2.float()) < 4e-3
