@@ -44,8 +44,11 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     for (int sched : scheds) {
         if (sched == 9 && (c.a_cm || c.b_cm)) continue;
         // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
-        const bool pol = sched >= 100;
-        vila_gemm_force_sched(pol ? 0 : sched);
+        // pseudo schedules 256 / 192: default kernels with that tile height forced (0 elsewhere = automatic)
+        const bool bmf = sched == 256 || sched == 192;
+        vila_gemm_force_bm(bmf ? sched : 0);
+        const bool pol = sched >= 100 && !bmf;
+        vila_gemm_force_sched((pol || bmf) ? 0 : sched);
         vila_gemm_force_hybrid(pol ? sched == 101 : 1);
         auto call = [&]() {
             int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, W.d, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
@@ -88,6 +91,7 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     vila_gemm_force_tile(0);
     vila_gemm_force_sched(0);
     vila_gemm_force_hybrid(1);
+    vila_gemm_force_bm(0);
     CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
 }
 
@@ -126,8 +130,12 @@ int main(int argc, char** argv) {
         for (int i : {3, 1}) run_case(fwd[i], {100, 101, 100, 101}, ws, ws_bytes);
         for (int i : {2, 3, 4, 7, 8, 6, 5}) run_case(bwd[i], {100, 101, 100, 101}, ws, ws_bytes);
     }
+    if (!strcmp(what, "bm")) {         // 256- vs 192-row tiles on the shapes with M = 3076
+        for (int i : {0, 1, 2, 3, 4}) run_case(fwd[i], {256, 192, 256, 192}, ws, ws_bytes);
+        for (int i : {0, 1, 2, 3, 4, 14}) run_case(bwd[i], {256, 192, 256, 192}, ws, ws_bytes);
+    }
     if (!strcmp(what, "lay")) for (auto& c : lay) run_case(c, {0, 1}, ws, ws_bytes);
-    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {5, 6, 5, 6}, ws, ws_bytes);
-    if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 6, 0, 6}, ws, ws_bytes);     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
+    if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 6, 10, 0, 6, 10}, ws, ws_bytes);     // default (SCHED 7) vs the 8-barrier role split vs round 1
+    if (!strcmp(what, "bwd") || !strcmp(what, "all")) for (auto& c : bwd) run_case(c, {0, 2, 0, 2}, ws, ws_bytes);            // default (SCHED 7 + launch policies) vs the lock-step two-tiles-ahead schedule     // contraction-major: 0 = default (two tiles ahead), 1 = one tile ahead
     return 0;
 }

@@ -104,6 +104,8 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       /
 int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
 int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s);
 int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s);
+int g_gemm256_bm = 0;              // tuning hook (vila_gemm_force_bm): 0 = prefer_bm192's rule, 192 / 256 = force that tile height
+extern "C" void vila_gemm_force_bm(int bm) { g_gemm256_bm = bm; }
 static int g_gemm256_hybrid = 1;   // tuning hook: 0 = never cut a GEMM into whole rounds + K-sliced tail
 extern "C" void vila_gemm_force_hybrid(int on) { g_gemm256_hybrid = on; }
 
@@ -186,7 +188,9 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
     if (a.out_f32) return launch256_t<1, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
     switch (a.epi) {
-        case EPI_NONE: return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
+        case EPI_NONE:
+            if (prefer_bm192(a.M, a.N, g_gemm256_bm)) return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED, 192>(a, s);
+            return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
         case EPI_GELU_TANH: return launch256_t<0, EPI_GELU_TANH, false, false, T256_CC_SCHED>(a, s);
         case EPI_GELU_ERF: return launch256_t<0, EPI_GELU_ERF, false, false, T256_CC_SCHED>(a, s);
     }

@@ -15,13 +15,14 @@ extern int g_gemm256_sched;
 
 template <bool ACM, bool BCM>
 static int launch_cm_t(const GemmArgs& a, int sched, hipStream_t s) {
-    // default: dgrad (only B contraction-major) runs the role-split schedule (SCHED 6: +3-6 % over SCHED 2); with a contraction-major A
-    // (wgrad) every fragment costs two transpose reads, the read/issue sections outgrow the other group's MFMA sections and the
-    // two-tiles-ahead lock-step schedule (SCHED 2) stays ahead by 8 %.  vila_gemm_force_sched: 1 = SCHED 0, 2 / 5 / 6 = that schedule.
+    // default for every layout: the role-split schedule with two 32-MFMA phases per K-tile (SCHED 7).  vila_gemm_force_sched:
+    // 1 = SCHED 0 (round 1), 2 / 5 / 6 = that schedule
     if (sched == 1) return launch256_t<0, EPI_NONE, ACM, BCM, 0>(a, s);
+    if (sched == 2) return launch256_t<0, EPI_NONE, ACM, BCM, 2>(a, s);
     if (sched == 5) return launch256_t<0, EPI_NONE, ACM, BCM, 5>(a, s);
-    if (sched == 6 || (sched == 0 && !ACM)) return launch256_t<0, EPI_NONE, ACM, BCM, 6>(a, s);
-    return launch256_t<0, EPI_NONE, ACM, BCM, 2>(a, s);
+    if (sched == 6) return launch256_t<0, EPI_NONE, ACM, BCM, 6>(a, s);
+    // (192-row tiles were measured for dgrad too: -2 % on K = 3584 / 4608, +3 % on K = 18944: not used for contraction-major operands)
+    return launch256_t<0, EPI_NONE, ACM, BCM, 7>(a, s);
 }
 
 // bf16 out (+ bias / residual), no activation: dX = dY . W (b_cm) and dW = dY^T . X (a_cm, b_cm)
@@ -34,22 +35,22 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s) {
 
 int launch_gemm256_cm_splitk(const GemmArgs& b, int splits, float* slab, int per, hipStream_t s) {
     (void)slab;
-    if (b.a_cm && b.b_cm) return launch256_t<3, EPI_NONE, true, true, 2>(b, s, splits, 0, -1, 0, per);
-    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 6>(b, s, splits, 0, -1, 0, per);
-    return launch256_t<3, EPI_NONE, true, false, 2>(b, s, splits, 0, -1, 0, per);
+    if (b.a_cm && b.b_cm) return launch256_t<3, EPI_NONE, true, true, 7>(b, s, splits, 0, -1, 0, per);
+    if (b.b_cm) return launch256_t<3, EPI_NONE, false, true, 7>(b, s, splits, 0, -1, 0, per);
+    return launch256_t<3, EPI_NONE, true, false, 7>(b, s, splits, 0, -1, 0, per);
 }
 
 // a tile range of a contraction-major GEMM: mode 0 = finished bf16 tiles, mode 5 = K-sliced raw sums into compact per-tile slabs
 // (gemm256.hip try_hybrid: whole rounds + sliced tail)
 int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s) {
     if (mode == 0) {
-        if (a.a_cm && a.b_cm) return launch256_t<0, EPI_NONE, true, true, 2>(a, s, 1, tile0, n_tiles);
-        if (a.b_cm) return launch256_t<0, EPI_NONE, false, true, 6>(a, s, 1, tile0, n_tiles);
-        return launch256_t<0, EPI_NONE, true, false, 2>(a, s, 1, tile0, n_tiles);
+        if (a.a_cm && a.b_cm) return launch256_t<0, EPI_NONE, true, true, 7>(a, s, 1, tile0, n_tiles);
+        if (a.b_cm) return launch256_t<0, EPI_NONE, false, true, 7>(a, s, 1, tile0, n_tiles);
+        return launch256_t<0, EPI_NONE, true, false, 7>(a, s, 1, tile0, n_tiles);
     }
-    if (a.a_cm && a.b_cm) return launch256_t<5, EPI_NONE, true, true, 2>(a, s, splits, tile0, n_tiles, 0, per);
-    if (a.b_cm) return launch256_t<5, EPI_NONE, false, true, 6>(a, s, splits, tile0, n_tiles, 0, per);
-    return launch256_t<5, EPI_NONE, true, false, 2>(a, s, splits, tile0, n_tiles, 0, per);
+    if (a.a_cm && a.b_cm) return launch256_t<5, EPI_NONE, true, true, 7>(a, s, splits, tile0, n_tiles, 0, per);
+    if (a.b_cm) return launch256_t<5, EPI_NONE, false, true, 7>(a, s, splits, tile0, n_tiles, 0, per);
+    return launch256_t<5, EPI_NONE, true, false, 7>(a, s, splits, tile0, n_tiles, 0, per);
 }
 
 // forward layout with another DMA schedule (tuning / A-B measurement through vila_gemm_force_sched)

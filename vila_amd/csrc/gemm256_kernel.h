@@ -20,6 +20,8 @@
 //   2  as 1 but one extra barrier only (before phase 3) and all 8 pieces of tile t+2 issued there
 //   3  register-pipelined fragments, one barrier per tile (forward default)
 //   5  role-split 8-barrier schedule: the two wave groups run one barrier interval apart (see the K loop)
+//   6  as 5 with the fragment reads retired in front of the barrier and two DMA pieces per phase
+//   7  role split with TWO phases of 32 MFMAs per K-tile (4 barriers): the default
 //   9  ablation: schedule 0 without any DMA inside the loop (wrong results; bounds what hiding the loads completely would buy)
 #pragma once
 #include "kernels.h"
@@ -32,15 +34,22 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
-constexpr int T256_CC_SCHED = 6;   // default schedule of the forward (contraction-contiguous) layout: role-split, two DMA pieces per phase
+constexpr int T256_CC_SCHED = 7;   // default schedule of every layout: role split, two phases of 32 MFMAs per K-tile
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   // K-tail source (zero-initialised); one per translation unit (no RDC)
 
 // MODE: 0 = bf16 out (bias/GELU/residual), 1 = fp32 out, 2 = gate/up fused (bf16 out), 3 = split-K fp32 slab (raw accumulators),
 //       4 = gate/up split-K: raw gate and up accumulators into two fp32 planes per K-slice (the tail round of an under-filled grid)
 //       5 = split-K into COMPACT per-tile slabs [K-slice][tile of this launch][256][256] fp32 (the tail tiles behind whole rounds)
 // tile0 = first tile id of this launch (a GEMM may be issued as "full rounds" + "split tail"), col0 = first output column of the slab
-template <int MODE, int EPI, bool ACM, bool BCM, int SCHED>
+// BM = output rows per tile: 256, or 192 (role-split schedules, A in the forward layout): M = 3076 x N = 3584 is 13 x 14 = 182 tiles of
+// 256 rows — one round on 71 % of the CUs — but 17 x 14 = 238 tiles of 192 rows, each 3/4 of the MFMAs.  The LDS image keeps its 128-row
+// half-tile slots (rows 96..127 of a half are loaded and not used), each wave owns 96 rows = 6 A fragments.  Measured: the K-loop's pace
+// is set by its barrier intervals more than by its MFMA count, so 3/4 of the MFMAs buy 2-9 % (o_proj 92 -> 84 us, down_proj 424 -> 417 us),
+// not 25 %; used for the forward layout only.
+template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
+    static_assert(BM == 256 || (BM == 192 && !ACM && (SCHED == 5 || SCHED == 6 || SCHED == 7) && MODE == 0), "192-row tiles: role-split schedules, forward-layout A");
+    constexpr int NA = BM / 64;                        // A fragments per quadrant (4, or 3 with 192-row tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
     constexpr int BUF_BYTES = 4 * HALF_BYTES;          // A_lo, A_hi, B_lo, B_hi
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     const int l15 = lane & 15, lg = lane >> 4;
     const int id = xcd_remap(blockIdx.x, gridDim.x) + tile0;
     const int tm = id % tiles_m, tn = id / tiles_m;
-    const int m0 = tm * 256, n0 = tn * BN_OUT;
+    const int m0 = tm * BM, n0 = tn * BN_OUT;
     const int M = p.M, N = p.N;
 
     // ---- DMA source offsets ----
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                 int gm = m0 + h * 128 + cm_ch * 8; gm = gm + 8 <= M ? gm : (M >= 8 ? M - 8 : 0);      // rows beyond M: any valid rows (masked at the store)
                 aoff[h][i] = (uint32_t)(cm_k + 32 * i) * (uint32_t)p.lda + gm;
             } else {
-                int gm = m0 + h * 128 + srow + 64 * i; gm = gm < M ? gm : M - 1;
+                int gm = m0 + h * (BM / 2) + srow + 64 * i; gm = gm < M ? gm : M - 1;
                 aoff[h][i] = (uint32_t)gm * (uint32_t)p.lda + kch * 8;
             }
             b_up[h][i] = false;
@@ -230,6 +239,87 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (SCHED == 7) {
+        // Role split with TWO phases of 32 MFMAs per K-tile (4 barriers per tile instead of 8).  Measured premise: a 192-row tile (12
+        // MFMAs per phase instead of 16) runs the SCHED 6 loop in the same time per K-tile — the barrier intervals, not the MFMA count,
+        // set its pace.  Phase 0: reads B0, B1, A0 (16 fragments reads), quadrants (A0,B0) (A0,B1); phase 1: reads A1, quadrants (A1,B1)
+        // (A1,B0).  Fragment reads are retired in front of the section's barrier (as in SCHED 6).  (ONE phase of 64 MFMAs — 2 barriers per
+        // tile, all 24 fragments live, asymmetric DMA roles — was built and measured too: 96 fragment registers push the kernel to 256 VGPRs
+        // with spills and it runs 15-27 % slower than this schedule.)  Barrier arithmetic, tile t, phase p:
+        // group 0 reads / issues in interval 4t+2p+1 and multiplies in 4t+2p+2, group 1 one later.
+        //   WAR: all B reads of tile t (phase 0) are retired by every wave before barrier 4t+2, the A reads (phase 1) before 4t+4
+        //        -> B halves of tile t+2 are staged in phase 1 of tile t (group 0: after 4t+2), A halves in phase 0 of tile t+1 (after 4t+4)
+        //   RAW: the counted wait sits in phase 1 in front of its barrier (4t+3 / 4t+4) and leaves the 4 pieces issued in the same
+        //        section (B of tile t+2) in flight; the first reads of tile t+1 follow barrier 4t+4 (group 0) / 4t+5 (group 1).
+        issue_tile(0, 0);
+        if (nt > 1) { issue_tile(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+        auto enter_mfma = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+        };
+        auto leave_mfma = [&]() {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfma16 = [&](bf16x8 (&A)[4][2], bf16x8 (&Bf)[2][2], int ai, int bj) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ai + i][bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], Bf[j][ks], acc[ai + i][bj + j], 0, 0, 0);
+        };
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
+            const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES;
+            // phase 0: all B fragments, A rows 0..63; the A halves of tile t+1 go into the other buffer (tile 1's came with the prologue)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { bf0[j][ks] = fragB(cB, b_row0 + j * 16, ks); bf1[j][ks] = fragB(cB, b_row0 + 32 + j * 16, ks); }
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, i * 16, ks);
+            if (t >= 1 && t + 1 < nt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) issue_piece(t + 1, buf ^ 1, false, h, i);
+            }
+            enter_mfma(); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2); leave_mfma();
+            // phase 1: A rows 64..127; the B halves of tile t+2 into THIS buffer, then the counted wait for tile t+1
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, NA * 16 + i * 16, ks);
+            if (t + 2 < nt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) issue_piece(t + 2, buf, true, h, i);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (t + 1 < nt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            enter_mfma(); mfma16(af, bf1, NA, 2); mfma16(af, bf0, NA, 0); leave_mfma();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     } else if constexpr (SCHED == 5 || SCHED == 6) {
         // Role-split schedule (the guide's 8-phase structure): the K-tile is four phases {fragment reads + LDS-DMA issue | barrier |
         // 16 MFMAs | barrier}, and the two wave groups (wr = 0 / 1: ONE wave of each on every SIMD) run ONE barrier interval apart, so
@@ -276,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NA; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[ai + i][bj + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][ks], Bf[j][ks], acc[ai + i][bj + j], 0, 0, 0);
@@ -291,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) bf0[j][ks] = fragB(cB, b_row0 + j * 16, ks);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NA; ++i)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, i * 16, ks);
             if (t >= 1 && t + 1 < nt) {
@@ -310,11 +400,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             enter_mfma(); mfma16(af, bf1, 0, 2); leave_mfma();
             // phase 2: A rows 64..127
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NA; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, 64 + i * 16, ks);
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, NA * 16 + i * 16, ks);
             if (EARLY && t + 2 < nt) { issue_piece(t + 2, buf, true, 0, 0); issue_piece(t + 2, buf, true, 0, 1); }
-            enter_mfma(); mfma16(af, bf1, 4, 2); leave_mfma();
+            enter_mfma(); mfma16(af, bf1, NA, 2); leave_mfma();
             // phase 3: no reads; the B halves of tile t+2 into THIS buffer, then the counted wait for tile t+1
             if (t + 2 < nt) {
 #pragma unroll
@@ -325,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             } else if (t + 1 < nt) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            enter_mfma(); mfma16(af, bf0, 4, 0); leave_mfma();
+            enter_mfma(); mfma16(af, bf0, NA, 0); leave_mfma();
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -455,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
     for (int pl = 0; pl < PASSES; ++pl) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NA; ++q) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -479,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int rr = it * RPI + rr0;
-            const int gm = m0 + wr * 128 + q * 32 + rr, gc = ncol0 + c4;
+            const int gm = m0 + wr * (BM / 2) + q * 32 + rr, gc = ncol0 + c4;
             if (gm < M && gc < N) {
                 f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
                 if (MODE == 3) {
@@ -508,21 +598,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     }
 }
 
+// 192-row tiles (BM) when they need fewer tile-times than 256-row tiles: rounds(tiles) x work per tile, a 192-row tile priced at 0.78 of a
+// 256-row one (3/4 of the MFMAs on the same B traffic).  force: 0 = this rule, 192 / 256 = that tile height (vila_gemm_force_bm)
+static inline bool prefer_bm192(int M, int N, int force) {
+    if (force == 192) return true;
+    if (force == 256) return false;
+    const int t256 = cdiv(M, 256) * cdiv(N, 256), t192 = cdiv(M, 192) * cdiv(N, 256);
+    return 0.78 * cdiv(t192, 256) < 0.97 * cdiv(t256, 256);
+}
+
 // tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
-template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0>
+template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256>
 static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
     const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
-    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, bn);
+    const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, bn);
     if (n_tiles < 0) n_tiles = tiles_m * tiles_n;
     const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int kt = cdiv(a.K, T256_BK);
     if (per <= 0) per = kt / splits;
-    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
     VILA_LAUNCH_CHECK();
     return 0;
 }
