@@ -1,14 +1,13 @@
 // Instantiations of the 256x256 kernel for contraction-major operands (dgrad / wgrad without transposed copies) and for the DMA
 // schedule variants (gemm256_kernel.h SCHED), kept in their own translation unit so the two files compile in parallel.
 //
-// Measured on MI355X (tools/gemm_bench, uniform [-1,1) operands, profiles/r02_gemm_bench_cm_sched.log), TF/s for SCHED 0 / 1 / 2:
-//   forward layout  T=3076: qkv 880 / 834 / 856, gate 878 / 864 / 902, down+res 764 / 744 / 727; 4096^3 986 / 979 / 991; 8192^3 1048 / 1055 / 1052
-//                   -> the deeper DMA pipelines change nothing there (kept behind vila_gemm_force_sched for A/B runs); SCHED 9 (no DMA
-//                      in the loop at all) reaches 1130-1490: the loads cost 28-42 %, but as issue/LDS-write contention, not as latency
-//   dgrad (b_cm)    qkv 646 / 629 / 711, o 630 / 604 / 704, gate 653 / 625 / 739, down 790 / 781 / 861
-//   wgrad (a_cm+b_cm) qkv 804 / 820 / 910, o 673 / 680 / 753, gate 722 / 707 / 808, down 747 / 733 / 814
-//                   -> contraction-major sources touch 64 different rows per K-tile (longer, more variable DMA latency): the
-//                      two-tiles-ahead schedule with ONE extra barrier (SCHED 2) is worth +9-13 %; it is the default for these layouts
+// Measured on MI355X (tools/gemm_bench, uniform [-1,1) operands; logs under profiles/r02_gemm_bench_*.log), TF/s, T = 3076:
+//   schedule                          fwd qkv / o / gate / down      dgrad qkv / o / gate / down     wgrad qkv / o / gate / down
+//   0  lock-step, one tile ahead        917 /  700 /  896 /  796      646 /  630 /  653 /  790       804 /  673 /  722 /  747
+//   2  lock-step, two tiles ahead       no change for the forward      737 /  719 /  773 /  865       905 /  760 /  810 /  832
+//   6  role split, 8 barriers / tile    1014 /  780 / 1026 /  883      761 /  738 /  807 /  906       -8 % vs SCHED 2
+//   7  role split, 4 barriers / tile    1105 /  882 / 1117 /  969      845 /  843 /  888 /  955       983 /  813 /  830 /  839   <- default
+//   (wgrad gate / down with the whole-rounds + sliced-tail policy of gemm256.hip: 870 / 889)
 #include "gemm256_kernel.h"
 
 extern int g_gemm256_sched;
