@@ -257,6 +257,12 @@ int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* 
                        const int64_t* tok_strides, const int32_t* head_strides, const int32_t* cu_seqlens, int n_seq, int total_tokens,
                        int max_seqlen, int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, const float* lse, float* delta,
                        vila_stream_t stream);
+/* the same in separately launchable parts (bit mask): 1 = delta = rowsum(dO o O) (needed by the other two), 2 = dQ, 4 = dK / dV.  The parts
+ * share no output: once delta is done a trainer runs dQ and dK / dV on different streams (vila_amd/train.py, VILA_SFT_ATTN_STREAM) */
+int vila_attn_bwd_bf16_parts(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                             const int64_t* tok_strides, const int32_t* head_strides, const int32_t* cu_seqlens, int n_seq, int total_tokens,
+                             int max_seqlen, int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, const float* lse, float* delta,
+                             int parts, vila_stream_t stream);
 /* torch.optim.AdamW semantics on flat buffers: fp32 master/m/v, bf16 grad in (times grad_scale), bf16 param out */
 int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);

@@ -2,7 +2,9 @@
 kernels go — kernels or the gaps between them?
 usage: python tools/rocpd_timeline.py trace_results.db <first-kernel-substring> <last-kernel-substring> [occurrence=-1] [out.txt]
 e.g.   python tools/rocpd_timeline.py gpurun_out/prof_r02/trace_results.db im2col_kernel argmax_stage2 -1 profiles/r02_ttft_timeline.txt
-The window runs from the start of the chosen occurrence of the first marker to the end of the next occurrence of the last marker."""
+The window runs from the start of the chosen occurrence of the first marker to the end of the next occurrence of the last marker;
+with "@next" as the last marker it runs to the start of the NEXT occurrence of the first marker (one period, e.g. one training step).
+Per-stream busy time is printed as well (kernels of different streams overlap)."""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -16,11 +18,17 @@ starts = [i for i, r in enumerate(rows) if first in r[0]]
 if not starts:
     sys.exit(f"no kernel matching {first!r}")
 i0 = starts[occ]
-i1 = next((i for i in range(i0, len(rows)) if last in rows[i][0]), None)
-if i1 is None:
-    sys.exit(f"no kernel matching {last!r} after the marker")
+if last == "@next":
+    k = starts.index(i0)
+    if k + 1 >= len(starts):
+        sys.exit("no later occurrence of the first marker")
+    i1 = starts[k + 1] - 1
+else:
+    i1 = next((i for i in range(i0, len(rows)) if last in rows[i][0]), None)
+    if i1 is None:
+        sys.exit(f"no kernel matching {last!r} after the marker")
 win = rows[i0:i1 + 1]
-t0, t1 = win[0][1], win[-1][2]
+t0, t1 = win[0][1], (rows[i1 + 1][1] if last == "@next" else win[-1][2])
 busy, cur_end, gaps = 0, t0, []
 per = defaultdict(lambda: [0, 0])
 for k, (name, s, e, _) in enumerate(win):
@@ -33,6 +41,10 @@ for k, (name, s, e, _) in enumerate(win):
 tot = t1 - t0
 print(f"window: {len(win)} kernels, {tot / 1e3:.1f} us wall; busy (union of kernels) {busy / 1e3:.1f} us = {100 * busy / tot:.1f} %; "
       f"gaps {sum(g[0] for g in gaps) / 1e3:.1f} us in {len(gaps)} gaps", file=out)
+per_stream = defaultdict(int)
+for name, s_, e_, st in win:
+    per_stream[st] += e_ - s_
+print("per stream busy (us): " + ", ".join(f"stream {k}: {v / 1e3:.1f}" for k, v in sorted(per_stream.items(), key=lambda kv: -kv[1])), file=out)
 print("\nper kernel (calls, total us, avg us):", file=out)
 for name, (c, d) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     print(f"  {c:5d} {d / 1e3:10.1f} {d / c / 1e3:9.2f}  {name[:120]}", file=out)

@@ -148,6 +148,8 @@ PROTOTYPES = {
     "vila_rope_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vila_attn_bwd_bf16": (c_int, [c_void_p] * 8 + [C.POINTER(c_int64), C.POINTER(C.c_int32), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vila_attn_bwd_bf16_parts": (c_int, [c_void_p] * 8 + [C.POINTER(c_int64), C.POINTER(C.c_int32), c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "vila_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
     "vila_adamw_step_lean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,

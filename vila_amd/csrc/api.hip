@@ -599,10 +599,10 @@ extern "C" int vila_rope_fwd_bf16(void* qkv, const float* cs, const float* sn, c
 extern "C" int vila_rope_bwd_bf16(void* dqkv, const float* cs, const float* sn, int S_, int nq, int nkv, int hd, vila_stream_t stream) {
     return launch_rope_bwd(B(dqkv), cs, sn, S_, nq, nkv, hd, S(stream));
 }
-extern "C" int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+extern "C" int vila_attn_bwd_bf16_parts(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
                                   const int64_t* tok_strides /*[8] q,k,v,o,do,dq,dk,dv*/, const int32_t* head_strides /*[8]*/,
                                   const int32_t* cu_seqlens, int n_seq, int total_tokens, int max_seqlen, int n_q_heads, int n_kv_heads,
-                                  int head_dim, int causal, float scale, const float* lse, float* delta, vila_stream_t stream) {
+                                  int head_dim, int causal, float scale, const float* lse, float* delta, int parts, vila_stream_t stream) {
     AttnBwdArgs a{};
     a.q = B(q); a.k = B(k); a.v = B(v); a.o = B(o); a.d_o = B(d_o); a.dq = B(dq); a.dk = B(dk); a.dv = B(dv);
     a.q_tok_stride = tok_strides[0]; a.k_tok_stride = tok_strides[1]; a.v_tok_stride = tok_strides[2]; a.o_tok_stride = tok_strides[3];
@@ -612,7 +612,14 @@ extern "C" int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, c
     for (int i = 0; i < 8; ++i) VILA_REQUIRE(tok_strides[i] % 8 == 0 && head_strides[i] % 8 == 0, "attn_bwd: strides must be multiples of 8 elements");
     a.cu_seqlens = cu_seqlens; a.n_seq = n_seq; a.total_tokens = total_tokens; a.max_seqlen = max_seqlen;
     a.n_q_heads = n_q_heads; a.n_kv_heads = n_kv_heads; a.head_dim = head_dim; a.causal = causal; a.scale = scale; a.lse = lse; a.delta = delta;
-    return launch_attn_bwd(a, S(stream));
+    return launch_attn_bwd(a, S(stream), parts);
+}
+extern "C" int vila_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                                  const int64_t* tok_strides, const int32_t* head_strides, const int32_t* cu_seqlens, int n_seq, int total_tokens,
+                                  int max_seqlen, int n_q_heads, int n_kv_heads, int head_dim, int causal, float scale, const float* lse, float* delta,
+                                  vila_stream_t stream) {
+    return vila_attn_bwd_bf16_parts(q, k, v, o, d_o, dq, dk, dv, tok_strides, head_strides, cu_seqlens, n_seq, total_tokens, max_seqlen, n_q_heads,
+                                    n_kv_heads, head_dim, causal, scale, lse, delta, 7, stream);
 }
 extern "C" int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
                                float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream) {

@@ -432,8 +432,10 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void attn_bwd_dkv_kernel
     }
 }
 
+// parts: 1 = delta (rowsum(dO o O), needed by both others), 2 = dQ, 4 = dK / dV.  The three launches share no output, so a caller may put
+// dQ and dK / dV on different streams once delta is done (vila_attn_bwd_bf16_parts)
 template <int HD, bool CAUSAL>
-static int launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
+static int launch_bwd_t(const AttnBwdArgs& a, hipStream_t s, int parts) {
     constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
     const size_t lds_dq = (size_t)(2 * 64 * (HDP + 8) + DN * 16 * 72) * 2;
     const size_t lds_stage = (size_t)(2 * 32 * (HDP + 8) + 2 * DN * 16 * 40) * 2;
@@ -445,24 +447,31 @@ static int launch_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
         VILA_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, CAUSAL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv2));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.total_tokens * a.n_q_heads, 16)), dim3(256), 0, s, a);
-    VILA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL>), dim3(cdiv(a.max_seqlen, 64), a.n_q_heads, a.n_seq), dim3(256), lds_dq, s, a);
-    VILA_LAUNCH_CHECK();
-    const dim3 grid_kv(cdiv(a.max_seqlen, 64), a.n_kv_heads, a.n_seq);
-    if ((int64_t)grid_kv.x * grid_kv.y * grid_kv.z <= 320) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 2>), grid_kv, dim3(512), lds_kv2, s, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 1>), grid_kv, dim3(256), lds_kv1, s, a);
-    VILA_LAUNCH_CHECK();
+    if (parts & 1) {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.total_tokens * a.n_q_heads, 16)), dim3(256), 0, s, a);
+        VILA_LAUNCH_CHECK();
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL>), dim3(cdiv(a.max_seqlen, 64), a.n_q_heads, a.n_seq), dim3(256), lds_dq, s, a);
+        VILA_LAUNCH_CHECK();
+    }
+    if (parts & 4) {
+        const dim3 grid_kv(cdiv(a.max_seqlen, 64), a.n_kv_heads, a.n_seq);
+        if ((int64_t)grid_kv.x * grid_kv.y * grid_kv.z <= 320) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 2>), grid_kv, dim3(512), lds_kv2, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, 1>), grid_kv, dim3(256), lds_kv1, s, a);
+        VILA_LAUNCH_CHECK();
+    }
     return 0;
 }
 
-int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
+int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s, int parts) {
+    VILA_REQUIRE(parts >= 1 && parts <= 7, "attn_bwd: parts must be a combination of 1 (delta), 2 (dQ), 4 (dK/dV)");
     VILA_REQUIRE(a.n_seq >= 1 && a.total_tokens >= 1 && a.max_seqlen >= 1, "attn_bwd: empty input");
     VILA_REQUIRE(a.n_q_heads % a.n_kv_heads == 0, "attn_bwd: q heads must be a multiple of kv heads");
     VILA_REQUIRE(a.cu_seqlens != nullptr || (int64_t)a.n_seq * a.max_seqlen == a.total_tokens, "attn_bwd: uniform batches need total = n_seq*max_seqlen");
     VILA_REQUIRE(a.lse != nullptr && a.delta != nullptr, "attn_bwd: lse / delta workspace missing");
-    if (a.head_dim == 128) return a.causal ? launch_bwd_t<128, true>(a, s) : launch_bwd_t<128, false>(a, s);
-    if (a.head_dim == 72) return a.causal ? launch_bwd_t<72, true>(a, s) : launch_bwd_t<72, false>(a, s);
-    if (a.head_dim == 64) return a.causal ? launch_bwd_t<64, true>(a, s) : launch_bwd_t<64, false>(a, s);
+    if (a.head_dim == 128) return a.causal ? launch_bwd_t<128, true>(a, s, parts) : launch_bwd_t<128, false>(a, s, parts);
+    if (a.head_dim == 72) return a.causal ? launch_bwd_t<72, true>(a, s, parts) : launch_bwd_t<72, false>(a, s, parts);
+    if (a.head_dim == 64) return a.causal ? launch_bwd_t<64, true>(a, s, parts) : launch_bwd_t<64, false>(a, s, parts);
     VILA_FAIL(-1, "attn_bwd: unsupported head_dim %d", a.head_dim);
 }

@@ -346,8 +346,11 @@ def rope_bwd_(dqkv: torch.Tensor, cs, sn, nq: int, nkv: int, hd: int) -> None:
     check(_L().vila_rope_bwd_bf16(dqkv.data_ptr(), cs.data_ptr(), sn.data_ptr(), dqkv.shape[0], nq, nkv, hd, _stream()), "rope_bwd")
 
 
-def attn_bwd(q, k, v, o, do, lse, causal: bool, dq, dk, dv, scale: Optional[float] = None, cu_seqlens=None, max_seqlen=None, n_seq: int = 1):
-    """All of q,k,v,o,do,dq,dk,dv are [T, H, D] views (last dim contiguous).  lse [Hq, T] fp32 from attn_fwd(return_lse=True)."""
+def attn_bwd(q, k, v, o, do, lse, causal: bool, dq, dk, dv, scale: Optional[float] = None, cu_seqlens=None, max_seqlen=None, n_seq: int = 1,
+             parts: int = 7, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All of q,k,v,o,do,dq,dk,dv are [T, H, D] views (last dim contiguous).  lse [Hq, T] fp32 from attn_fwd(return_lse=True).
+    parts (bit mask): 1 = delta = rowsum(dO o O), 2 = dQ, 4 = dK / dV; the default does all three.  Returns delta [Hq, T] fp32, to be
+    passed back in when the parts are launched separately (dQ and dK / dV share no output and may run on different streams)."""
     import ctypes as C
     T, Hq, D = q.shape
     Hkv = k.shape[1]
@@ -357,10 +360,15 @@ def attn_bwd(q, k, v, o, do, lse, causal: bool, dq, dk, dv, scale: Optional[floa
         n_seq = cu_seqlens.numel() - 1
     else:
         max_seqlen = T // n_seq
-    delta = torch.empty((Hq, T), device=q.device, dtype=torch.float32)
-    check(_L().vila_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                  ts, hs, _p(cu_seqlens), n_seq, T, int(max_seqlen), Hq, Hkv, D, int(causal),
-                                  float(scale if scale is not None else D ** -0.5), lse.data_ptr(), delta.data_ptr(), _stream()), "attn_bwd")
+    if delta is None:
+        if not parts & 1:
+            raise ValueError("attn_bwd: parts without 1 (delta) need the delta tensor of an earlier call")
+        delta = torch.empty((Hq, T), device=q.device, dtype=torch.float32)
+    check(_L().vila_attn_bwd_bf16_parts(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                        dv.data_ptr(), ts, hs, _p(cu_seqlens), n_seq, T, int(max_seqlen), Hq, Hkv, D, int(causal),
+                                        float(scale if scale is not None else D ** -0.5), lse.data_ptr(), delta.data_ptr(), int(parts), _stream()),
+          "attn_bwd")
+    return delta
 
 
 def adamw_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0, lean: bool = False) -> None:

@@ -227,6 +227,9 @@ class SFTTrainer:
         flag = lambda name, default: os.environ.get(name, default) not in ("0", "", "false")
         self.side = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_SIDE", "1")) else None
         self.opt = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_OPT_STREAM", "1")) else None
+        # dK / dV on its own stream beside dQ: measured 211.3 / 209.7 -> 210.3 / 209.7 ms, i.e. nothing (the chip already runs ~2 kernels at a
+        # time and the step is throughput-bound): off by default, kept as a switch
+        self.attn_s = torch.cuda.Stream(device=dev) if (on_gpu and flag("VILA_SFT_ATTN_STREAM", "0")) else None
         self.use_c_abi = flag("VILA_SFT_C_ABI", "0")            # step(): forward+backward as ONE vila_sft_fwd_bwd call (else Python-orchestrated ops)
         self.lean_adamw = flag("VILA_SFT_LEAN_ADAMW", "1")      # <= 32-VGPR optimizer kernel: co-resident with the GEMM blocks
         self.cm = flag("VILA_SFT_CM", "1")  # dgrad / wgrad on the tensors as they lie (no transposed copies) where the shapes allow
@@ -236,6 +239,21 @@ class SFTTrainer:
         self.cm_vit = self.cm and flag("VILA_SFT_CM_VIT", "1")
         self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.side is not None) else None   # the side stream's own slabs
         self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
+
+    def _attn_bwd(self, *a, **kw) -> None:
+        """Flash-attention backward.  dQ and dK / dV share no output and both under-fill the chip (208 blocks at 4 x 769 tokens, 4-13 % of the
+        MFMA rate), so once delta is done dK / dV runs on its own stream beside dQ and the two meet again in front of the QKV dgrad."""
+        if self.attn_s is None:
+            ops.attn_bwd(*a, **kw)
+            return
+        main = torch.cuda.current_stream()
+        delta = ops.attn_bwd(*a, parts=1, **kw)
+        self.attn_s.wait_event(main.record_event())                     # delta, dO and the saved q / k / v are final
+        with torch.cuda.stream(self.attn_s):
+            ops.attn_bwd(*a, parts=4, delta=delta, **kw)
+            done = self.attn_s.record_event()
+        ops.attn_bwd(*a, parts=2, delta=delta, **kw)
+        main.wait_event(done)                                            # (every later use or free of these tensors is ordered behind this)
 
     def _ready(self, prefix: str) -> None:
         """Gradients under `prefix` are final once the compute stream and the wgrad stream reach this point: hand the bucket to the
@@ -323,8 +341,8 @@ class SFTTrainer:
             da = linear_bwd(s.a.view(B * N, D), P(l + "self_attn.out_proj.weight"), dx_mid, G(l + "self_attn.out_proj.weight"), G(l + "self_attn.out_proj.bias"), **kw)
             dqkv = torch.empty_like(s.qkv)
             q3, d3 = s.qkv.view(B * N, 3 * H, hd), dqkv.view(B * N, 3 * H, hd)
-            ops.attn_bwd(q3[:, :H], q3[:, H:2 * H], q3[:, 2 * H:], s.a, da.view(B * N, H, hd), s.lse, False,
-                         d3[:, :H], d3[:, H:2 * H], d3[:, 2 * H:], n_seq=B)
+            self._attn_bwd(q3[:, :H], q3[:, H:2 * H], q3[:, 2 * H:], s.a, da.view(B * N, H, hd), s.lse, False,
+                           d3[:, :H], d3[:, H:2 * H], d3[:, 2 * H:], n_seq=B)
             dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"), **kw)
             dxi = ops.norm_bwd(s.x_in, P(l + "layer_norm1.weight"), dh1, G(l + "layer_norm1.weight"), G(l + "layer_norm1.bias"), v.layer_norm_eps, False)
             dx = ops.add(dx_mid, dxi)
@@ -425,8 +443,8 @@ class SFTTrainer:
             da = linear_bwd(s.a.view(T, nq * hd), P(l + "self_attn.o_proj.weight"), dx_mid, G(l + "self_attn.o_proj.weight"), **kw)
             dqkv = torch.empty_like(s.qkv)
             q3, d3 = s.qkv.view(T, nq + 2 * nkv, hd), dqkv.view(T, nq + 2 * nkv, hd)
-            ops.attn_bwd(q3[:, :nq], q3[:, nq:nq + nkv], q3[:, nq + nkv:], s.a, da.view(T, nq, hd), s.lse, True,
-                         d3[:, :nq], d3[:, nq:nq + nkv], d3[:, nq + nkv:], cu_seqlens=saved.cu, max_seqlen=saved.max_seqlen)
+            self._attn_bwd(q3[:, :nq], q3[:, nq:nq + nkv], q3[:, nq + nkv:], s.a, da.view(T, nq, hd), s.lse, True,
+                           d3[:, :nq], d3[:, nq:nq + nkv], d3[:, nq + nkv:], cu_seqlens=saved.cu, max_seqlen=saved.max_seqlen)
             ops.rope_bwd_(dqkv, saved.cs, saved.sn, nq, nkv, hd)
             dh1 = linear_bwd(s.h1, self._fused(l + "self_attn.", "weight"), dqkv, self._fused_grad(l + "self_attn.", "weight"), self._fused_grad(l + "self_attn.", "bias"), **kw)
             dxi = ops.norm_bwd(s.x_in, P(l + "input_layernorm.weight"), dh1, G(l + "input_layernorm.weight"), None, c.rms_norm_eps, True)
