@@ -1,0 +1,50 @@
+#!/bin/bash
+# Full GPU validation pass: test-suite, every bench line (default, SFT, C-ABI SFT, forced process group, other modes), MFMA counters,
+# kernel traces and the TTFT timeline.  Run on the GPU box from the repo root (gpurun -- bash tools/validate_gpu.sh); results under gpurun_out/.
+cd "$GRAFT_REPO_ROOT" || exit 1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p "$O"
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > "$O/val_pytest.log"
+tail -3 "$O/val_pytest.log"
+for i in 1 2; do
+  timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_$i.err" | tee "$O/val_sft_$i.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
+done
+VILA_SFT_C_ABI=1 timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_c.err" | tee "$O/val_sft_c.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft c-abi ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
+VILA_BENCH_FORCE_DIST=1 timeout 300 python bench.py --mode sft --steps 3 --warmup 1 2>"$O/val_sft_forcedist.err" | tee "$O/val_sft_forcedist.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[0]); print('sft force-dist (nccl, world 1) ->', d['ms_per_step'], 'ms')"
+timeout 600 python bench.py > "$O/val_bench.json" 2> "$O/val_bench.err"
+python - <<'P'
+import json
+try:
+    d = json.loads(open("gpurun_out/val_bench.json").read().strip().splitlines()[-1])
+    print("value", d["value"], "ttft", d["ttft_ms"], "prefill frac", d["prefill"]["roofline"]["frac"], "sft", d.get("sft", {}).get("ms_per_step"), "sustained", d.get("sustained", {}).get("tokens_per_s"))
+except Exception as e:
+    print("bench parse failed", e)
+P
+: > "$O/val_other_modes.jsonl"
+for args in "--w4" "--w8-vit" "--dynamic-s2" "--mode video" "--mode video --tsp"; do
+  timeout 400 python bench.py $args --no-sft --no-sustain --no-cpu-baseline 2>>"$O/val_other_modes.err" | tail -1 >> "$O/val_other_modes.jsonl"
+done
+python - <<'P'
+import json
+for line in open("gpurun_out/val_other_modes.jsonl"):
+    try:
+        d = json.loads(line); print(d.get("metric", "")[:60], "|", d.get("value"), d.get("unit"), "| ttft", d.get("ttft_ms"), "| ms/step", d.get("ms_per_step"))
+    except Exception as e:
+        print("bad line", e)
+P
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tail -1
+cp "$O/pmc_mfma_val_sft/summary.txt" "$O/val_pmc_mfma_sft_step.txt" 2>/dev/null
+timeout 600 bash tools/pmc_mfma.sh val_ttft --no-sft --no-sustain --steps 8 --warmup 2 | tail -1
+cp "$O/pmc_mfma_val_ttft/summary.txt" "$O/val_pmc_mfma_ttft_decode.txt" 2>/dev/null
+timeout 600 bash tools/profile.sh val_sft --mode sft --steps 3 --warmup 1 2>&1 | tail -1
+if [ -f "$O/prof_val_sft/trace_results.db" ]; then
+  python tools/rocpd_summary.py "$O/prof_val_sft/trace_results.db" "$O/val_sft_kernel_stats.csv"; rm -f "$O/prof_val_sft/trace_results.db"
+fi
+timeout 600 bash tools/profile.sh val --no-sft --no-sustain --steps 32 --warmup 8 2>&1 | tail -1
+if [ -f "$O/prof_val/trace_results.db" ]; then
+  python tools/rocpd_summary.py "$O/prof_val/trace_results.db" "$O/val_bench_kernel_stats.csv"
+  python tools/rocpd_timeline.py "$O/prof_val/trace_results.db" im2col_kernel argmax_stage2 -4 "$O/val_ttft_timeline.txt"
+  rm -f "$O/prof_val/trace_results.db"
+fi
+find "$O" -name "*.db" -size +1M -delete
+head -8 "$O/val_pmc_mfma_sft_step.txt"
