@@ -209,6 +209,9 @@ int vila_gemm_bf16_t(const void* A, int64_t lda, int a_cm, const void* W, int64_
 void vila_gemm_force_sched(int sched);
 /* tuning hook for the launch policy fed by a workspace: whole rounds of 256x256 tiles + K-sliced tail tiles (1 = on, default; 0 = off) */
 void vila_gemm_force_hybrid(int on);
+/* tuning hook for the decode step's attention (caches up to 2048 positions): 2 (default) / 1 = per-head blocks over 256-key slices with the
+ * merge in the o_proj GEMV's prologue (512 / 256 o_proj blocks), 0 = one block per query head over the whole context + plain o_proj */
+void vila_decode_force_attn(int mode);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */

@@ -125,6 +125,36 @@ def test_decode_matches_prefill_logits(case):
     assert rel_l2(lg, ref) < 1.5e-2, f"decode vs prefill rel={rel_l2(lg, ref):.3e}"
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_decode_attention_over_256_key_slices_matches_the_single_block_kernel(mode):
+    """vila_decode_force_attn: per-head blocks over 256-key slices + the merge in the o_proj GEMV prologue (2 = default, 1 = fewer o_proj
+    blocks) must give the logits of the one-block-per-head kernel (0; same math, another summation order) — on a context long enough for
+    three active slices, eager and through the captured graph."""
+    from vila_amd import _lib
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    cfg = configs.tiny("mlp_downsample")
+    model = build_model(cfg, seed=5)
+    H = cfg.llm.hidden_size
+    g = torch.Generator().manual_seed(3)
+    e = (torch.randn(1, 600, H, generator=g) * 0.5).to(torch.bfloat16).cuda()          # 600 prompt rows -> slices 0..2 active while decoding
+    n = 6
+    lib.vila_decode_force_attn(0)
+    model.llm._invalidate()
+    ids0, lg0 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, use_graph=False, eos_token_id=-1)
+    try:
+        lib.vila_decode_force_attn(mode)
+        model.llm._invalidate()
+        ids1, lg1 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, forced_ids=ids0[0].cpu(), use_graph=False, eos_token_id=-1)
+        idsg = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)
+        idse = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=False, eos_token_id=-1)
+    finally:
+        lib.vila_decode_force_attn(2)
+        model.llm._invalidate()
+    assert rel_l2(lg1, lg0) < 5e-3, f"split-256 vs single-block decode logits rel={rel_l2(lg1, lg0):.3e}"
+    assert torch.equal(idsg, idse)
+
+
 def test_vlm_generate_end_to_end(case):
     cfg, seed, fx, w, model = case
     px = synthetic.make_pixels(cfg, 2, seed).to(torch.bfloat16)

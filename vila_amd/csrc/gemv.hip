@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     if (early) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
     if (has) epi_fetch(g);
     if constexpr (MODE == 2) {
-        const int n_active = (*p.pos_ptr + DEC_KS) / DEC_KS;     // ceil((pos+1)/KS)
+        const int ks = p.split_keys > 0 ? p.split_keys : DEC_KS;
+        const int n_active = (*p.pos_ptr + ks) / ks;             // ceil((pos+1)/ks)
         stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
     } else {
         stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
@@ -213,8 +214,10 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
     } else if (a.mode == 2) {
         VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
         lds += (size_t)a.n_splits * (a.K / 128) * 4;
-        if (grid > 256) grid = 256;     // the merge prologue is paid per block: keep ~1 block per CU
-        hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        const int cap = a.grid_cap > 0 ? a.grid_cap : 256;           // the merge prologue is paid per block: default ~1 block per CU
+        if (grid > cap) grid = cap;
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
         if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, a, n_groups);
@@ -434,13 +437,19 @@ __global__ __launch_bounds__(128) void attn_decode_merge(AttnDecodeArgs p) {
 // price is that the G = 7 query heads of a kv head each read that head's K/V (served by L2 / MALL, 2.5 % of a token's bytes).
 //   scores: lane = (key = lane/4, d quarter = lane%4): 32 FMAs + 2 cross-lane adds;  P.V: lane = (4-key subgroup, 8-wide d chunk)
 // ------------------------------------------------------------------------------------------------
+// SPLIT: grid (nq, ceil(max_ctx / 256)); block (h, s) covers keys [256 s, 256 s + 256) — ONE 16-key chunk per wave, no loop — and writes the
+// un-normalised partial (o, m, l) of that slice; the merge over the <= 8 slices happens in the o_proj GEMV's prologue (gemv_kernel<2>).
+template <bool SPLIT>
 __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     __shared__ float sq[128];
     __shared__ float so[16][128];
     __shared__ float sml[16][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, kvh = h / (p.nq / p.nkv);
-    const int nkeys = *p.pos_ptr + 1;
+    const int key_lo = SPLIT ? blockIdx.y * 256 : 0;
+    const int nkeys_all = *p.pos_ptr + 1;
+    if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
+    const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
     const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
     const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
     if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
             vv[j] = (vk < nkeys) ? *(const u32x4*)(vb + (int64_t)vk * 128 + dc * 8) : (u32x4){0u, 0u, 0u, 0u};
         }
     };
-    int k0 = wave * 16;
+    int k0 = key_lo + wave * 16;
     if (k0 < nkeys) load_chunk(k0, kc, vc);
     for (; k0 < nkeys; k0 += 256) {
         const int kn = k0 + 256;
@@ -525,7 +534,13 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
             L += wgt * sml[w][1];
             acc += wgt * so[w][tid];
         }
-        p.o[h * 128 + tid] = f2bf(acc / L);
+        if (SPLIT) {
+            const int64_t slot = (int64_t)blockIdx.y * p.nq + h;
+            p.part_o[slot * 128 + tid] = acc;
+            if (tid == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
+        } else {
+            p.o[h * 128 + tid] = f2bf(acc / L);
+        }
     }
 }
 
@@ -533,8 +548,14 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.hd == 128, "attn_decode: head_dim must be 128 (got %d)", a.hd);
     VILA_REQUIRE(a.nq % a.nkv == 0 && a.nq / a.nkv <= DEC_MAXG, "attn_decode: GQA group %d/%d unsupported (max %d)", a.nq, a.nkv, DEC_MAXG);
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
+    if (a.split256) {                                            // partials per 256-key slice; merged by the o_proj GEMV (mode 2, split_keys 256)
+        VILA_REQUIRE(a.max_ctx <= 2048 && a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: 256-key slices need max_ctx <= 2048");
+        hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
+        VILA_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.o != nullptr && a.max_ctx <= 2048 && !a.force_split) {
-        hipLaunchKernelGGL(attn_decode_head, dim3(a.nq), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(attn_decode_head<false>, dim3(a.nq), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
         return 0;
     }

@@ -82,6 +82,8 @@ struct GemvArgs {
     float* y_f32;             // [N] fp32 out (logits) (or null)
     int N, K; int mode;       // 0 plain, 1 gate/up silu-mul, 2 plain with x = merge of the decode-attention partials
     const float* part_o; const float* part_ml; const int32_t* pos_ptr; int n_splits;   // mode 2
+    int split_keys;           // mode 2: keys per partial slice (0 = the 64-key slices of attn_decode_partial)
+    int grid_cap;             // mode 2: upper bound of the grid (0 = 256 blocks)
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
 struct QkvDecodeArgs {
@@ -101,6 +103,7 @@ struct AttnDecodeArgs {
     const int32_t* pos_ptr;          // context length BEFORE this token; keys 0..pos inclusive are attended
     int nq, nkv, hd, max_ctx, n_splits; float scale;
     int force_split;                 // 1: always use the split-KV + merge pair (default: single-launch per-head kernel when max_ctx <= 2048)
+    int split256;                    // 1: per-head blocks over 256-key slices, partials only (merged in the o_proj GEMV prologue)
 };
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
