@@ -371,8 +371,6 @@ def decode_main(a, rank, world, dev, dist):
     from vila_amd import _lib, configs, ops, synthetic
     from vila_amd.vlm import build_model
     lib = _lib.load()
-    if os.environ.get("VILA_DECODE_ATTN"):                       # A/B switch for the decode attention variants (vila_decode_force_attn)
-        lib.vila_decode_force_attn(int(os.environ["VILA_DECODE_ATTN"]))
     cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
     n_tiles, media_cfg = 1, {}
     if a.dynamic_s2:

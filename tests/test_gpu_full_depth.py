@@ -59,9 +59,14 @@ def test_full_depth_logits_and_ids_vs_oracle_golden():
     got = lg.float().cpu().gather(1, top_ids)
     rel = rel_l2(got, top_vals)
     assert rel < 3e-2, f"full-depth logits (top-32 entries of 1 prefill + {n - 1} decode rows) rel={rel:.3e}"
-    err = float((got - top_vals).abs().max())
-    decisive = (top_vals[:, 0] - top_vals[:, 1]) > 4 * err
-    assert bool(decisive.any()), f"no decisive step: err {err:.3e}, margins {(top_vals[:, 0] - top_vals[:, 1]).tolist()}"
+    # SURVEY §8c id rule with the error observed AT EACH STEP (max-abs over that step's 32 fixture entries): one global maximum over all
+    # 8 x 32 entries made the rule hinge on a single outlier entry and on one step of this fixture (margins 0.2 .. 1.5 against a 0.37-0.41
+    # worst entry: two summation orders of the same decode attention flipped it between "1 decisive step" and "none")
+    err_t = (got - top_vals).abs().max(dim=1).values
+    err = float(err_t.max())
+    decisive = (top_vals[:, 0] - top_vals[:, 1]) > 4 * err_t
+    print(f"full depth: per-step max-abs err {[round(float(x), 3) for x in err_t]}, margins {[round(float(x), 3) for x in (top_vals[:, 0] - top_vals[:, 1])]}")
+    assert bool(decisive.any()), f"no decisive step: per-step err {err_t.tolist()}, margins {(top_vals[:, 0] - top_vals[:, 1]).tolist()}"
     am = lg.float().cpu().argmax(-1)
     assert torch.equal(am[decisive], gold[decisive]), f"ids {am.tolist()} vs oracle {gold.tolist()} (err {err:.3e}, decisive {decisive.tolist()})"
     # free-running greedy through the captured hipGraph: identical to the oracle until the first non-decisive step

@@ -394,8 +394,12 @@ extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max
 // decode attention variant (vila_decode_force_attn): 2 (default) = per-head blocks over 256-key slices, merged in the prologue of the o_proj GEMV
 // (512 blocks); 1 = the same with 256 o_proj blocks; 0 = one block per query head over the whole context + plain o_proj (round 1).
 // Measured at context 785..913 (bench.py): 328.7 / 335.7 / 342.0 tok/s for 0 / 1 / 2.
-static int g_decode_attn = 2;
+static int g_decode_attn = -1;     // -1: not set yet -> environment VILA_DECODE_ATTN, else 2
 extern "C" void vila_decode_force_attn(int mode) { g_decode_attn = mode; }
+static int decode_attn_mode() {
+    if (g_decode_attn < 0) { const char* e = getenv("VILA_DECODE_ATTN"); g_decode_attn = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    return g_decode_attn;
+}
 static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
                             const VilaSampling* sp, vila_stream_t stream);
 extern "C" int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
@@ -453,12 +457,12 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
         ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
-        const bool split256 = g_decode_attn >= 1 && cache->max_ctx <= 2048 && hd == 128;
+        const bool split256 = decode_attn_mode() >= 1 && cache->max_ctx <= 2048 && hd == 128;
         ad.split256 = split256 ? 1 : 0;
         VILA_TRY(launch_attn_decode(ad, s));
         GemvArgs o{};
         o.x = ao; o.W = B(L.wo); o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
-        if (split256) { o.mode = 2; o.part_o = part_o; o.part_ml = part_ml; o.pos_ptr = st->pos; o.n_splits = cdiv(cache->max_ctx, 256); o.split_keys = 256; o.grid_cap = g_decode_attn == 2 ? 512 : 256; }
+        if (split256) { o.mode = 2; o.part_o = part_o; o.part_ml = part_ml; o.pos_ptr = st->pos; o.n_splits = cdiv(cache->max_ctx, 256); o.split_keys = 256; o.grid_cap = decode_attn_mode() == 2 ? 512 : 256; }
         VILA_TRY(launch_gemv(o, s));
         GemvArgs gu{};
         gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.W = B(L.w_gate); gu.W2 = B(L.w_up); gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
