@@ -1,6 +1,6 @@
 // Standalone GEMM micro-benchmark + spot-check for libvila_hip.so (no PyTorch: a gpurun call with it costs seconds, not minutes).
 //   build:  hipcc -O2 -std=c++17 tools/gemm_bench.cpp -o tools/gemm_bench -Lvila_amd/lib -lvila_hip -Wl,-rpath,'$ORIGIN/../vila_amd/lib'
-//   run:    tools/gemm_bench [fwd|bwd|lay|pmc|pol|all]
+//   run:    tools/gemm_bench [fwd|bwd|lay|pmc|pol|bm|race|all]
 // For every shape and DMA schedule (vila_gemm_force_sched): HIP-event timing on the null stream (random uniform [-1,1) bf16 data —
 // the guide's rule 25: never quote zero-filled operands), TFLOP/s, and the max error of 384 sampled outputs against a double-precision
 // dot product on the host, relative to sqrt(K) (the scale of the sum).  Layout flags: a_cm / b_cm = operand stored [K][rows].
@@ -95,6 +95,45 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
 }
 
+// Race screen for the barrier-staggered schedules: the default schedule must reproduce the lock-step round-1 schedule BIT FOR BIT (every
+// accumulator receives the same MFMAs in the same order in both), on every one of `runs` launches — a hazard in the staggered groups'
+// LDS traffic would show up as occasional differing tiles.  K-sliced launch policies are switched off (they change the summation order).
+static int race_case(const Case& c, int runs, void* ws, size_t ws_bytes) {
+    Mat A = c.a_cm ? make(c.K, c.M, 1.0f) : make(c.M, c.K, 1.0f);
+    Mat W = c.b_cm ? make(c.K, c.N, 1.0f) : make(c.N, c.K, 1.0f);
+    Mat R = make(c.residual ? c.M : 1, c.residual ? c.N : 8, 1.0f);
+    const size_t n = (size_t)c.M * c.N;
+    uint16_t* C; CK(hipMalloc(&C, n * 2));
+    std::vector<uint16_t> ref(n), got(n);
+    const int64_t lda = c.a_cm ? c.M : c.K, ldw = c.b_cm ? c.N : c.K;
+    const bool cc = !c.a_cm && !c.b_cm;
+    auto call = [&]() {
+        int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, W.d, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
+        if (rc != 0) { fprintf(stderr, "  %s: rc=%d %s\n", c.name, rc, vila_last_error()); exit(3); }
+    };
+    vila_gemm_force_hybrid(0);
+    vila_gemm_force_tile(cc ? 4 : 0);
+    vila_gemm_force_sched(cc ? 10 : 1);                    // lock-step schedule (SCHED 0)
+    CK(hipMemset(C, 0xff, n * 2)); call(); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ref.data(), C, n * 2, hipMemcpyDeviceToHost));
+    vila_gemm_force_sched(0);
+    int bad_runs = 0; size_t bad_elems = 0;
+    for (int r = 0; r < runs; ++r) {
+        CK(hipMemset(C, 0xff, n * 2)); call(); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), C, n * 2, hipMemcpyDeviceToHost));
+        if (memcmp(got.data(), ref.data(), n * 2) != 0) {
+            ++bad_runs;
+            for (size_t i = 0; i < n; ++i) bad_elems += got[i] != ref[i];
+        }
+    }
+    printf("race %-28s M=%6d N=%6d K=%6d cm=%d%d res=%d : %d launches, %d differ from the lock-step schedule (%zu elements)%s\n", c.name, c.M, c.N, c.K,
+           c.a_cm, c.b_cm, c.residual, runs, bad_runs, bad_elems, bad_runs ? "  <-- MISMATCH" : "");
+    fflush(stdout);
+    vila_gemm_force_tile(0); vila_gemm_force_sched(0); vila_gemm_force_hybrid(1);
+    CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
+    return bad_runs;
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
@@ -133,6 +172,17 @@ int main(int argc, char** argv) {
     if (!strcmp(what, "bm")) {         // 256- vs 192-row tiles on the shapes with M = 3076
         for (int i : {0, 1, 2, 3, 4}) run_case(fwd[i], {256, 192, 256, 192}, ws, ws_bytes);
         for (int i : {0, 1, 2, 3, 4, 14}) run_case(bwd[i], {256, 192, 256, 192}, ws, ws_bytes);
+    }
+    if (!strcmp(what, "race")) {
+        std::vector<Case> rc = {
+            {"256^3", 256, 256, 256, 0, 0, 0}, {"512^3", 512, 512, 512, 0, 0, 0}, {"4096^3", 4096, 4096, 4096, 0, 0, 0},
+            {"fwd down+res", 3076, 3584, 18944, 0, 0, 1}, {"fwd o_proj (192-row tiles)", 3076, 3584, 3584, 0, 0, 1}, {"ragged cc", 1000, 1032, 1496, 0, 0, 1},
+            {"dgrad gate", 3076, 3584, 18944, 0, 1, 0}, {"dgrad ragged", 1000, 1032, 1496, 0, 1, 1},
+            {"wgrad qkv", 4608, 3584, 3076, 1, 1, 0}, {"wgrad ragged", 1032, 520, 777, 1, 1, 1}, {"a_cm only", 2048, 2048, 2048, 1, 0, 0},
+        };
+        int bad = 0;
+        for (auto& c : rc) bad += race_case(c, c.M * (int64_t)c.N > 8000000 ? 30 : 100, ws, ws_bytes);
+        printf("race screen: %s\n", bad ? "FAILED" : "clean");
     }
     if (!strcmp(what, "lay")) for (auto& c : lay) run_case(c, {0, 1}, ws, ws_bytes);
     if (!strcmp(what, "fwd") || !strcmp(what, "all")) for (auto& c : fwd) run_case(c, {0, 6, 10, 0, 6, 10}, ws, ws_bytes);     // default (SCHED 7) vs the 8-barrier role split vs round 1
