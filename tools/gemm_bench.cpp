@@ -45,16 +45,17 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
         if (sched == 9 && (c.a_cm || c.b_cm)) continue;
         // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
         // pseudo schedules 256 / 192: default kernels with that tile height forced (0 elsewhere = automatic)
+        const bool tilef = sched >= 300 && sched < 320;          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
         const bool bmf = sched == 256 || sched == 192;
         vila_gemm_force_bm(bmf ? sched : 0);
-        const bool pol = sched >= 100 && !bmf;
-        vila_gemm_force_sched((pol || bmf) ? 0 : sched);
+        const bool pol = sched >= 100 && !bmf && !tilef;
+        vila_gemm_force_sched((pol || bmf || tilef) ? 0 : sched);
         vila_gemm_force_hybrid(pol ? sched == 101 : 1);
         auto call = [&]() {
             int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, W.d, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
             if (rc != 0) { fprintf(stderr, "  %s sched %d: rc=%d %s\n", c.name, sched, rc, vila_last_error()); exit(3); }
         };
-        vila_gemm_force_tile((!c.a_cm && !c.b_cm && !pol) ? 4 : 0);          // forward layout: pin the 256x256 kernel so the schedules are comparable
+        vila_gemm_force_tile(tilef ? sched - 300 : (!c.a_cm && !c.b_cm && !pol) ? 4 : 0);          // forward layout: pin the 256x256 kernel so the schedules are comparable
         CK(hipMemset(C, 0xff, (size_t)c.M * c.N * 2));
         for (int i = 0; i < 3; ++i) call();
         CK(hipDeviceSynchronize());
@@ -172,6 +173,13 @@ int main(int argc, char** argv) {
     if (!strcmp(what, "bm")) {         // 256- vs 192-row tiles on the shapes with M = 3076
         for (int i : {0, 1, 2, 3, 4}) run_case(fwd[i], {256, 192, 256, 192}, ws, ws_bytes);
         for (int i : {0, 1, 2, 3, 4, 14}) run_case(bwd[i], {256, 192, 256, 192}, ws, ws_bytes);
+    }
+    if (!strcmp(what, "pre")) {        // prefill / tower shapes: automatic choice vs forced kernels (5 = split-K 256^2, 4 = 256^2, 7 = 128x64 ring, 8 = 128x128 ring)
+        std::vector<Case> pc = {
+            {"LLM qkv  S=768", 768, 4608, 3584, 0, 0, 0}, {"LLM o+res S=768", 768, 3584, 3584, 0, 0, 1},
+            {"ViT qkv  M=1024", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc2+res", 1024, 1152, 4304, 0, 0, 1},
+        };
+        for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
     }
     if (!strcmp(what, "race")) {
         std::vector<Case> rc = {
