@@ -278,6 +278,35 @@ def test_sft_step_updates_parameters_and_lowers_loss():
     assert out.shape == (1, 2)
 
 
+def test_captured_decode_graph_follows_the_weights_into_and_through_training():
+    """ADVICE (round 1): the decode hipGraph bakes weight pointers in.  generate -> SFTTrainer(model) (parameters move into the flat buffer)
+    -> generate -> training steps -> generate must never replay a graph that reads the old storage: after the move the captured path
+    reproduces the same ids, after training it agrees with the eager launches on the NEW weights (and the logits did change)."""
+    from vila_amd import configs, synthetic
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny("mlp_downsample")
+    model = build_model(cfg, seed=6)
+    px = synthetic.make_pixels(cfg, 1, 6).to(torch.bfloat16)
+    ids = synthetic.make_prompt(cfg, 16, 1, 6)[None]
+    media = {"image": [px[0].cuda()]}
+    kw = dict(max_new_tokens=6, eos_token_id=-1)
+    before = model.generate(input_ids=ids, media=media, **kw)                      # captures the graph on the original storage
+    e, _, _ = model._embed(ids, media)
+    _, lg0 = model.llm.generate(inputs_embeds=e, return_logits=True, use_graph=False, **kw)
+    tr = SFTTrainer(model, lr=5e-3)                                                # parameters become views of the flat buffer
+    moved = model.generate(input_ids=ids, media=media, **kw)
+    assert torch.equal(moved, before)
+    labels = ids.clone(); labels[:, :8] = -100
+    for _ in range(4):
+        tr.step(ids, [px[0].cuda()], labels)
+    e, _, _ = model._embed(ids, media)
+    graph = model.llm.generate(inputs_embeds=e, use_graph=True, **kw)
+    eager, lg1 = model.llm.generate(inputs_embeds=e, return_logits=True, use_graph=False, **kw)
+    assert torch.equal(graph, eager)
+    assert float((lg1[0] - lg0[0]).abs().max()) > 1e-2                            # the weights really moved
+
+
 def test_per_bucket_adamw_equals_one_flat_step():
     """The optimizer stream applies AdamW bucket by bucket as soon as a layer's gradients are final (overlapped with the backward of
     the layers below).  Same kernels, same gradients: after two steps the parameters, master copy and moments must equal those of the
