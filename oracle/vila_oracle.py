@@ -575,3 +575,24 @@ def encode_images_dynamic_s2(pixels_tiles, block_sizes, w, cfg) -> List[torch.Te
         m = merge_chessboard(part, b[0], b[1])                                   # [1, C, H, W]
         outs.append(m[0].flatten(1).transpose(0, 1))                             # "1 c h w -> (h w) c"
     return outs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampling: the distribution generate(do_sample=True) draws from
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_distribution(logits: torch.Tensor, temperature: float, top_k: int, top_p: float) -> torch.Tensor:
+    """HF's processor chain behind `llm.generate(..., do_sample=True)` (llava/model/llava_arch.py:833 -> GenerationMixin.sample; order of
+    `_get_logits_processor`): TemperatureLogitsWarper (logits / T) -> TopKLogitsWarper (keep the k largest; ties with the k-th stay) ->
+    TopPLogitsWarper (ascending cumulative softmax, drop while cum <= 1 - top_p, keep at least one) -> softmax.  fp64, one row.
+    Pinned by tests/golden/sampling_hf.npz, which oracle/make_golden_sampling.py produced by executing transformers' own classes."""
+    z = logits.double() / temperature
+    kth = torch.topk(z, min(top_k, z.numel())).values[-1]
+    z = z.masked_fill(z < kth, float("-inf"))
+    if top_p < 1.0:
+        srt, idx = torch.sort(z, descending=False)
+        cum = srt.softmax(-1).cumsum(-1)
+        remove = cum <= (1 - top_p)
+        remove[-1] = False                                   # min_tokens_to_keep = 1
+        z = z.masked_fill(torch.zeros_like(remove).scatter(0, idx, remove), float("-inf"))
+    return z.softmax(-1)
+

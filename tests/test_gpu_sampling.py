@@ -11,16 +11,31 @@ pytestmark = pytest.mark.gpu
 
 
 def _hf_distribution(logits, temperature, top_k, top_p):
-    """TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax, as in transformers/generation/logits_process.py."""
-    z = logits.double() / temperature
-    kth = torch.topk(z, top_k).values[-1]
-    z = z.masked_fill(z < kth, float("-inf"))
-    srt, idx = torch.sort(z, descending=False)
-    cum = srt.softmax(-1).cumsum(-1)
-    remove = cum <= (1 - top_p)
-    remove[-1] = False                                   # min_tokens_to_keep = 1
-    z = z.masked_fill(torch.zeros_like(remove).scatter(0, idx, remove), float("-inf"))
-    return z.softmax(-1)
+    """The oracle's restatement of HF's processor chain (pinned on CPU against transformers' own classes: tests/test_oracle_golden.py)."""
+    from oracle import vila_oracle as O
+    return O.sample_distribution(logits, temperature, top_k, top_p)
+
+
+def test_sampler_matches_the_hf_executed_fixture():
+    """tests/golden/sampling_hf.npz holds distributions produced by transformers' TemperatureLogitsWarper / TopKLogitsWarper /
+    TopPLogitsWarper themselves; the on-device sampler's post-filter probabilities must equal them (fp32 softmax on the device: 2e-5)."""
+    import os
+    import numpy as np
+    from vila_amd import ops
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling_hf.npz"))
+    n = 0
+    while f"c{n}_params" in fx:
+        V, temperature, top_k, top_p = fx[f"c{n}_params"]
+        logits = torch.from_numpy(fx[f"c{n}_logits"]).cuda()
+        ref = torch.from_numpy(fx[f"c{n}_probs"])
+        tok, dist, ids = ops.sample(logits, float(temperature), int(top_k), float(top_p), seed=n, return_dist=True)
+        got = torch.zeros(int(V), dtype=torch.float64)
+        valid = ids >= 0
+        got[ids[valid].long().cpu()] = dist[valid].double().cpu()
+        assert float((got - ref).abs().max()) < 2e-5, (n, float((got - ref).abs().max()))
+        assert float(ref[int(tok)]) > 0
+        n += 1
+    assert n >= 6
 
 
 @pytest.mark.parametrize("V,temperature,top_k,top_p", [(1000, 1.0, 50, 1.0), (152064, 0.2, 50, 0.9), (152064, 0.7, 64, 0.5), (5000, 1.5, 1, 0.9), (300, 0.9, 40, 0.3)])

@@ -110,3 +110,24 @@ def test_packed_equals_padded(case):
     assert abs(float(loss_p) - float(loss)) < 1e-5 * abs(float(loss))
     idx, cu, mx = O.get_unpad_data(pm, seqlens)
     assert cu.tolist() == [0] + torch.cumsum(seqlens, 0).tolist() and mx == int(seqlens.max())
+
+
+def test_sample_distribution_matches_hf_processors_fixture():
+    """oracle.sample_distribution vs distributions produced by transformers' own TemperatureLogitsWarper / TopKLogitsWarper /
+    TopPLogitsWarper (oracle/make_golden_sampling.py, executed in the build container): the sampling leg of the oracle is pinned by
+    reference-executed vectors like the rest."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import vila_oracle as O
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling_hf.npz"))
+    n = 0
+    while f"c{n}_params" in fx:
+        V, temperature, top_k, top_p = fx[f"c{n}_params"]
+        got = O.sample_distribution(torch.from_numpy(fx[f"c{n}_logits"]), float(temperature), int(top_k), float(top_p))
+        ref = torch.from_numpy(fx[f"c{n}_probs"])
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6, (n, float((got - ref).abs().max()))   # HF divides by T in fp32
+        assert int((got > 0).sum()) == int((ref > 0).sum())
+        n += 1
+    assert n >= 6
+
