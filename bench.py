@@ -264,41 +264,59 @@ def sft_measure(model, cfg, a, rank, dev, dist, steps: int, warmup: int):
     from vila_amd.train import SFTTrainer
     tr = SFTTrainer(model, lr=2e-5, weight_decay=0.0)
     b = a.micro_batch
-    pixels = synthetic.make_pixels(cfg, b, rank, device=dev, dtype=torch.bfloat16)
+    s2 = bool(getattr(cfg, "dynamic_s2", False))
+    tiles = 14 if s2 else 1                   # dynamic_s2 (the NVILA-8B recipe): a square image = 1 + 4 + 9 tiles of 448^2, block size (3, 3)
+    pixels = synthetic.make_pixels(cfg, b * tiles, rank, device=dev, dtype=torch.bfloat16)
     ids = torch.stack([synthetic.make_prompt(cfg, a.prompt_tokens, 1, 10 * rank + i) for i in range(b)], 0)
     labels = ids.clone()
     labels[:, : 1 + a.prompt_tokens - 256] = -100
-    S = cfg.tokens_per_tile + 1 + a.prompt_tokens
-    images = [pixels[i] for i in range(b)]
+    S = (cfg.tokens_per_tile * 9 if s2 else cfg.tokens_per_tile) + 1 + a.prompt_tokens
+    images = [pixels[i] for i in range(b * tiles)]
+    blocks = [(3, 3)] * b if s2 else None
     box = {"loss": float("nan")}
 
     def one():
-        box["loss"] = tr.step(ids, images, labels)
+        box["loss"] = tr.step(ids, images, labels, block_sizes=blocks)
     for _ in range(warmup):
         one()
     elapsed = timed_region(dist, dev, steps, one, torch.cuda.synchronize)
     return elapsed, float(box["loss"]), S, tr
 
 
-def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: float):
+def sft_flops_per_sample(cfg, S: int, n_targets: int = 256) -> float:
+    """fwd + bwd (3x the forward GEMM / attention work, no recompute) of one packed sample: tower on its tiles, projector on its blocks,
+    S-token decoder, lm_head on the rows that have a target.  The plain 769-token sample gives SURVEY §8d's 35.8 TFLOP."""
+    s2 = bool(getattr(cfg, "dynamic_s2", False))
+    fwd = vit_flops(cfg, 14 if s2 else 1) + projector_flops(cfg, 9 if s2 else 1)
+    fwd += llm_prefill_flops(cfg, S) - 2 * cfg.llm.hidden_size * cfg.llm.vocab_size + 2 * n_targets * cfg.llm.hidden_size * cfg.llm.vocab_size
+    return 3.0 * fwd
+
+
+def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: float, tflop_per_sample: float = SFT_TFLOP_PER_SAMPLE):
     step_s = elapsed / steps
-    flops = SFT_TFLOP_PER_SAMPLE * 1e12 * b
+    flops = tflop_per_sample * 1e12 * b
     return {"ms_per_step": round(step_s * 1e3, 2), "tokens_per_s": round(world * b * S / step_s, 1), "steps": steps, "micro_batch": b, "loss": round(loss, 4),
             "roofline": {"bound": "mfma", "achieved": round(flops / step_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(flops / step_s / (MFMA_PEAK_TF * 1e12), 4), "traffic": None,
-                         "note": f"whole step incl. optimizer; {SFT_TFLOP_PER_SAMPLE} TFLOP per 769-token sample fwd+bwd (SURVEY §8d), no activation recompute"}}
+                         "note": f"whole step incl. optimizer; {tflop_per_sample:.1f} TFLOP per {S}-token sample fwd+bwd (SURVEY §8d), no activation recompute; "
+                                 "max_grad_norm = None (scripts/NVILA-Lite/sft.sh sets no clipping)"}}
 
 
 def sft_main(a, rank, world, dev, dist):
     from vila_amd import configs
     from vila_amd.vlm import build_model
     cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    if a.dynamic_s2:
+        cfg.dynamic_s2 = True                 # the recipe NVILA-8B is actually trained with (scripts/NVILA/stage1_9tile.sh:19-22)
+        cfg.name += "-dynamic-s2"
     model = build_model(cfg, seed=0, device=dev)
     elapsed, loss, S, tr = sft_measure(model, cfg, a, rank, dev, dist, a.steps, a.warmup)
     if rank == 0:
-        blk = sft_block(elapsed, a.steps, a.micro_batch, S, world, loss)
+        blk = sft_block(elapsed, a.steps, a.micro_batch, S, world, loss,
+                        sft_flops_per_sample(cfg, S) / 1e12 if a.dynamic_s2 else SFT_TFLOP_PER_SAMPLE)
         print(json.dumps({
-            "metric": "SFT step throughput, NVILA-8B, packed 1x448^2 image + 512-token samples", "value": blk["tokens_per_s"],
+            "metric": ("SFT step throughput, NVILA-8B dynamic_s2 recipe, packed (1 + 4 + 9 tiles of 448^2) image + 512-token samples" if a.dynamic_s2
+                       else "SFT step throughput, NVILA-8B, packed 1x448^2 image + 512-token samples"), "value": blk["tokens_per_s"],
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": blk["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 master/AdamW state)",
             "data": "synthetic", "loss": blk["loss"],

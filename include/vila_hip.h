@@ -168,6 +168,8 @@ typedef struct {
     int top_k;           /* 1..64 */
     float top_p;         /* (0, 1] */
     uint64_t seed;
+    const uint64_t* seed_dev;   /* optional device scalar: when non-NULL the kernel reads the seed from it (a captured decode graph then
+                                   serves every sampled request: the host updates 8 bytes instead of re-capturing) and `seed` is ignored */
 } VilaSampling;
 size_t vila_sample_workspace_bytes(void);
 /* logits [n] fp32 -> *out; counter: device scalar mixed into the RNG (nullable); dist_out (nullable): [64] probabilities actually sampled
@@ -306,6 +308,12 @@ typedef struct {
     const int32_t* cu_seqlens; int n_seq; int max_seqlen;            /* flash-attn varlen description (model/utils/packing.py:12-21) */
     const int32_t* target_rows; const int64_t* targets; int n_targets;  /* packed rows that predict a label, and the labels */
     float loss_scale;
+    /* dynamic_s2 recipe (scripts/NVILA/stage1_9tile.sh:19-22; llava_arch.py:298-390): s2_n_blocks > 0 => `pixels` holds the n_images TILES
+     * of every scale of every image, the tower output goes through vila_s2_merge_bf16 (s2_desc, device [s2_n_blocks][6]) into the
+     * projector (in_dim = n_scales * tower hidden, s2_n_blocks inputs), feat_src indexes the projector's [s2_n_blocks * tokens] rows
+     * (the final chessboard merge is folded into it by the host plan), and the backward runs vila_s2_merge_bwd_bf16 (s2_tile_desc,
+     * device [n_images][8]).  s2_n_blocks = 0: the plain single-scale path (the fields are ignored). */
+    const int32_t* s2_desc; const int32_t* s2_tile_desc; int s2_n_blocks; int s2_n_scales; int32_t s2_splits[4];
 } VilaSftBatch;
 size_t vila_sft_workspace_bytes(const VilaVitWeights* vit, const VilaProjWeights* proj, const VilaLlmWeights* llm, const VilaSftBatch* batch);
 int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, const VilaProjWeights* proj, const VilaProjWeights* proj_grad,
@@ -321,6 +329,12 @@ int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, 
  * ------------------------------------------------------------------------------------------------------------ */
 int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,
                        const int32_t* splits, vila_stream_t stream);
+/* Backward of the above for the SFT step of the dynamic_s2 recipe (autograd through llava_arch.py:298-379: F.interpolate(mode="area")
+ * backward = dy / |window| broadcast into each scale's chessboard, merge / split_chessboard adjoints), as one gather:
+ *   dy [n_blocks, g*g, n_scales*C] -> dx [n_tiles, g*g, C] (every element written, no accumulation)
+ *   tile_desc device [n_tiles][8] = {first output block of the tile's image, bh, bw, scale index, tile row, tile col, single, 0} */
+int vila_s2_merge_bwd_bf16(const void* dy, void* dx, const int32_t* tile_desc, int n_tiles, int grid, int channels, int n_scales,
+                           const int32_t* splits, vila_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------

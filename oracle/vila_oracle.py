@@ -482,9 +482,16 @@ def vlm_generate(pixels_list, input_ids, w, cfg, max_new_tokens: int, **kw):
     return greedy_generate(e, w, cfg, max_new_tokens, **kw)
 
 
-def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True):
-    """Training forward of llava_llama.py:94-159 (packing branch): _embed -> repack -> llm(..., labels)."""
-    media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
+def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True, block_sizes=None):
+    """Training forward of llava_llama.py:94-159 (packing branch): _embed -> repack -> llm(..., labels).
+    dynamic_s2 (cfg.dynamic_s2, llava_arch.py:369-390): pixels_list = the tiles of every scale of every image, block_sizes = one entry per
+    image (media_config["image"]["block_sizes"]); BasicImageEncoder appends the "\n" embedding to each IMAGE's merged tokens."""
+    if len(pixels_list) and getattr(cfg, "dynamic_s2", False):
+        feats = encode_images_dynamic_s2(torch.stack(list(pixels_list), 0), block_sizes, w, cfg)
+        end = embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+        media = [torch.cat([f, end], 0) for f in feats]
+    else:
+        media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
     e, l, m = embed_splice(input_ids, media, w, cfg, labels=labels, attention_mask=attention_mask)
     if packed:
         pe, pm, pp, pl, seqlens = repack(e, m, l)

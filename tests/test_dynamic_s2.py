@@ -89,3 +89,61 @@ def test_s2_generate_end_to_end():
     feats = model.encode_images(px.cuda(), block_sizes=[(3, 3)])
     ref = O.encode_images_dynamic_s2(px.float(), [(3, 3)], w, cfg)[0]
     assert feats.shape == (1, 36, cfg.llm.hidden_size) and rel_l2(feats[0], ref) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward of the merge (SFT step of the dynamic_s2 recipe)
+# ---------------------------------------------------------------------------------------------------------------------
+def _merge_bwd_formula(dy, tile_desc, g, C, n_scales, splits):
+    """Python restatement of s2_merge_bwd_kernel's index arithmetic (TEST CODE: checks the gather formula against autograd on the CPU,
+    the kernel itself is checked against autograd on the GPU below)."""
+    n_tiles = tile_desc.shape[0]
+    dx = torch.zeros((n_tiles, g * g, C), dtype=torch.float64)
+    for t in range(n_tiles):
+        blk0, bh, bw, k, ti, tj, single, _ = tile_desc[t].tolist()
+        for tok in range(g * g):
+            if single:
+                dx[t, tok] = dy[blk0, tok].view(n_scales, C).sum(0)
+                continue
+            sh, sw = (splits[k], splits[k]) if k < n_scales - 1 else (bh, bw)
+            Hout, Wout, Hk, Wk = g * bh, g * bw, g * sh, g * sw
+            yy, xx = ti * g + tok // g, tj * g + tok % g
+            for Y in range((yy * Hout) // Hk, ((yy + 1) * Hout + Hk - 1) // Hk):
+                ys, ye = (Y * Hk) // Hout, ((Y + 1) * Hk + Hout - 1) // Hout
+                for X in range((xx * Wout) // Wk, ((xx + 1) * Wout + Wk - 1) // Wk):
+                    xs, xe = (X * Wk) // Wout, ((X + 1) * Wk + Wout - 1) // Wout
+                    b, pos = blk0 + (Y // g) * bw + (X // g), (Y % g) * g + (X % g)
+                    dx[t, tok] += dy[b, pos, k * C:(k + 1) * C] / ((ye - ys) * (xe - xs))
+    return dx
+
+
+@pytest.mark.parametrize("blocks,scales,g", [([(2, 3), None], [56, 112, 168], 4), ([(3, 3)], [8, 16, 24], 4), ([(1, 2), (1, 1), None, (3, 2)], [8, 16, 24], 2),
+                                             ([(1, 1)], [8, 16], 3)])
+def test_s2_merge_backward_formula_is_the_autograd_adjoint(blocks, scales, g):
+    """Up- and down-sampling scales (a 1x2 image's 2x2 middle scale is LARGER than its output grid), `None` blocks, several images."""
+    plan = host.s2_plan(blocks, scales, g, 2)
+    C = 3
+    gen = torch.Generator().manual_seed(1)
+    feats = torch.randn(plan.n_tiles, g * g, C, generator=gen, dtype=torch.float64, requires_grad=True)
+    x, _ = O.s2_merge_to_projector_input(feats, blocks, scales, -1)
+    dy = torch.randn(x.shape, generator=gen, dtype=torch.float64)
+    (x * dy).sum().backward()
+    got = _merge_bwd_formula(dy, plan.tile_desc, g, C, len(scales), plan.splits)
+    assert plan.tile_desc.shape == (plan.n_tiles, 8)
+    assert float((got - feats.grad).abs().max()) < 5e-6            # the reference interpolates in fp32 (llava_arch.py:341)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,scales,g", [([(2, 3), None], [56, 112, 168], 4), ([(1, 2), (1, 1), None, (3, 2)], [8, 16, 24], 2), ([(3, 3)], [448, 896, 1344], 32)])
+def test_s2_merge_backward_kernel_vs_autograd(blocks, scales, g):
+    from vila_amd import ops
+    plan = host.s2_plan(blocks, scales, g, 2)
+    C = 16 if g < 32 else 1152
+    gen = torch.Generator().manual_seed(2)
+    feats = torch.randn(plan.n_tiles, g * g, C, generator=gen).to(torch.bfloat16).float().requires_grad_(True)
+    x, _ = O.s2_merge_to_projector_input(feats, blocks, scales, -1)
+    dy = torch.randn(x.shape, generator=gen).to(torch.bfloat16)
+    (x * dy.float()).sum().backward()
+    got = ops.s2_merge_bwd(dy.cuda(), plan.tile_desc.cuda(), len(scales), plan.splits)
+    assert got.shape == feats.shape
+    assert rel_l2(got, feats.grad) < 3e-3, f"rel={rel_l2(got, feats.grad):.3e}"        # fp32 sums, one bf16 rounding

@@ -2,7 +2,8 @@
 fp32 CPU oracle.
 
 The oracle needs minutes and ~20 GB at this size, so it ran once (oracle/make_golden_full.py) and its KB-sized fingerprints are
-committed as tests/golden/nvila8b_full_depth.npz: top-32 logits of the prefill's last row and of 8 teacher-forced decode steps, the
+committed as tests/golden/nvila8b_full_depth.npz (an ORACLE-executed fixture: the chain to the reference is oracle <- reference-executed
+tiny-depth fixtures, tests/test_oracle_golden.py): top-32 logits of the prefill's last row and of 8 teacher-forced decode steps, the
 greedy ids, a few tower / projector / embedding rows.  Here the SAME weights are drawn with the CPU generator (tensor by tensor,
 ~1 min), the HIP path runs, and the stated rules apply: hidden rows rel-L2 <= 2e-2 (tower, projector), logits <= 3e-2 on the stored
 entries, token ids bit-exact at every step whose oracle top-1/top-2 margin exceeds 4x the observed max-abs logit error
@@ -28,6 +29,8 @@ def test_full_depth_logits_and_ids_vs_oracle_golden():
     fx = np.load(GOLDEN)
     cfg = configs.nvila_8b()
     seed = int(fx["seed"])
+    # the fixture's synthetic lm_head has heavy-tailed row norms (a peaked next-token distribution, oracle/make_golden_full.py)
+    cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = float(fx["lm_head_tail"]), int(fx["lm_head_tail_seed"]), float(fx["lm_head_tail_max"])
     specs = {n: (shape, kind) for n, shape, kind in synthetic.all_specs(cfg)}
     for i, k in enumerate(FINGERPRINT_KEYS):       # same CPU RNG stream as the host the golden was made on?
         shape, kind = specs[k]
@@ -66,7 +69,9 @@ def test_full_depth_logits_and_ids_vs_oracle_golden():
     err = float(err_t.max())
     decisive = (top_vals[:, 0] - top_vals[:, 1]) > 4 * err_t
     print(f"full depth: per-step max-abs err {[round(float(x), 3) for x in err_t]}, margins {[round(float(x), 3) for x in (top_vals[:, 0] - top_vals[:, 1])]}")
-    assert bool(decisive.any()), f"no decisive step: per-step err {err_t.tolist()}, margins {(top_vals[:, 0] - top_vals[:, 1]).tolist()}"
+    # the fixture was built so that most steps ARE decisive: a pass on one lucky step (round 2) is not accepted
+    assert int(decisive.sum()) >= 6, (f"only {int(decisive.sum())} of {n} steps decisive: per-step err {err_t.tolist()}, "
+                                      f"margins {(top_vals[:, 0] - top_vals[:, 1]).tolist()}")
     am = lg.float().cpu().argmax(-1)
     assert torch.equal(am[decisive], gold[decisive]), f"ids {am.tolist()} vs oracle {gold.tolist()} (err {err:.3e}, decisive {decisive.tolist()})"
     # free-running greedy through the captured hipGraph: identical to the oracle until the first non-decisive step

@@ -106,7 +106,14 @@ def test_generate_do_sample_graph_equals_eager_and_batch_equals_rows():
     eg = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], use_graph=False, **kw)
     assert g.shape == (1, 10) and torch.equal(g, eg)
     greedy = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], max_new_tokens=10, eos_token_id=-1)
+    # a new seed must NOT drop the captured graph (the seed is a device scalar the sampler reads): same session, same graph object
+    g = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], use_graph=True, **kw)
+    sess, graph = model.llm._decode, model.llm._decode.graph
+    assert graph is not None
     other = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], use_graph=True, **dict(kw, seed=78))
+    assert model.llm._decode is sess and model.llm._decode.graph is graph, "a different seed re-captured the decode graph"
+    again = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], use_graph=True, **kw)
+    assert torch.equal(again, g) and not torch.equal(other, g)                    # the replayed graph follows the seed scalar
     assert not (torch.equal(g, greedy) and torch.equal(other, greedy))            # it really samples
     both = model.llm.generate(inputs_embeds=e, attention_mask=m, **kw)
     r0 = model.llm.generate(inputs_embeds=e[:1], attention_mask=m[:1], **kw)

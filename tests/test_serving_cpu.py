@@ -103,8 +103,12 @@ def test_chat_completions_endpoint_schema_and_errors():
     r = client.post("/chat/completions", json=dict(body, temperature=0.7, top_p=0.8))
     assert r.status_code == 200 and m.sampling["do_sample"] is True
     assert abs(m.sampling["temperature"] - 0.7) < 1e-6 and abs(m.sampling["top_p"] - 0.8) < 1e-6 and m.sampling["top_k"] == 50
+    # a request without the fields gets the REFERENCE's defaults (server.py:101-102: temperature 0.2, top_p 0.9 -> sampled)
     r = client.post("/chat/completions", json=body)
-    assert r.status_code == 200 and m.sampling == {}                  # temperature 0 (the shim's default) stays greedy
+    assert r.status_code == 200 and m.sampling["do_sample"] is True
+    assert abs(m.sampling["temperature"] - 0.2) < 1e-6 and abs(m.sampling["top_p"] - 0.9) < 1e-6
+    r = client.post("/chat/completions", json=dict(body, temperature=0.0))
+    assert r.status_code == 200 and m.sampling == {}                  # an explicit temperature 0 stays greedy (do_sample = temperature > 0)
 
 
 def test_prompt_split_matches_extract_media():
@@ -116,3 +120,4 @@ def test_prompt_split_matches_extract_media():
     assert _split_prompt("a literal <image> token") == ("a literal  token", [])
     text, images = _split_prompt(["<image> describe", img])
     assert text == "describe<image>" and images == [img]
+    assert _split_prompt("a typed <vila/video> token") == ("a typed  token", [])     # every MEDIA_TOKENS value, not only <image>

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU session of round 3: parity first, then the A/B measurements of this round's kernels.  Run from the repo root on the GPU box:
+#   gpurun -- bash tools/gpu_session.sh <tag> [steps...]       results under gpurun_out/<tag>/
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${1:-s}; shift
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
+for step in "$@"; do
+case $step in
+  gemm_bwd)  timeout 300 tools/gemm_bench bwd > "$O/gemm_bench_bwd.log" 2>&1; tail -40 "$O/gemm_bench_bwd.log" ;;
+  gemm_fwd)  timeout 300 tools/gemm_bench fwd > "$O/gemm_bench_fwd.log" 2>&1; tail -30 "$O/gemm_bench_fwd.log" ;;
+  tests)     timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > "$O/pytest.log"; tail -30 "$O/pytest.log" ;;
+  tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
+  tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;
+  attn)      VILA_ATTN_FWD=v1 timeout 300 python tools/microbench.py attn > "$O/attn_v1.log" 2>&1; timeout 300 python tools/microbench.py attn > "$O/attn_new.log" 2>&1
+             paste -d'\n' "$O/attn_v1.log" "$O/attn_new.log" ;;
+  sft)       for i in 1 2; do timeout 400 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/sft_$i.err" | tee "$O/sft_$i.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"; done ;;
+  sft_s2)    timeout 600 python bench.py --mode sft --dynamic-s2 --micro-batch 1 --steps 3 --warmup 1 2>"$O/sft_s2.err" | tee "$O/sft_s2.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft dynamic_s2 ->', d['ms_per_step'], 'ms  frac', d['roofline']['frac'])" ;;
+  bench)     timeout 600 python bench.py > "$O/bench.json" 2> "$O/bench.err"; python - "$O/bench.json" <<'P'
+import json,sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("value", d["value"], "ttft", d["ttft_ms"], "prefill frac", d["prefill"]["roofline"]["frac"], "sft", d.get("sft", {}).get("ms_per_step"), "roofline", d["roofline"]["frac"])
+except Exception as e:
+    print("bench parse failed", e)
+P
+             ;;
+  bench_fast) timeout 400 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/bench_fast.json" 2> "$O/bench_fast.err"; python -c "
+import json; d=json.loads(open('$O/bench_fast.json').read().strip().splitlines()[-1]); print('value', d['value'], 'ttft', d['ttft_ms'], 'prefill frac', d['prefill']['roofline']['frac'])" ;;
+  video)     for args in "--mode video" "--mode video --tsp"; do timeout 400 python bench.py $args 2>>"$O/video.err" | tail -1 | tee -a "$O/video.jsonl" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:60], d['value'], 'ms encode', d['encode_ms'], 'prefill', d['llm_prefill_ms'])"; done ;;
+  smoke)     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+  *) echo "unknown step $step" ;;
+esac
+done

@@ -59,7 +59,7 @@ class VilaKvCache(C.Structure):
 
 
 class VilaSampling(C.Structure):
-    _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", C.c_uint64)]
+    _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", C.c_uint64), ("seed_dev", c_void_p)]
 
 
 class VilaDecodeState(C.Structure):
@@ -73,7 +73,8 @@ class VilaSftBatch(C.Structure):
                 ("feat_src", c_void_p), ("feat_dst", c_void_p), ("n_feat", c_int),
                 ("nl_src", c_void_p), ("nl_dst", c_void_p), ("n_nl", c_int),
                 ("positions", c_void_p), ("cu_seqlens", c_void_p), ("n_seq", c_int), ("max_seqlen", c_int),
-                ("target_rows", c_void_p), ("targets", c_void_p), ("n_targets", c_int), ("loss_scale", c_float)]
+                ("target_rows", c_void_p), ("targets", c_void_p), ("n_targets", c_int), ("loss_scale", c_float),
+                ("s2_desc", c_void_p), ("s2_tile_desc", c_void_p), ("s2_n_blocks", c_int), ("s2_n_scales", c_int), ("s2_splits", C.c_int32 * 4)]
 
 
 GRAD_READY_CB = C.CFUNCTYPE(None, c_void_p, c_int, c_int)
@@ -166,6 +167,7 @@ PROTOTYPES = {
                                  C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmWeights), C.POINTER(VilaSftBatch), c_void_p, c_void_p, c_size_t,
                                  GRAD_READY_CB, c_void_p, c_void_p]),
     "vila_s2_merge_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
+    "vila_s2_merge_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -187,7 +187,7 @@ def save_optimizer(trainer, output_dir: str, max_shard_bytes: int = 4 << 30) -> 
             name = f"{key}-{i:05d}.safetensors"
             save_file({key: t[o:o + per].detach().to("cpu").contiguous()}, os.path.join(folder, name), metadata={"format": "pt"})
             files.append({"file": name, "key": key, "offset": o, "numel": int(min(per, f.numel - o))})
-    meta = {"step": int(f.step_count), "numel": int(f.numel), "files": files,
+    meta = {"step": int(f.step_count), "numel": int(f.numel), "files": files, "bucket_steps": dict(getattr(f, "bucket_steps", {})),
             "index": {n: [int(o), int(k), list(shape)] for n, (o, k, shape) in f.index.items()},
             "hyper": {"lr": trainer.lr, "betas": list(trainer.betas), "eps": trainer.eps, "weight_decay": trainer.wd}}
     with open(os.path.join(folder, "optimizer.json"), "w") as fh:
@@ -201,6 +201,19 @@ def load_optimizer(trainer, model_dir: str) -> None:
     folder = os.path.join(model_dir, "optimizer")
     meta = json.load(open(os.path.join(folder, "optimizer.json")))
     bufs = {"master": f.master, "exp_avg": f.m, "exp_avg_sq": f.v}
+    # validate the whole state BEFORE the first byte is copied into the live buffers: every tensor of this model present with the shape
+    # it has here, every file entry inside the saved extent (a failed load used to leave half-overwritten state behind)
+    missing = [n for n in f.index if n not in meta["index"]]
+    if missing:
+        raise KeyError(f"optimizer state lacks tensors: {missing[:8]}")
+    bad = [n for n, (o, k, shape) in f.index.items() if int(meta["index"][n][1]) != int(k) or list(meta["index"][n][2]) != list(shape)]
+    if bad:
+        n = bad[0]
+        raise ValueError(f"optimizer state tensor '{n}' has shape {meta['index'][n][2]}, the model has {list(f.index[n][2])} "
+                         f"({len(bad)} mismatching tensors)")
+    for ent in meta["files"]:
+        if ent["key"] not in bufs or ent["offset"] < 0 or ent["offset"] + ent["numel"] > meta["numel"]:
+            raise ValueError(f"optimizer state file entry out of range: {ent}")
     same_layout = meta["numel"] == f.numel and all(n in f.index and list(f.index[n][:2]) == v[:2] for n, v in meta["index"].items())
     with torch.no_grad():
         for ent in meta["files"]:
@@ -215,8 +228,6 @@ def load_optimizer(trainer, model_dir: str) -> None:
                 if lo < hi and n in f.index:
                     do = f.index[n][0]
                     bufs[ent["key"]][do + (lo - so): do + (hi - so)].copy_(chunk[lo - o: hi - o])
-        missing = [n for n in f.index if n not in meta["index"]]
-        if missing:
-            raise KeyError(f"optimizer state lacks tensors: {missing[:8]}")
         f.params.copy_(f.master)
+    f.bucket_steps = {str(k): int(v) for k, v in meta.get("bucket_steps", {}).items()}
     f.step_count = int(meta["step"])

@@ -82,6 +82,12 @@ class VilaConfig:
     newline_token_id: int = 198      # tokenizer("\n").input_ids for Qwen2 (encoders/image/basic.py:22-27)
     init_std: float = 0.02
     lm_head_std: float = 0.05
+    # > 0: the rows of the synthetic lm_head get Pareto(a = lm_head_tail) norms, the largest scaled to lm_head_tail_max x lm_head_std
+    # (a peaked next-token distribution like a trained model's: i.i.d. Gaussian rows give top-1 / top-2 margins of ~0.2 sigma over 152 k
+    # candidates, below 4x the bf16 logit error, so hardly any greedy step of a parity test would be decisive)
+    lm_head_tail: float = 0.0
+    lm_head_tail_seed: int = 0
+    lm_head_tail_max: float = 10.0
     name: str = "nvila-8b"
     # dynamic_s2 multi-scale recipe (scripts/NVILA/stage1_9tile.sh:19-22); off = the README benchmark setting (README.md:87)
     dynamic_s2: bool = False

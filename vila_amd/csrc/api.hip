@@ -241,7 +241,7 @@ extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T)
     b += align_up((size_t)T * QKV * 2, 256);                   // qkv
     b += align_up((size_t)T * F * 2, 256);                     // act
     b += 2 * align_up((size_t)T * (s->head_dim / 2) * 4, 256); // rope cos/sin
-    b += align_up((size_t)T * H * 2, 256);                     // gathered last rows / final norm
+    b += align_up((size_t)(T > 8 ? T : 8) * H * 2, 256);       // gathered last rows / final norm (the pruned last layer keeps 2 x n_last <= 8 rows there)
     b += align_up((size_t)6 * T * H * 4, 256);                 // split-K fp32 slabs (down_proj; tail round of gate/up) at small T
     return b + 8192;
 }
@@ -264,7 +264,7 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     bf16_t* act = a.take<bf16_t>((size_t)T * F);
     float* cs = a.take<float>((size_t)T * hd / 2);
     float* sn = a.take<float>((size_t)T * hd / 2);
-    bf16_t* lastbuf = a.take<bf16_t>((size_t)T * H);
+    bf16_t* lastbuf = a.take<bf16_t>((size_t)(T > 8 ? T : 8) * H);
     float* skws = a.take<float>((size_t)6 * T * H);
     const size_t skws_bytes = (size_t)6 * T * H * 4;
     VILA_REQUIRE(a.ok(), "llm_prefill: workspace arena overflow");
@@ -416,7 +416,7 @@ extern "C" size_t vila_sample_workspace_bytes(void) { return sample_workspace_by
 extern "C" int vila_sample_f32(const float* logits, int n, const VilaSampling* sp, const int32_t* counter, int64_t* out, void* workspace,
                                float* dist_out, vila_stream_t stream) {
     VILA_REQUIRE(sp != nullptr && logits != nullptr && out != nullptr && workspace != nullptr, "sample: NULL argument");
-    return launch_sample(logits, n, sp->temperature, sp->top_k, sp->top_p, sp->seed, counter, out, workspace, dist_out, S(stream));
+    return launch_sample(logits, n, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, counter, out, workspace, dist_out, S(stream));
 }
 static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
                             const VilaSampling* sp, vila_stream_t stream) {
@@ -474,7 +474,7 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     GemvArgs lm{};
     lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
     VILA_TRY(launch_gemv(lm, s));
-    if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, st->pos, st->token, smp_ws, nullptr, s));
+    if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
     else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
     VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
     return 0;
@@ -650,6 +650,13 @@ extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* d
     int sp[4] = {1, 1, 1, 1};
     for (int k = 0; k < n_scales - 1 && k < 4; ++k) sp[k] = splits[k];
     return launch_s2_merge(B(feats), B(out), desc, n_blocks, grid, channels, n_scales, sp, S(stream));
+}
+
+extern "C" int vila_s2_merge_bwd_bf16(const void* dy, void* dx, const int32_t* tile_desc, int n_tiles, int grid, int channels, int n_scales,
+                                      const int32_t* splits /*[host] n_scales-1*/, vila_stream_t stream) {
+    int sp[4] = {1, 1, 1, 1};
+    for (int k = 0; k < n_scales - 1 && k < 4; ++k) sp[k] = splits[k];
+    return launch_s2_merge_bwd(B(dy), B(dx), tile_desc, n_tiles, grid, channels, n_scales, sp, S(stream));
 }
 
 // video encoders: BasicVideoEncoder (pool 1,1,1) / TSPVideoEncoder token assembly in one launch

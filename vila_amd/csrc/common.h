@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <type_traits>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits; all activations / weights are bf16 in HBM
 
@@ -51,6 +52,47 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- LDS transpose read as inline asm ---------------------------------------------------------------------------------------------
+// `__builtin_amdgcn_ds_read_tr16_b64_*` is modelled by the compiler as an LDS access that may also WRITE, so behind any LDS-DMA
+// (`global_load_lds`) still in flight it gets a conservative `s_waitcnt vmcnt(0)` in front of it — which drains the whole DMA ring
+// once per phase (found in round 3 in the contraction-major GEMMs and in the attention kernels).  The asm form is invisible to that
+// pass; the price is that its result is unprotected until OUR wait: retire it with `lds_wait<N>(regs...)`, which ties the destination
+// registers to the `s_waitcnt lgkmcnt(N)` so that no consumer can be scheduled in front of it.  LDS operations return in order, so
+// compiler-tracked reads in between only make either side's counted waits more conservative, never wrong.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF> __device__ __forceinline__ u32x2 ds_read_tr16_b64(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N> __device__ __forceinline__ void lds_wait_imm() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N));
+}
+template <int N, typename... R> __device__ __forceinline__ void lds_wait(R&... regs) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+    if constexpr (sizeof...(R) == 2) {
+        auto tie = [](auto& a, auto& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); };
+        tie(regs...);
+    } else if constexpr (sizeof...(R) == 4) {
+        auto tie = [](auto& a, auto& b, auto& c, auto& d) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N)); };
+        tie(regs...);
+    } else if constexpr (sizeof...(R) == 8) {
+        auto tie = [](auto& a, auto& b, auto& c, auto& d, auto& e, auto& f, auto& g, auto& h) {
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N)); };
+        tie(regs...);
+    } else {
+        static_assert(sizeof...(R) == 2, "lds_wait: 2, 4 or 8 registers");
+    }
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
 // ---- host side ----

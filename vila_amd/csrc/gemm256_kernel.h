@@ -151,14 +151,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 
     // fragment f (16 rows at row16 = f) of a half-tile at `base`, k-step ks
     auto frag_cc = [&](const char* base, int row0, int ks) -> bf16x8 { return *(const bf16x8*)(base + row0 * 128 + foff[ks]); };
+    // SCHED 7 reads its contraction-major fragments with the ASM form of the transpose read (common.h): the builtin is treated as a
+    // possible LDS write and gets an `s_waitcnt vmcnt(0)` in front of it whenever LDS-DMA pieces are in flight — i.e. the queue this
+    // schedule keeps 4-8 pieces deep was drained in every phase of the dgrad / wgrad kernels (round 2: MfmaUtil 0.39-0.40 against
+    // 0.54 for the forward layout, whose ds_read_b128 are not affected).  The asm results are retired by `retire()` below.
+    constexpr bool ASM_TR = (SCHED == 7) && (ACM || BCM);
     auto frag_cm = [&](const char* base, int row0, int ks) -> bf16x8 {
         const char* q = base + cm_base + ks * 32 * 256 + ((((row0 >> 4) ^ cm_rg) & 7) << 5);
-        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
-        const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 256));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (ASM_TR) {
+            const uint32_t a = lds_addr(q);
+            const u32x2 lo = ds_read_tr16_b64<0>(a), hi = ds_read_tr16_b64<4 * 256>(a);
+            u32x4 w; w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+            return __builtin_bit_cast(bf16x8, w);
+        } else {
+            const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+            const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 256));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
     };
     auto fragA = [&](const char* base, int row0, int ks) -> bf16x8 { if constexpr (ACM) return frag_cm(base, row0, ks); else return frag_cc(base, row0, ks); };
     auto fragB = [&](const char* base, int row0, int ks) -> bf16x8 { if constexpr (BCM) return frag_cm(base, row0, ks); else return frag_cc(base, row0, ks); };
+    // SCHED 7: the k-step's 8 KB stride travels in the instruction's offset field (an asm read cannot have it folded by the compiler)
+    auto frag_cm7 = [&](const char* base, int row0, auto ksc) -> bf16x8 {
+        constexpr int KS = decltype(ksc)::value;
+        const uint32_t a = lds_addr(base + cm_base + ((((row0 >> 4) ^ cm_rg) & 7) << 5));
+        const u32x2 lo = ds_read_tr16_b64<KS * 32 * 256>(a), hi = ds_read_tr16_b64<KS * 32 * 256 + 4 * 256>(a);
+        u32x4 w; w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    auto fragA7 = [&](const char* base, int row0, auto ksc) -> bf16x8 {
+        if constexpr (ACM) return frag_cm7(base, row0, ksc); else return frag_cc(base, row0, decltype(ksc)::value);
+    };
+    auto fragB7 = [&](const char* base, int row0, auto ksc) -> bf16x8 {
+        if constexpr (BCM) return frag_cm7(base, row0, ksc); else return frag_cc(base, row0, decltype(ksc)::value);
+    };
 
     const int kt_all = (p.K + T256_BK - 1) / T256_BK;
     const int nt = SPLIT ? ((kt_all - kt0) < k_tiles_per_split ? (kt_all - kt0) : k_tiles_per_split) : kt_all;   // last slice may be shorter
@@ -258,9 +284,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
         asm volatile("" ::: "memory");
         if (wr == 1) __builtin_amdgcn_s_barrier();
         bf16x8 af[4][2], bf0[2][2], bf1[2][2];
-        auto enter_mfma = [&]() {
+        // lgkmcnt(0) with the fragment registers tied to it: results of the asm transpose reads must not be consumed (nor the MFMAs
+        // that consume them be scheduled) in front of this wait; for compiler-tracked reads the tie is a no-op
+        auto retire_a = [&]() {
+            if constexpr (ASM_TR) {
+                if constexpr (NA == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]),
+                                 "+v"(af[3][0]), "+v"(af[3][1]) :: "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1])
+                                 :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        auto retire_b = [&]() {
+            if constexpr (ASM_TR)
+                asm volatile("" : "+v"(bf0[0][0]), "+v"(bf0[0][1]), "+v"(bf0[1][0]), "+v"(bf0[1][1]), "+v"(bf1[0][0]), "+v"(bf1[0][1]),
+                             "+v"(bf1[1][0]), "+v"(bf1[1][1]));
+        };
+        auto enter_mfma = [&](bool with_b) {
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            retire_a();                                      // s_waitcnt lgkmcnt(0): every outstanding LDS read of this wave
+            if (with_b) retire_b();                          // (same wait: only ties the B fragments behind it)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -287,26 +333,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             const char* cA = smem + buf * BUF_BYTES + a_half * HALF_BYTES;
             const char* cB = smem + buf * BUF_BYTES + (2 + b_half) * HALF_BYTES;
             // phase 0: all B fragments, A rows 0..63; the A halves of tile t+1 go into the other buffer (tile 1's came with the prologue)
+            static_for<0, 2>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) { bf0[j][ks] = fragB7(cB, b_row0 + j * 16, ksc); bf1[j][ks] = fragB7(cB, b_row0 + 32 + j * 16, ksc); }
+            });
+            static_for<0, 2>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) { bf0[j][ks] = fragB(cB, b_row0 + j * 16, ks); bf1[j][ks] = fragB(cB, b_row0 + 32 + j * 16, ks); }
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, i * 16, ks);
+                for (int i = 0; i < NA; ++i) af[i][ks] = fragA7(cA, i * 16, ksc);
+            });
             if (t >= 1 && t + 1 < nt) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) issue_piece(t + 1, buf ^ 1, false, h, i);
             }
-            enter_mfma(); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2); leave_mfma();
+            enter_mfma(true); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2); leave_mfma();
             // phase 1: A rows 64..127; the B halves of tile t+2 into THIS buffer, then the counted wait for tile t+1
+            static_for<0, 2>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[i][ks] = fragA(cA, NA * 16 + i * 16, ks);
+                for (int i = 0; i < NA; ++i) af[i][ks] = fragA7(cA, NA * 16 + i * 16, ksc);
+            });
             if (t + 2 < nt) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -316,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             } else if (t + 1 < nt) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            enter_mfma(); mfma16(af, bf1, NA, 2); mfma16(af, bf0, NA, 0); leave_mfma();
+            enter_mfma(false); mfma16(af, bf1, NA, 2); mfma16(af, bf0, NA, 0); leave_mfma();
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

@@ -41,11 +41,15 @@ int launch_copy_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_row, con
 int launch_argmax(const float* logits, int V, int64_t* out, float* tmpv, int* tmpi, hipStream_t s);
 // stochastic token choice (sample.hip): temperature -> top-k (1..64) -> top-p -> draw; counter = device scalar mixed into the RNG
 size_t sample_workspace_bytes();
-int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const int32_t* counter, int64_t* out,
+int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev, const int32_t* counter, int64_t* out,
                   void* workspace, float* prob_out, hipStream_t s);
 // dynamic_s2 merge (s2.hip): tower output -> projector input, desc = device [n_blocks][6] {tile_base, bh, bw, i, j, single}
 int launch_s2_merge(const bf16_t* feats, bf16_t* out, const int32_t* desc, int n_blocks, int g, int C, int n_scales, const int* splits,
                     hipStream_t s);
+// adjoint of the merge: dy [n_blocks][g*g][n_scales*C] -> dx [n_tiles][g*g][C]; tdesc = device [n_tiles][8] {first block of the image,
+// bh, bw, scale, tile row, tile col, single, 0}
+int launch_s2_merge_bwd(const bf16_t* dy, bf16_t* dx, const int32_t* tdesc, int n_tiles, int g, int C, int n_scales, const int* splits,
+                        hipStream_t s);
 
 // video token assembly (video.hip): temporal / spatial mean pooling + start / end token rows per pooled frame
 int launch_video_pool(const bf16_t* feats, bf16_t* out, int nt, int nl, int C, int pt, int ph, int pw, const bf16_t* start_rows, int n_start,

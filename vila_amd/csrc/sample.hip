@@ -69,7 +69,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 
 // stage 3: global top-64, then temperature / top-k / top-p / draw by wave 0
 __global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restrict__ in_keys, int n_in, float inv_temperature, int top_k, float top_p,
-                                                        uint64_t seed, const int32_t* __restrict__ counter, int64_t* __restrict__ out, float* __restrict__ prob_out) {
+                                                        uint64_t seed_imm, const uint64_t* __restrict__ seed_dev, const int32_t* __restrict__ counter, int64_t* __restrict__ out, float* __restrict__ prob_out) {
     __shared__ uint64_t keys[1024];
     for (int i = threadIdx.x; i < 1024; i += 256) keys[i] = i < n_in ? in_keys[i] : 0;
     smp_sort1024(keys);
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restri
         const float t = __shfl_up(cum, o, 64);
         if (lane >= o) cum += t;
     }
+    const uint64_t seed = seed_dev != nullptr ? *seed_dev : seed_imm;
     const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)(uint32_t)(counter != nullptr ? *counter : 0)));
     const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * kept_total;      // uniform in [0, kept_total)
     const unsigned long long hit = __ballot(keep && cum > u);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restri
 
 size_t sample_workspace_bytes() { return (size_t)(SMP_S1_BLOCKS + SMP_S2_BLOCKS) * SMP_CAND * sizeof(uint64_t) + 256; }
 
-int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const int32_t* counter, int64_t* out,
+int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev, const int32_t* counter, int64_t* out,
                   void* workspace, float* prob_out, hipStream_t s) {
     VILA_REQUIRE(n > 0 && temperature > 0.f, "sample: temperature must be positive (got %g); use greedy search for temperature 0", (double)temperature);
     VILA_REQUIRE(top_k >= 1 && top_k <= SMP_CAND, "sample: top_k must be in 1..%d (got %d): the on-device selection keeps %d candidates", SMP_CAND, top_k, SMP_CAND);
@@ -122,7 +123,7 @@ int launch_sample(const float* logits, int n, float temperature, int top_k, floa
     VILA_LAUNCH_CHECK();
     hipLaunchKernelGGL(smp_select_kernel, dim3(SMP_S2_BLOCKS), dim3(256), 0, s, (const float*)nullptr, (const uint64_t*)c1, SMP_S1_BLOCKS * SMP_CAND, 1024, c2);
     VILA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smp_final_kernel, dim3(1), dim3(256), 0, s, (const uint64_t*)c2, SMP_S2_BLOCKS * SMP_CAND, 1.0f / temperature, top_k, top_p, seed, counter, out, prob_out);
+    hipLaunchKernelGGL(smp_final_kernel, dim3(1), dim3(256), 0, s, (const uint64_t*)c2, SMP_S2_BLOCKS * SMP_CAND, 1.0f / temperature, top_k, top_p, seed, seed_dev, counter, out, prob_out);
     VILA_LAUNCH_CHECK();
     return 0;
 }

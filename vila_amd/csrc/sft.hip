@@ -111,12 +111,20 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     const int g_ = vs.image / vs.patch, Nv = g_ * g_, Mv = n_img * Nv, D = vs.hidden, Fv = vs.inter, hdv = D / (vs.heads > 0 ? vs.heads : 1);
     const int Kc = vs.channels * vs.patch * vs.patch, Kp = (Kc + 7) / 8 * 8;
     const int kdown = (pj->kind == VILA_PROJ_MLP_DOWNSAMPLE_3X3_FIX) ? 3 : 2;
-    const int gd = (g_ + kdown - 1) / kdown, Tm = gd * gd, C1 = kdown * kdown * D, Mp_ = n_img * Tm;
+    // dynamic_s2: the projector sees s2_n_blocks inputs of n_scales * D channels (the merge sits between tower and projector)
+    const bool s2 = b->s2_n_blocks > 0;
+    const int n_pin = s2 ? b->s2_n_blocks : n_img;              // projector inputs ("images" of the projector)
+    const int Dp = s2 ? b->s2_n_scales * D : D;                 // projector input channels
+    const int gd = (g_ + kdown - 1) / kdown, Tm = gd * gd, C1 = kdown * kdown * Dp, Mp_ = n_pin * Tm;
+    int s2_splits[4] = {1, 1, 1, 1};
+    for (int k = 0; s2 && k < b->s2_n_scales - 1 && k < 4; ++k) s2_splits[k] = b->s2_splits[k];
     std::vector<VitSaved> vsv(vs.n_layers_run);
     bf16_t *patches = nullptr, *vx = nullptr, *p_y = nullptr, *p_yn = nullptr, *p_z1 = nullptr, *p_h1 = nullptr, *p_h1n = nullptr, *p_z2 = nullptr, *p_h2 = nullptr,
            *proj = nullptr;
     if (n_img > 0) {
-        VILA_REQUIRE(pj->in_dim == D, "sft: the dynamic_s2 projector input (in_dim %d != tower hidden %d) has no backward here", pj->in_dim, D);
+        VILA_REQUIRE(pj->in_dim == Dp, "sft: projector in_dim %d != %d (tower hidden %d x %d scales)", pj->in_dim, Dp, D, s2 ? b->s2_n_scales : 1);
+        VILA_REQUIRE(!s2 || (b->s2_desc != nullptr && b->s2_tile_desc != nullptr && b->s2_n_scales >= 1 && b->s2_n_scales <= 4),
+                     "sft: dynamic_s2 needs s2_desc, s2_tile_desc and 1..4 scales");
         VILA_REQUIRE(b->pixels != nullptr, "sft: pixels are NULL");
         patches = a.take<bf16_t>((size_t)Mv * Kp);
         bf16_t* wpad = a.take<bf16_t>((size_t)D * Kp);
@@ -151,8 +159,13 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
             x = xo;
         }
         // projector (base_projector.py:145-174): space-to-depth -> LN -> Linear -> GELU(erf) [-> LN -> Linear -> GELU] -> Linear
+        if (s2) {                                             // merge_features_for_dynamic_s2 + split_chessboard + rearrange as one gather
+            bf16_t* merged = a.take<bf16_t>((size_t)n_pin * Nv * Dp);
+            RUN(launch_s2_merge(x, merged, b->s2_desc, n_pin, g_, D, b->s2_n_scales, s2_splits, c.s));
+            x = merged;
+        }
         p_y = a.take<bf16_t>((size_t)Mp_ * C1); p_yn = a.take<bf16_t>((size_t)Mp_ * C1);
-        RUN(launch_space_to_depth(x, p_y, n_img, g_, D, kdown, c.s));
+        RUN(launch_space_to_depth(x, p_y, n_pin, g_, Dp, kdown, c.s));
         RUN(launch_layernorm(p_y, B(pj->ln1_w), B(pj->ln1_b), p_yn, Mp_, C1, 1e-5f, c.s));
         proj = a.take<bf16_t>((size_t)Mp_ * H);
         if (kdown == 2) {
@@ -161,7 +174,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
             RUN(launch_act_fwd(p_z1, p_h1, (int64_t)Mp_ * H, 2, c.s));
             VILA_TRY(gemm(c, p_h1, H, B(pj->fc2_w), H, B(pj->fc2_b), nullptr, 0, proj, H, Mp_, H, H));
         } else {
-            const int C3 = 3 * D;
+            const int C3 = 3 * Dp;
             p_z1 = a.take<bf16_t>((size_t)Mp_ * C3); p_h1 = a.take<bf16_t>((size_t)Mp_ * C3); p_h1n = a.take<bf16_t>((size_t)Mp_ * C3);
             p_z2 = a.take<bf16_t>((size_t)Mp_ * H); p_h2 = a.take<bf16_t>((size_t)Mp_ * H);
             VILA_TRY(gemm(c, p_yn, C1, B(pj->fc1_w), C1, B(pj->fc1_b), nullptr, 0, p_z1, C3, Mp_, C3, C1));
@@ -311,7 +324,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         dz1 = a.take<bf16_t>((size_t)Mp_ * H);
         RUN(launch_act_bwd(p_z1, dh1, dz1, (int64_t)Mp_ * H, 2, c.s));
     } else {
-        const int C3 = 3 * D;
+        const int C3 = 3 * Dp;
         bf16_t* dh2 = a.take<bf16_t>((size_t)Mp_ * H);
         VILA_TRY(linear_bwd(c, p_h2, B(pj->fc3_w), dproj, B((void*)pg->fc3_w), B((void*)pg->fc3_b), dh2, nullptr, Mp_, H, H, vit_cm(), true));
         bf16_t* dz2 = a.take<bf16_t>((size_t)Mp_ * H);
@@ -323,14 +336,20 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         dz1 = a.take<bf16_t>((size_t)Mp_ * C3);
         RUN(launch_act_bwd(p_z1, dh1, dz1, (int64_t)Mp_ * C3, 2, c.s));
     }
-    const int N1 = (kdown == 2) ? H : 3 * D;
+    const int N1 = (kdown == 2) ? H : 3 * Dp;
     bf16_t* dyn = a.take<bf16_t>((size_t)Mp_ * C1);
     VILA_TRY(linear_bwd(c, p_yn, B(pj->fc1_w), dz1, B((void*)pg->fc1_w), B((void*)pg->fc1_b), dyn, nullptr, Mp_, N1, C1, vit_cm(), true));
     bf16_t* dy = a.take<bf16_t>((size_t)Mp_ * C1);
     VILA_TRY(norm_bwd(c, p_y, B(pj->ln1_w), dyn, dy, B((void*)pg->ln1_w), B((void*)pg->ln1_b), Mp_, C1, 1e-5f, 0));
     ready(VILA_BUCKET_PROJECTOR, 0);
     bf16_t* dv = a.take<bf16_t>((size_t)Mv * D);
-    RUN(launch_depth_to_space(dy, dv, n_img, g_, D, kdown, c.s));
+    if (s2) {
+        bf16_t* dmerged = a.take<bf16_t>((size_t)n_pin * Nv * Dp);
+        RUN(launch_depth_to_space(dy, dmerged, n_pin, g_, Dp, kdown, c.s));
+        RUN(launch_s2_merge_bwd(dmerged, dv, b->s2_tile_desc, n_img, g_, D, b->s2_n_scales, s2_splits, c.s));
+    } else {
+        RUN(launch_depth_to_space(dy, dv, n_img, g_, D, kdown, c.s));
+    }
 
     // ================= vision tower backward =================
     bf16_t* dv_pp[2] = {a.take<bf16_t>((size_t)Mv * D), a.take<bf16_t>((size_t)Mv * D)};

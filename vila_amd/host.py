@@ -113,16 +113,19 @@ def s2_plan(block_sizes, scales, grid: int, downsample: int):
     s2_resize_output_to_scale_idx = -1 (the NVILA recipe, scripts/NVILA/stage1_9tile.sh:22):
       desc      [n_blocks, 6] i32  {first tile of the image, bh, bw, block row, block col, single}  for vila_s2_merge_bf16
       n_tiles   total tiles the tower must have produced (checked like the reference's assert, :360-362)
+      tile_desc [n_tiles, 8] i32   {first output block of the tile's image, bh, bw, scale index, tile row, tile col, single, 0}  for the
+                backward (vila_s2_merge_bwd_bf16)
       perm      per image: for every output token (h w order over the merged (g' bh) x (g' bw) grid, :386-389) its row in the
                 projector output [n_blocks * g'^2]   (merge_chessboard + "1 c h w -> (h w) c" as one row gather)
     """
     splits = [s // scales[0] for s in scales[:-1]]
     n_pre = sum(s * s for s in splits)
     gd = (grid + downsample - 1) // downsample
-    desc, perms, base, blk = [], [], 0, 0
+    desc, tdesc, perms, base, blk = [], [], [], 0, 0
     for bs in block_sizes:
         if bs is None:
             desc.append([base, 1, 1, 0, 0, 1])
+            tdesc.append([blk, 1, 1, 0, 0, 0, 1, 0])
             perms.append(torch.arange(blk * gd * gd, (blk + 1) * gd * gd, dtype=torch.int32))
             base += 1
             blk += 1
@@ -131,10 +134,19 @@ def s2_plan(block_sizes, scales, grid: int, downsample: int):
         for i in range(bh):
             for j in range(bw):
                 desc.append([base, bh, bw, i, j, 0])
+        # tiles of the image in tower order: scales ascending, each scale's chessboard row-major (merge_chessboard, llava_arch.py:255-275)
+        for k, sp in enumerate(splits):
+            for i in range(sp):
+                for j in range(sp):
+                    tdesc.append([blk, bh, bw, k, i, j, 0, 0])
+        for i in range(bh):
+            for j in range(bw):
+                tdesc.append([blk, bh, bw, len(splits), i, j, 0, 0])
         Y = torch.arange(gd * bh)[:, None]
         X = torch.arange(gd * bw)[None, :]
         src = (blk + (Y // gd) * bw + (X // gd)) * gd * gd + (Y % gd) * gd + (X % gd)
         perms.append(src.reshape(-1).to(torch.int32))
         base += n_pre + bh * bw
         blk += bh * bw
-    return SimpleNamespace(desc=torch.tensor(desc, dtype=torch.int32), n_tiles=base, n_blocks=blk, perms=perms, splits=splits)
+    return SimpleNamespace(desc=torch.tensor(desc, dtype=torch.int32), tile_desc=torch.tensor(tdesc, dtype=torch.int32), n_tiles=base,
+                           n_blocks=blk, perms=perms, splits=splits)

@@ -259,6 +259,12 @@ class HipMultimodalProjector(_HipModule):
 # --------------------------------------------------------------------------------------------------------------
 # LLM
 # --------------------------------------------------------------------------------------------------------------
+def _as_i64(u: int) -> int:
+    """uint64 bit pattern -> the int64 holding the same bits (torch has no uint64 fill)."""
+    u = int(u) & 0xFFFFFFFFFFFFFFFF
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
 class CausalLMOutput(SimpleNamespace):
     """Fields of HF CausalLMOutputWithPast that llava_llama.py:134-159 consumes."""
 
@@ -405,17 +411,21 @@ class HipQwen2ForCausalLM(_HipModule):
     def _decode_session(self, cache, max_new_tokens: int, sampling=None):
         """Device-resident decode state + workspace (+ captured hipGraph) reused across generate() calls.
         sampling: None (greedy) or (temperature, top_k, top_p, seed) — baked into the captured graph, hence part of the key."""
+        # the seed is NOT part of the key: it lives in a device scalar the sampler reads (VilaSampling.seed_dev), so every sampled request
+        # with the same (temperature, top_k, top_p) replays the same captured graph (ADVICE round 2: a fresh seed per call used to drop
+        # the graph, the workspace and the weight struct on every sampled request)
         key = (cache.k.data_ptr(), max_new_tokens, self.model.embed_tokens.weight.data_ptr(),
-               _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr(), sampling)
+               _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr(), None if sampling is None else tuple(sampling[:3]))
         if self._decode is not None and self._decode.key == key:
+            if sampling is not None:
+                self._decode.seed.fill_(_as_i64(sampling[3]))
             return self._decode
         self._invalidate()          # another cache / length / weight storage: drop the old session and its graph
         dev = self.device
         lib = _lib.load()
         w = self._struct()
         st = SimpleNamespace(key=key, cache=cache)
-        st.sampling = None if sampling is None else _lib.VilaSampling(float(sampling[0]), int(sampling[1]), float(sampling[2]),
-                                                                      int(sampling[3]) & 0xFFFFFFFFFFFFFFFF)
+        st.sampling = None
         # the session outlives the call that creates it: built outside inference mode even when the first generate() runs under
         # torch.inference_mode() (llava_arch.py:823), or a later no_grad caller could not update `pos` / `token` in place
         with torch.inference_mode(False):
@@ -425,6 +435,11 @@ class HipQwen2ForCausalLM(_HipModule):
             st.n_out = torch.zeros(1, device=dev, dtype=torch.int32)
             st.logits = torch.zeros(self.lcfg.vocab_size, device=dev, dtype=torch.float32)
             st.ws = torch.empty((lib.vila_llm_decode_workspace_bytes(C.byref(w.shape), cache.max_ctx),), device=dev, dtype=torch.uint8)
+            st.seed = torch.zeros(1, device=dev, dtype=torch.int64)          # the sampler's seed (bit pattern of a uint64)
+        if sampling is not None:
+            st.seed.fill_(_as_i64(sampling[3]))
+            st.sampling = _lib.VilaSampling(float(sampling[0]), int(sampling[1]), float(sampling[2]), int(sampling[3]) & 0xFFFFFFFFFFFFFFFF,
+                                            st.seed.data_ptr())
         st.c = _lib.VilaDecodeState(st.pos.data_ptr(), st.token.data_ptr(), st.out_ids.data_ptr(), st.n_out.data_ptr(),
                                     max(max_new_tokens, 1), st.logits.data_ptr())
         st.graph = None

@@ -399,3 +399,18 @@ def s2_merge(feats: torch.Tensor, desc: torch.Tensor, n_scales: int, splits) -> 
     check(_L().vila_s2_merge_bf16(feats.contiguous().data_ptr(), out.data_ptr(), desc.contiguous().data_ptr(), desc.shape[0], g, Cc, n_scales, sp,
                                   _stream()), "s2_merge")
     return out
+
+
+def s2_merge_bwd(dy: torch.Tensor, tile_desc: torch.Tensor, n_scales: int, splits) -> torch.Tensor:
+    """Adjoint of s2_merge: dy [n_blocks, N, n_scales*C] + per-tile descriptors [n_tiles, 8] i32 (host.s2_plan) -> dfeats [n_tiles, N, C]."""
+    import ctypes as C
+    _need(dy, name="dy")
+    assert tile_desc.dtype == torch.int32 and tile_desc.is_cuda and tile_desc.dim() == 2 and tile_desc.shape[1] == 8
+    _, N, CC = dy.shape
+    Cc = CC // n_scales
+    g = int(round(N ** 0.5))
+    dx = torch.empty((tile_desc.shape[0], N, Cc), device=dy.device, dtype=dy.dtype)
+    sp = (C.c_int32 * max(len(splits), 1))(*splits) if len(splits) else (C.c_int32 * 1)(1)
+    check(_L().vila_s2_merge_bwd_bf16(dy.contiguous().data_ptr(), dx.data_ptr(), tile_desc.contiguous().data_ptr(), tile_desc.shape[0], g, Cc,
+                                      n_scales, sp, _stream()), "s2_merge_bwd")
+    return dx

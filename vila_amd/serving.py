@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 IMAGE_TOKEN = "<image>"
+MEDIA_TOKENS = {"image": "<image>", "video": "<vila/video>"}          # llava/constants.py:32-35
 _DATA_URL = re.compile(r"^data:image/(png|jpe?g);base64,(.*)$", re.S)
 
 
@@ -58,8 +59,9 @@ def _split_prompt(prompt: Union[str, Sequence[Any]]):
     text, images = "", []
     for part in ([prompt] if isinstance(prompt, str) else prompt):
         if isinstance(part, str):
-            if IMAGE_TOKEN in part:
-                part = part.replace(IMAGE_TOKEN, "").strip()
+            for token in MEDIA_TOKENS.values():                       # every media token, the video one included (media.py:103-106)
+                if token in part:
+                    part = part.replace(token, "").strip()
             text += part
         else:
             images.append(part)
@@ -119,7 +121,7 @@ def _request_models():
         ChatMessage = pydantic.create_model("ChatMessage", role=(str, ...), content=(Union[str, List[Dict[str, Any]]], ...))
         ChatCompletionRequest = pydantic.create_model(
             "ChatCompletionRequest", model=(str, ...), messages=(List[ChatMessage], ...), max_tokens=(Optional[int], 512),
-            temperature=(Optional[float], 0.0), top_p=(Optional[float], 1.0), stream=(Optional[bool], False))
+            temperature=(Optional[float], 0.2), top_p=(Optional[float], 0.9), stream=(Optional[bool], False))      # server.py:101-102
         _MODELS = (ChatMessage, ChatCompletionRequest)
     return _MODELS
 
@@ -160,7 +162,8 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B"):
             parts, system = _prompt_of(request.messages)
             with torch.inference_mode():
                 text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
-                                        temperature=request.temperature or 0.0, top_p=request.top_p if request.top_p is not None else 1.0)
+                                        temperature=request.temperature if request.temperature is not None else 0.2,
+                                        top_p=request.top_p if request.top_p is not None else 0.9)
             if request.stream:
                 def chunks() -> Iterator[str]:
                     for i, word in enumerate(re.findall(r"\S+\s*", text)):

@@ -93,12 +93,27 @@ def _draw(name: str, shape, kind: str, cfg: VilaConfig, seed: int, device) -> to
     if kind == "w":
         return x * cfg.init_std
     if kind == "h":
-        return x * cfg.lm_head_std
+        x = x * cfg.lm_head_std
+        a = float(getattr(cfg, "lm_head_tail", 0.0))
+        if a > 0:
+            x = x * lm_head_row_scale(name, shape[0], cfg).to(device)[:, None]
+        return x
     if kind == "b":
         return x * 0.02
     if kind == "g":  # norm gains: 1 + noise so a dropped gain multiply is visible to parity tests
         return 1.0 + 0.1 * x
     raise ValueError(kind)
+
+
+def lm_head_row_scale(name: str, rows: int, cfg: VilaConfig) -> torch.Tensor:
+    """Pareto(a) row norms of the synthetic lm_head (configs.VilaConfig.lm_head_tail), always drawn with the CPU generator in fp64 and
+    normalised so that the largest is lm_head_tail_max; keyed by (name, lm_head_tail_seed) only, so that the rows keep their direction
+    when the seed of the scales changes (oracle/make_golden_full.py searches over it: logits scale row by row)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32((name + "/tail").encode()) ^ (int(cfg.lm_head_tail_seed) * 0x9E3779B1)) & 0x7FFFFFFF)
+    u = torch.rand(rows, generator=g, dtype=torch.float64).clamp_min(1e-12)
+    s = u.pow(-1.0 / float(cfg.lm_head_tail))
+    return (s / s.max() * float(cfg.lm_head_tail_max)).float()
 
 
 def make_weights(cfg: VilaConfig, seed: int = 0, device="cpu", dtype=torch.float32,

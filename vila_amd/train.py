@@ -77,6 +77,7 @@ class FlatParams:
             self.m = torch.zeros_like(self.master)
             self.v = torch.zeros_like(self.master)
         self.step_count = 0
+        self.bucket_steps: Dict[str, int] = {}     # AdamW updates seen per gradient bucket (bias correction; see SFTTrainer._adamw_bucket)
 
     def sync_master_from_params(self) -> None:
         """Call after the bf16 parameters were overwritten behind the trainer's back (checkpoint.load_weights_into / model.load_weights
@@ -86,16 +87,28 @@ class FlatParams:
             self.master.copy_(self.params)
 
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        names = sorted(self.bucket_steps)
         return {"master": self.master, "exp_avg": self.m, "exp_avg_sq": self.v,
-                "step": torch.tensor([self.step_count], dtype=torch.int64), "numel": torch.tensor([self.numel], dtype=torch.int64)}
+                "step": torch.tensor([self.step_count], dtype=torch.int64), "numel": torch.tensor([self.numel], dtype=torch.int64),
+                "bucket_steps": torch.tensor([self.bucket_steps[n] for n in names], dtype=torch.int64),
+                "bucket_names": torch.tensor(list("\n".join(names).encode()), dtype=torch.uint8)}
 
     def load_optimizer_state(self, sd: Dict[str, torch.Tensor]) -> None:
         if int(sd["numel"][0]) != self.numel:
             raise ValueError(f"optimizer state holds {int(sd['numel'][0])} elements, the model has {self.numel}")
+        for k in ("master", "exp_avg", "exp_avg_sq"):     # validate everything BEFORE the first copy into the live buffers
+            if k not in sd:
+                raise KeyError(f"optimizer state has no '{k}'")
+            if tuple(sd[k].shape) != (self.numel,):
+                raise ValueError(f"optimizer state '{k}' has shape {tuple(sd[k].shape)}, expected ({self.numel},)")
         with torch.no_grad():
             self.master.copy_(sd["master"]); self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
             self.params.copy_(self.master)               # bf16 params are the rounding of the master copy
         self.step_count = int(sd["step"][0])
+        self.bucket_steps = {}
+        if "bucket_names" in sd and sd["bucket_names"].numel():
+            names = bytes(sd["bucket_names"].to(torch.uint8).tolist()).decode().split("\n")
+            self.bucket_steps = {n: int(c) for n, c in zip(names, sd["bucket_steps"].tolist())}
 
     def grad(self, name: str) -> torch.Tensor:
         o, k, shape = self.index[name]
@@ -239,6 +252,7 @@ class SFTTrainer:
         self.cm_vit = self.cm and flag("VILA_SFT_CM_VIT", "1")
         self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.side is not None) else None   # the side stream's own slabs
         self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
+        self._touched: List[str] = []      # bucket prefixes whose gradients this step produced, in the order they became final
 
     def _attn_bwd(self, *a, **kw) -> None:
         """Flash-attention backward.  dQ and dK / dV share no output and both under-fill the chip (208 blocks at 4 x 769 tokens, 4-13 % of the
@@ -259,21 +273,36 @@ class SFTTrainer:
         """Gradients under `prefix` are final once the compute stream and the wgrad stream reach this point: hand the bucket to the
         optimizer stream (exchange, then AdamW on that slice) and carry on with the layers below."""
         if self.opt is None:
+            # no optimizer stream: the exchange is ordered behind the compute stream, so the wgrad stream (the weight-gradient GEMMs and
+            # bias column sums of this bucket are still in flight there) has to be joined first, or the all-reduce would read / overwrite
+            # gradient slices that are being written (ADVICE round 2)
+            if self.side is not None:
+                torch.cuda.current_stream().wait_event(self.side.record_event())
+            self._touched.append(prefix)
             self.reducer.ready(prefix)
             return
         main = torch.cuda.current_stream()
         self.opt.wait_event(main.record_event())
         if self.side is not None:
             self.opt.wait_event(self.side.record_event())
+        self._touched.append(prefix)
         with torch.cuda.stream(self.opt):
             h = self.reducer.ready(prefix)
             if self._bucket_step:
                 if h is not None:
                     h.wait()                                        # the optimizer stream waits for this bucket's all-reduce only
-                f = self.flat
-                a, b = f.span(prefix)
-                ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
-                               self.eps, self.wd, f.step_count + 1, 1.0, lean=self.lean_adamw)
+                self._adamw_bucket(prefix, 1.0)
+
+    def _adamw_bucket(self, prefix: str, grad_scale: float) -> None:
+        """AdamW on the slice of one gradient bucket.  Semantics = torch.optim.AdamW with grad = None for what a step did not touch:
+        a bucket that received no gradient this step (text-only batch: tower + projector; the unused 27th ViT layer and post_layernorm:
+        never) is NOT updated — no weight decay, no moment decay — and its bias correction uses the number of updates IT has seen."""
+        f = self.flat
+        a, b = f.span(prefix)
+        step = f.bucket_steps.get(prefix, 0) + 1
+        f.bucket_steps[prefix] = step
+        ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
+                       self.eps, self.wd, step, grad_scale, lean=self.lean_adamw)
 
     # ------------------------------------------------------------------ ViT ------------------------------------------------
     def _vit_fwd(self, pixels: torch.Tensor):
@@ -452,6 +481,35 @@ class SFTTrainer:
             self._ready(l)
         return dx
 
+    # ------------------------------------------------------------------ media plan ----------------------------------------
+    def _media_plan(self, n_px: int, block_sizes):
+        """Integer plan of the image side of one batch.  Plain recipe: every image is one tile, its tokens are the projector's rows
+        [i*Tm, (i+1)*Tm).  dynamic_s2 (llava_arch.py:369-390): `n_px` tiles of all scales of all images, one entry of `block_sizes` per
+        IMAGE; the projector runs on the merged blocks and image i's tokens are the chessboard re-merge of its blocks = `perms[i]`.
+        -> (s2 plan or None, rows: per image the projector-output row of each of its tokens, n_pin = projector inputs)"""
+        cfg = self.cfg
+        Tm = cfg.tokens_per_tile
+        if not getattr(cfg, "dynamic_s2", False):
+            return None, [torch.arange(i * Tm, (i + 1) * Tm, dtype=torch.int64) for i in range(n_px)], n_px
+        from .host import s2_plan
+        if cfg.s2_resize_output_to_scale_idx not in (-1, len(cfg.s2_scales) - 1):
+            raise NotImplementedError("dynamic_s2: only s2_resize_output_to_scale_idx = -1 (the NVILA recipe) is implemented")
+        if block_sizes is None:
+            raise ValueError("dynamic_s2 training needs media_config['image']['block_sizes'] (one (h, w) or None per image)")
+        plan = s2_plan(list(block_sizes), list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+        if plan.n_tiles != n_px:
+            raise AssertionError(f"The number of blocks ({plan.n_tiles}) does not match length of image_features ({n_px})!")
+        return plan, [p.long() for p in plan.perms], plan.n_blocks
+
+    @staticmethod
+    def _media_rows(plan_img_src: torch.Tensor, rows: List[torch.Tensor]):
+        """Map the splice plan's media-row indices (into the concatenation of the per-image blocks [tokens..., "\n"]) to projector rows:
+        -> (feature row of every spliced media row or -1 for the "\n" end token)."""
+        if not rows:
+            return torch.empty((0,), dtype=torch.int64)
+        table = torch.cat([torch.cat([r, torch.tensor([-1], dtype=torch.int64)]) for r in rows]).to(plan_img_src.device)
+        return table[plan_img_src.long()]
+
     # ------------------------------------------------------------------ one C-ABI call ------------------------------------
     def _c_structs(self, ptr):
         """(VilaVitWeights, VilaProjWeights, VilaLlmWeights) whose pointers come from `ptr(name)`: flat.param for the weights, flat.grad for
@@ -502,7 +560,8 @@ class SFTTrainer:
         return vw, pw, lw, keep
 
     def forward_backward_c(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
-                           attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None) -> torch.Tensor:
+                           attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None,
+                           block_sizes=None) -> torch.Tensor:
         """forward_backward through ONE C-ABI call (`vila_sft_fwd_bwd`): the host plans the splice / pack (integers only), the library
         runs every forward and backward kernel and calls back per gradient bucket, where this class starts the exchange + AdamW on its
         optimizer stream exactly as the Python-orchestrated path does."""
@@ -510,19 +569,18 @@ class SFTTrainer:
         from . import _lib
         from ._lib import check
         model, cfg, flat = self.model, self.cfg, self.flat
-        if getattr(cfg, "dynamic_s2", False):
-            raise NotImplementedError("SFTTrainer: the dynamic_s2 merge (llava_arch.py:298-390) has no backward here")
         dev = model.device
         for st in (self.opt, self.side):
             if st is not None:
                 torch.cuda.current_stream().wait_stream(st)
         flat.grads.zero_()
         self.reducer.log.clear()
+        self._touched = []
         c = cfg.llm
-        n_img = len(images)
-        Tm = cfg.tokens_per_tile
+        n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
-        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right",
+        s2, rows, n_pin = self._media_plan(n_img, block_sizes)
+        plan = splice_plan(input_ids, attention_mask, labels, [int(r.numel()) + 1 for r in rows], cfg.image_token_id, "right",
                            max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
@@ -530,10 +588,10 @@ class SFTTrainer:
         inv[rp.rows] = torch.arange(T)
         i32 = lambda t: t.to(torch.int32).contiguous().to(dev)
         txt_src, txt_dst = i32(plan.txt_src), i32(inv[plan.txt_dst.long()])
-        src = plan.img_src.long()
+        mrow = self._media_rows(plan.img_src, rows)
         dst_p = inv[plan.img_dst.long()]
-        is_nl = (src % (Tm + 1)) == Tm
-        feat_src, feat_dst, nl_dst = i32(((src // (Tm + 1)) * Tm + src % (Tm + 1))[~is_nl]), i32(dst_p[~is_nl]), i32(dst_p[is_nl])
+        is_nl = mrow < 0
+        feat_src, feat_dst, nl_dst = i32(mrow[~is_nl]), i32(dst_p[~is_nl]), i32(dst_p[is_nl])
         nl_src = torch.full((int(nl_dst.numel()),), cfg.newline_token_id, dtype=torch.int32, device=dev)
         tgt = torch.full((T,), IGNORE_INDEX, dtype=torch.int64)
         tgt[:-1] = rp.labels[1:]
@@ -550,6 +608,11 @@ class SFTTrainer:
         b.nl_src, b.nl_dst, b.n_nl = P(nl_src), P(nl_dst), int(nl_dst.numel())
         b.positions, b.cu_seqlens, b.n_seq, b.max_seqlen = P(pos), P(cu), int(cu.numel()) - 1, int(rp.max_seqlen)
         b.target_rows, b.targets, b.n_targets, b.loss_scale = P(rows32), P(tg), n_valid, 1.0 / max(n_items, 1)
+        if s2 is not None:
+            s2_desc, s2_tdesc = s2.desc.contiguous().to(dev), s2.tile_desc.contiguous().to(dev)
+            b.s2_desc, b.s2_tile_desc, b.s2_n_blocks, b.s2_n_scales = P(s2_desc), P(s2_tdesc), n_pin, len(cfg.s2_scales)
+            for k, v in enumerate(s2.splits[:4]):
+                b.s2_splits[k] = int(v)
         if getattr(self, "_cw", None) is None:
             self._cw = self._c_structs(lambda n: flat.param(n).data_ptr())
             self._cg = self._c_structs(lambda n: flat.grad(n).data_ptr())
@@ -590,13 +653,14 @@ class SFTTrainer:
 
     # ------------------------------------------------------------------ the step -------------------------------------------
     def forward_backward(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
-                         attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None) -> torch.Tensor:
+                         attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None,
+                         block_sizes=None) -> torch.Tensor:
         """Forward + backward of the packed batch; gradients land in self.flat.grads (already all-reduced when DP > 1).
-        Returns the (local) loss = sum CE / num_items_in_batch as a device scalar."""
+        Returns the (local) loss = sum CE / num_items_in_batch as a device scalar.
+        dynamic_s2 (the NVILA-8B recipe, scripts/NVILA/stage1_9tile.sh:19-22): `images` = the tiles of every scale of every image in
+        tower order, `block_sizes` = media_config["image"]["block_sizes"] (one (h, w) or None per image); between tower and projector
+        run the merge kernel forward and its adjoint backward (llava_arch.py:298-390)."""
         model, cfg, flat = self.model, self.cfg, self.flat
-        if getattr(cfg, "dynamic_s2", False):
-            raise NotImplementedError("SFTTrainer: the dynamic_s2 merge (llava_arch.py:298-390) has no backward here; train with the plain "
-                                      "single-scale tower (cfg.dynamic_s2 = False)")
         dev = model.device
         P, G = flat.param, flat.grad
         for st in (self.opt, self.side):             # the previous step's optimizer / exchange / wgrad work reads grads, writes params
@@ -604,21 +668,23 @@ class SFTTrainer:
                 torch.cuda.current_stream().wait_stream(st)
         flat.grads.zero_()
         self.reducer.log.clear()
+        self._touched = []
         c = cfg.llm
         H = c.hidden_size
         # ---- vision + projector (+ "\n" end token) ----
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16) if len(images) else None
-        n_img = 0 if pixels is None else pixels.shape[0]
+        n_img = 0 if pixels is None else pixels.shape[0]          # tiles (dynamic_s2: of every scale of every image)
+        s2, rows, n_pin = self._media_plan(n_img, block_sizes)
         if n_img:
             feats, vit_saved = self._vit_fwd(pixels)
-            proj, proj_saved = self._proj_fwd(feats)                                   # [n_img, T', H]
-            Tm = proj.shape[1]
-        else:
-            Tm = 0
+            if s2 is not None:
+                s2_desc, s2_tdesc = s2.desc.to(dev), s2.tile_desc.to(dev)
+                feats = ops.s2_merge(feats, s2_desc, len(cfg.s2_scales), s2.splits)   # [n_blocks, N, n_scales*C]
+            proj, proj_saved = self._proj_fwd(feats)                                   # [n_pin, T', H]
         table = P("llm.model.embed_tokens.weight")
         # ---- splice + pack (llava_arch.py:412-490, 744-800) ----
         # training truncates every sample to tokenizer.model_max_length AFTER media expansion (llava_arch.py:519-526)
-        plan = splice_plan(input_ids, attention_mask, labels, [Tm + 1] * n_img, cfg.image_token_id, "right",
+        plan = splice_plan(input_ids, attention_mask, labels, [int(r.numel()) + 1 for r in rows], cfg.image_token_id, "right",
                            max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
@@ -631,27 +697,31 @@ class SFTTrainer:
         if n_img:
             # media row i of the [n_img, Tm + 1] block list: r < Tm -> projector row, r == Tm -> the "\n" end token; rows cut off by the
             # truncation are absent from plan.img_src / img_dst
-            src = plan.img_src.long()
+            mrow = self._media_rows(plan.img_src, rows).to(inv.device)
             dst_p = inv[plan.img_dst.long()]
-            is_nl = (src % (Tm + 1)) == Tm
-            feat_src = ((src // (Tm + 1)) * Tm + src % (Tm + 1))[~is_nl].to(torch.int32).to(dev)
+            is_nl = mrow < 0
+            feat_src = mrow[~is_nl].to(torch.int32).to(dev)
             feat_dst = dst_p[~is_nl].to(torch.int32).to(dev)
             nl_dst = dst_p[is_nl].to(torch.int32).to(dev)
             n_feat, n_nl = int(feat_dst.numel()), int(nl_dst.numel())
-            ops.copy_rows(proj.reshape(n_img * Tm, H), x0, feat_src, feat_dst, n_feat)
+            n_prow = proj.shape[0] * proj.shape[1]                                     # projector output rows
+            ops.copy_rows(proj.reshape(n_prow, H), x0, feat_src, feat_dst, n_feat)
             nl_src = torch.full((n_nl,), cfg.newline_token_id, dtype=torch.int32, device=dev)
             if n_nl:
                 ops.copy_rows(table, x0, nl_src, nl_dst, n_nl)
         pos = rp.position_ids.to(dev)
         cu = rp.cu_seqlens.to(dev)
-        lab = rp.labels.to(dev)
+        # rows that have a target (HF ForCausalLMLoss: shift by one inside each packed row): integer work on the plan's device — the
+        # host for host-side ids — so the step has no nonzero() launch + device sync in its middle
+        lab_h = rp.labels
+        tgt_h = torch.full((T,), IGNORE_INDEX, dtype=torch.int64, device=lab_h.device)
+        tgt_h[:-1] = lab_h[1:]
+        valid_h = torch.nonzero(tgt_h != IGNORE_INDEX, as_tuple=False).flatten()
+        n_valid = int(valid_h.numel())
+        valid, tgt_valid = valid_h.to(dev), tgt_h[valid_h].contiguous().to(dev)
         # ---- LLM ----
         saved = self._llm_fwd(x0, pos, cu, rp.max_seqlen)
-        # ---- loss on the rows that have a target (HF ForCausalLMLoss: shift by one inside each packed row) ----
-        tgt = torch.full((T,), IGNORE_INDEX, dtype=torch.int64, device=dev)
-        tgt[:-1] = lab[1:]
-        valid = torch.nonzero(tgt != IGNORE_INDEX, as_tuple=False).flatten()
-        n_valid = int(valid.numel())
+        # ---- loss on the rows that have a target ----
         n_items = n_valid if num_items_in_batch is None else int(num_items_in_batch)
         loss = torch.zeros((1,), device=dev, dtype=torch.float32)
         dhn = torch.zeros((T, H), device=dev, dtype=torch.bfloat16)
@@ -662,7 +732,7 @@ class SFTTrainer:
             hv = torch.empty((n_valid, H), device=dev, dtype=torch.bfloat16)
             ops.copy_rows(saved.hn, hv, rows32, None, n_valid)
             logits = ops.gemm(hv, head, out_f32=True)                                    # [n_valid, V] fp32 only
-            dlog = ops.ce_loss(logits, tgt[valid].contiguous(), loss, 1.0 / max(n_items, 1))
+            dlog = ops.ce_loss(logits, tgt_valid, loss, 1.0 / max(n_items, 1))
             del logits
             dhv = linear_bwd(hv, head, dlog, G(head_name), cm=self.cm, ws=self.ws)
             ops.copy_rows(dhv, dhn, None, rows32, n_valid)
@@ -682,10 +752,12 @@ class SFTTrainer:
             ops.scatter_add_rows(dnl, ge, nl_src)
         self._ready("llm.model.embed_tokens.")
         if n_img:
-            full = n_feat == n_img * Tm
-            dproj = (torch.empty if full else torch.zeros)((n_img * Tm, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
+            full = n_feat == n_prow
+            dproj = (torch.empty if full else torch.zeros)((n_prow, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
             ops.copy_rows(dx0, dproj, feat_dst, feat_src, n_feat)
-            dfeats = self._proj_bwd(dproj.view(n_img, Tm, H), proj_saved)
+            dfeats = self._proj_bwd(dproj.view(proj.shape[0], proj.shape[1], H), proj_saved)
+            if s2 is not None:                                                         # adjoint of the merge: back onto the tower's tiles
+                dfeats = ops.s2_merge_bwd(dfeats, s2_tdesc, len(cfg.s2_scales), s2.splits)
             self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
         for st in (self.side, self.opt):
             if st is not None:
@@ -703,9 +775,11 @@ class SFTTrainer:
             return
         scale = 1.0
         if self.max_grad_norm is not None:
-            norm = float(ops.sumsq(f.grads).sqrt())
+            norm = float(ops.sumsq(f.grads).sqrt())                  # untouched buckets hold zeros
             scale = min(1.0, self.max_grad_norm / (norm + 1e-6))
-        ops.adamw_step(f.master, f.m, f.v, f.grads, f.params, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, scale)
+        # the same buckets, the same per-bucket step counts as the per-bucket path: results do not depend on VILA_SFT_OPT_STREAM
+        for prefix in self._touched:
+            self._adamw_bucket(prefix, scale)
 
     def global_num_items(self, labels_packed_valid: int) -> int:
         """Token count summed over ranks (transformer_normalize_monkey_patch.py:261-263)."""
@@ -716,14 +790,14 @@ class SFTTrainer:
             return int(t.item())
         return labels_packed_valid
 
-    def step(self, input_ids, images, labels, attention_mask=None) -> float:
+    def step(self, input_ids, images, labels, attention_mask=None, block_sizes=None) -> float:
         n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
         n_global = self.global_num_items(n_local)
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
         try:
             fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
-            loss = fb(input_ids, images, labels, attention_mask, n_global)
+            loss = fb(input_ids, images, labels, attention_mask, n_global, block_sizes)
             self.optimizer_step()
         finally:
             self._bucket_step = False
