@@ -51,7 +51,8 @@ def parse(argv=None):
     ap.add_argument("--no-sft", action="store_true", help="decode mode: skip the bounded SFT sub-measurement (1 warm + 2 timed steps)")
     ap.add_argument("--no-sustain", action="store_true", help="decode mode: skip the >= 2 s sustained replay after the timed region")
     ap.add_argument("--eager-decode", action="store_true", help="experiment: launch the kernels of a token eagerly instead of replaying a hipGraph")
-    ap.add_argument("--config", default="nvila_8b", choices=["nvila_8b", "reduced"])
+    ap.add_argument("--config", default="nvila_8b", choices=["nvila_8b", "reduced", "nvila_lite_3b"],
+                    help="nvila_lite_3b = BASELINE configs[0] on the GPU (3x3 projector, 2048-wide 36-layer tied-head LLM; use --prompt-tokens 32)")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--tsp", action="store_true", help="video mode: TSPVideoEncoder pool_sizes=[[8,1,1]] (scripts/NVILA/stage4.sh:50) -> 8 x 257 tokens")
     ap.add_argument("--mode", default="decode", choices=["decode", "sft", "video"],
@@ -132,16 +133,48 @@ def selftest_main(a, rank, world):
     """Harness self-test on CPU/gloo: same launcher, rendezvous, barrier, max-over-ranks and JSON plumbing as the GPU modes; the
     "step" is a fixed sleep, so value ~= world / 2 ms.  NOT a performance number."""
     dist = init_dist("gloo") if world > 1 else None
+    extra = {}
+    step = lambda: time.sleep(0.002)
+    if a.mode == "sft":
+        # dry run of the SFT mode's data-parallel plumbing (no kernels): the trainer's flat buffers over a tiny CPU model, the global
+        # token count and every gradient bucket's exchange over the process group, in the backward order the real step announces them
+        from vila_amd import configs
+        from vila_amd.train import SFTTrainer
+        from vila_amd.vlm import HipLlavaLlamaModel
+        torch.manual_seed(0)
+        cfg = configs.tiny("mlp_downsample")
+        tr = SFTTrainer(HipLlavaLlamaModel(cfg, device="cpu"), optimizer_state=False)
+        tr.flat.grads = tr.flat.grads.float()
+        order = ["llm.lm_head.", "llm.model.norm."] + [f"llm.model.layers.{i}." for i in reversed(range(cfg.llm.num_hidden_layers))]
+        order += ["llm.model.embed_tokens.", "mm_projector."]
+        order += [f"vision_tower.vision_tower.vision_model.encoder.layers.{i}." for i in reversed(range(cfg.vision.num_used_layers))]
+        order += ["vision_tower.vision_tower.vision_model.embeddings."]
+        box = {}
+
+        def step():
+            box["n"] = tr.global_num_items(100 + rank)
+            tr.reducer.log.clear()
+            tr.flat.grads.fill_(float(rank + 1))
+            for pre in order:
+                tr._ready(pre)
+            tr.reducer.wait()
+        step()
+        covered = torch.zeros(tr.flat.numel, dtype=torch.bool)
+        for _, s0, e0 in tr.reducer.log:
+            covered[s0:e0] = True
+        want = float(sum(range(1, world + 1)))
+        extra = {"mode": "sft dry run", "global_num_items": box["n"], "buckets": len(tr.reducer.log),
+                 "exchange_ok": bool((tr.flat.grads[covered] == want).all()), "grad_exchange": tr.reducer.describe()}
     for _ in range(a.warmup):
-        time.sleep(0.002)
-    elapsed = timed_region(dist, None, a.steps, lambda: time.sleep(0.002), lambda: None)
+        step()
+    elapsed = timed_region(dist, None, a.steps, step, lambda: None)
     group_world = dist.get_world_size() if dist is not None else 1
     if rank == 0:
         print(json.dumps({"metric": "bench harness selftest (no GPU work)", "value": round(world * a.steps / elapsed, 2), "unit": "steps/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
                           "config": {"workload": "selftest", "parallelism": f"gloo x{world}", "group_world_size": group_world,
-                                     "requested_gpus": a.gpus}}))
+                                     "requested_gpus": a.gpus, **extra}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -389,7 +422,7 @@ def decode_main(a, rank, world, dev, dist):
     from vila_amd import _lib, configs, ops, synthetic
     from vila_amd.vlm import build_model
     lib = _lib.load()
-    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.nvila_lite_3b() if a.config == "nvila_lite_3b" else configs.reduced_8b(3, 4)
     n_tiles, media_cfg = 1, {}
     if a.dynamic_s2:
         cfg = configs.nvila_8b_s2()
@@ -578,17 +611,21 @@ def decode_main(a, rank, world, dev, dist):
         cpu = cpu_baseline(cfg, S, os.cpu_count() or 1)
     value = world * a.steps / elapsed
     out = {
-        "metric": "decode tokens/sec + TTFT, NVILA-8B 1-image prompt",
+        "metric": "decode tokens/sec + TTFT, NVILA-Lite-3B-shaped 1-image prompt (BASELINE configs[0] on the GPU)" if a.config == "nvila_lite_3b" else
+                  "decode tokens/sec + TTFT, NVILA-8B 1-image prompt",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / A100_DECODE_TOKS, 3) if a.config == "nvila_8b" else None,
         "vs_baseline_note": "value / 82.1 tok/s (NVILA-8B FP16 on ONE A100, TinyChat backend, README.md:65) — other hardware and fp16; no MI355X number is published",
-        "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16", "data": "synthetic (seeded random weights at NVILA-8B shapes; U(-1,1) pixels; random prompt ids)",
+        "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16",
+        "data": f"synthetic (seeded random weights at {cfg.name} shapes; U(-1,1) pixels; random prompt ids)",
         "ttft_ms": round(ttft * 1e3, 3),
         "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
         "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}{' + W8A8 vision tower' if a.w8_vit else ''}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
                                f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                   "decode": f"hipGraph replay of {launches} launches/token"},
+                   "decode": f"hipGraph replay of {launches} launches/token",
+                   **({"parity": "unpinned against the reference (its quantised backend, TinyChat / llm-awq, is external: no reference-held vectors); "
+                                 "pinned against the dequantise-then-fp32 oracle of the same quantised weights"} if (a.w4 or a.w8_vit) else {})},
         "roofline": roofline,
         "prefill": prefill,
         "sft": sft,

@@ -47,3 +47,13 @@ def test_under_torchrun_the_environment_wins():
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
     assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_sft_mode_dry_run_on_two_ranks():
+    """`python bench.py --mode sft --gpus 2` as the driver will run it, minus the kernels: the launcher, the trainer's flat buffers, the
+    global token count and every gradient bucket's SUM all-reduce over the group."""
+    out = _run(["--gpus", "2", "--mode", "sft", "--selftest", "--steps", "2", "--warmup", "1"])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["group_world_size"] == 2 and c["mode"] == "sft dry run"
+    assert c["global_num_items"] == 100 + 101 and c["exchange_ok"] is True and c["buckets"] >= 8
+    assert "world=2" in c["grad_exchange"]

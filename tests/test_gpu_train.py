@@ -378,3 +378,67 @@ def test_per_bucket_adamw_equals_one_flat_step():
     # used to apply weight decay there, so the trained weights depended on a performance switch)
     assert torch.equal(ma[~covered], mb[~covered]) and torch.equal(pa[~covered], pb[~covered])
     assert float(m1a[~covered].abs().max()) == 0 and float(m1b[~covered].abs().max()) == 0
+
+
+@pytest.mark.parametrize("use_c", [False, True])
+def test_autograd_seam_reference_training_call_site(use_c):
+    """SURVEY §8b / VERDICT round 2: after the swap the reference's own call site (transformer_normalize_monkey_patch.py:183-249) —
+    `loss = model(**inputs).loss; loss.backward(); optimizer.step(); model.zero_grad()` — must produce gradients.  `.grad` of every
+    parameter vs fp32 autograd through the oracle (cosine >= 0.99), gradient accumulation over two micro-batches, a torch optimizer step
+    on the parameters, zero_grad(set_to_none=True) and a fresh backward."""
+    from oracle import vila_oracle as O
+    from vila_amd import configs, synthetic
+    from vila_amd.train import count_targets
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny("mlp_downsample")
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, 8).items()}
+    px = synthetic.make_pixels(cfg, 2, 8).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(8)
+    ids = torch.randint(0, 900, (2, 12), generator=g); ids[:, 0] = cfg.image_token_id
+    labels = torch.randint(0, 900, (2, 12), generator=g); labels[:, :5] = -100
+    mask = torch.ones(2, 12, dtype=torch.bool); mask[1, 10:] = False
+    n_items = count_targets(ids, labels, mask, cfg.image_token_id)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    ref = O.vlm_sft_loss([p.float() for p in px], ids, labels, mask, wr, cfg, num_items_in_batch=n_items, packed=True)
+    ref.backward()
+
+    model = build_model(cfg, weights=w)
+    model.enable_autograd(use_c_abi=use_c)
+    model.train()
+    inputs = dict(input_ids=ids, media={"image": [p.cuda() for p in px]}, labels=labels, attention_mask=mask, num_items_in_batch=n_items)
+    params = {}
+    for prefix, mod in (("llm.", model.llm), ("vision_tower.", model.vision_tower), ("mm_projector.", model.mm_projector)):
+        params.update({prefix + n: p for n, p in mod.named_parameters()})
+    assert all(p.requires_grad and p.grad is None for p in params.values())
+    loss = model(**inputs).loss                                   # the reference's compute_loss
+    assert loss.requires_grad and abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref))
+    loss.backward()                                               # accelerator.backward(loss)
+    worst = 1.0
+    for name, gref in ((k, v.grad) for k, v in wr.items()):
+        got = params[name].grad
+        assert got is not None and got.shape == params[name].shape, name
+        if float(gref.norm()) < 1e-6:
+            continue
+        cos = float(F.cosine_similarity(got.float().cpu().flatten(), gref.flatten(), dim=0))
+        worst = min(worst, cos)
+        assert cos >= 0.99, (name, cos)
+    # gradient accumulation: a second micro-batch adds to .grad (same batch -> doubled, up to bf16 rounding of the sum)
+    g1 = {n: p.grad.float().clone() for n, p in params.items()}
+    (model(**inputs).loss * 0.5).backward()                       # upstream scaling (loss / gradient_accumulation_steps) reaches the grads
+    name = "llm.model.layers.0.mlp.down_proj.weight"
+    assert rel_l2(params[name].grad, 1.5 * g1[name]) < 1e-2
+    # a torch optimizer works on the parameters; the HIP path sees the update (parameters are views of the flat buffer)
+    opt = torch.optim.SGD(list(params.values()), lr=1e-2)
+    before = float(model(**inputs).loss)
+    opt.step()
+    model.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in params.values())
+    after = model(**inputs).loss
+    assert float(after) < before
+    after.backward()
+    assert rel_l2(params[name].grad, g1[name]) > 1e-3             # fresh gradients of the UPDATED weights, not stale ones
+    model.eval()
+    with torch.no_grad():
+        out = model(**inputs)                                     # eval mode: the inference forward (no autograd)
+    assert out.loss is not None and not out.loss.requires_grad
+    print(f"autograd seam ({'one C-ABI call' if use_c else 'python-orchestrated'}): loss {float(loss):.5f} vs oracle {float(ref):.5f}, worst cosine {worst:.4f}")

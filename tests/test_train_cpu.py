@@ -136,3 +136,99 @@ def test_optimizer_state_roundtrip_and_master_resync(tmp_path):
     for a, b in ((tr.flat.master, tr2.flat.master), (tr.flat.m, tr2.flat.m), (tr.flat.v, tr2.flat.v)):
         assert torch.equal(a, b)
     assert torch.equal(tr2.flat.params, tr.flat.master.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the data-parallel STEP on two gloo ranks: global token count, loss scaling, bucket exchange, identical masters
+# ---------------------------------------------------------------------------------------------------------------------
+def _adamw_reference(master, m, v, grad, param, lr, b1, b2, eps, wd, step, grad_scale=1.0, lean=False):
+    """torch restatement of vila_adamw_step (TEST CODE standing in for the HIP kernel on a CPU-only host): decoupled weight decay,
+    bias-corrected moments, fp32 master, bf16 parameter = rounding of the master."""
+    g = grad.float() * grad_scale
+    master.mul_(1.0 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = (v / (1.0 - b2 ** step)).sqrt_().add_(eps)
+    master.addcdiv_(m / (1.0 - b1 ** step), denom, value=-lr)
+    param.copy_(master.to(param.dtype))
+
+
+def _dp_step_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vila_amd import ops
+        from vila_amd.train import SFTTrainer
+        torch.manual_seed(0)
+        m = _tiny_model()                                    # same weights on every rank (same seed)
+        ops.adamw_step = _adamw_reference                    # no GPU here: the optimizer kernel is replaced by its torch restatement
+        tr = SFTTrainer(m, lr=1e-2, weight_decay=0.01)
+        tr.flat.grads = tr.flat.grads.float()                # gloo has no bf16 sum on every build; the logic is dtype-agnostic
+        cfg = m.cfg
+        # every rank has a different batch: different target counts (rank 0: 5 targets, rank 1: 9)
+        g = torch.Generator().manual_seed(50 + rank)
+        L = 12
+        ids = torch.randint(0, 900, (2, L), generator=g); ids[:, 0] = cfg.image_token_id
+        labels = torch.randint(0, 900, (2, L), generator=g); labels[:, : (9 if rank == 0 else 7)] = -100
+        local_ce_sum = 3.0 + rank                            # stands in for this rank's sum of token cross-entropies
+        order = _bucket_order(cfg)[1:] if cfg.llm.tie_word_embeddings else _bucket_order(cfg)
+        seen = {}
+
+        def fake_forward_backward(input_ids, images, lab, mask=None, num_items_in_batch=None, block_sizes=None):
+            """What the HIP forward+backward does, minus the math: gradients of (local sum CE) / GLOBAL count into the flat buffer,
+            every bucket announced in backward order, the exchange finished before returning, local loss = local sum / global count."""
+            seen["n_global"] = num_items_in_batch
+            tr._touched = []
+            tr.reducer.log.clear()
+            gg = torch.Generator().manual_seed(200 + rank)
+            tr.flat.grads.copy_(torch.randn(tr.flat.numel, generator=gg) * (1.0 / num_items_in_batch))
+            for pre in order:
+                tr._ready(pre)
+            tr.reducer.wait()
+            return torch.tensor(local_ce_sum / num_items_in_batch)
+        tr.forward_backward = fake_forward_backward
+        from vila_amd.train import count_targets
+        n_local = count_targets(ids, labels, None, cfg.image_token_id)
+        loss = tr.step(ids, [], labels)
+        # reference: what one process holding BOTH batches would do (sum of the rank gradients, one AdamW step per touched bucket)
+        n_all = [2 * (L - 9), 2 * (L - 7)]
+        want_global = sum(n_all)
+        ref_m = _tiny_model_seeded()
+        from vila_amd.train import FlatParams
+        rf = FlatParams(ref_m, with_optimizer_state=True)
+        gsum = sum(torch.randn(rf.numel, generator=torch.Generator().manual_seed(200 + r)) * (1.0 / want_global) for r in range(world))
+        for pre in order:
+            a, b = rf.span(pre)
+            _adamw_reference(rf.master[a:b], rf.m[a:b], rf.v[a:b], gsum[a:b], rf.params[a:b], 1e-2, 0.9, 0.999, 1e-8, 0.01, 1)
+        same_as_ref = torch.allclose(tr.flat.master, rf.master, atol=1e-6, rtol=1e-5)
+        import hashlib
+        digest = hashlib.sha256(tr.flat.master.numpy().tobytes()).hexdigest()     # (a tensor in the queue would need the sender to stay alive)
+        q.put((rank, n_local, seen["n_global"], want_global, float(loss), digest, bool(same_as_ref), len(tr.reducer.log)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _tiny_model_seeded():
+    torch.manual_seed(0)
+    return _tiny_model()
+
+
+def test_dp_step_gloo_world2_global_count_loss_scaling_and_identical_masters():
+    """the whole data-parallel step around the (stubbed) forward+backward on two gloo ranks —
+    `global_num_items` sums the per-rank target counts (transformer_normalize_monkey_patch.py:261-263), each rank's loss is its
+    sum CE / GLOBAL count so that the SUM over ranks is the global mean (:242-247), every bucket is exchanged, and after the optimizer
+    step both ranks hold bit-identical fp32 masters equal to what a single process with both batches computes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    (r0, n0, g0, want, l0, m0, ok0, nb0), (r1, n1, g1, _, l1, m1, ok1, nb1) = res
+    assert n0 != n1 and g0 == g1 == n0 + n1 == want, (n0, n1, g0, g1, want)
+    assert abs((l0 + l1) - (3.0 + 4.0) / want) < 1e-6                      # sum over ranks of (local sum / global count) = global mean CE
+    assert m0 == m1, "the two ranks' masters differ (bitwise) after one data-parallel step"
+    assert ok0 and ok1 and nb0 == nb1 > 0

@@ -335,6 +335,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the immediate");
 }
 
+// max over lane l and lane l ^ 16 (resp. l ^ 32) without the LDS crossbar: gfx950's row swaps.  v_permlane16_swap exchanges the odd
+// 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
+// of the second; fed the same value twice, the two results hold (x[l], x[l ^ 16]) resp. (x[l], x[l ^ 32]) in some order for every lane.
+__device__ __forceinline__ float xor16_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // retire `cnt` fragments (two 8-B halves each) of a P.V group: wait until at most N younger LDS reads are outstanding, registers tied
 template <int N, int cnt> __device__ __forceinline__ void pv_retire(u32x2 (&v)[4][2]) {
     if constexpr (cnt == 4) lds_wait<N>(v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]);
@@ -479,28 +493,50 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // everyone's pieces of tile t are in; everyone is done with tile t-1
         asm volatile("" ::: "memory");
-        if (t + NST - 1 < ntiles) issue_tile(t + NST - 1);  // into the stage tile t-1 was read from
         const int key0 = t * KT;
-        if (!wave_has_rows || (CAUSAL && key0 > qw_last)) continue;     // nothing of this tile is visible to this wave's rows
+        const bool active = wave_has_rows && !(CAUSAL && key0 > qw_last);   // else nothing of this tile is visible to this wave's rows
         const char* cK = smem + (t % NST) * C::STAGE;
         v_lds = lds_addr(cK + C::IMG);
 
         // ---- S^T = K Q^T ----
         f32x4 sacc[4][QF];
+        if (active) {
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+            for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-            for (int f = 0; f < QF; ++f) sacc[jn][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < QF; ++f) sacc[jn][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (TIGHT) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
+                for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
-                const bf16x8 kf = *(const bf16x8*)(cK + jn * 16 * ROWB + koff[kk]);
+                    for (int jn = 0; jn < 4; ++jn) {
+                        const bf16x8 kf = *(const bf16x8*)(cK + jn * 16 * ROWB + koff[kk]);
 #pragma unroll
-                for (int f = 0; f < QF; ++f)
-                    sacc[jn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf_[f][kk], sacc[jn][f], 0, 0, 0);
+                        for (int f = 0; f < QF; ++f)
+                            sacc[jn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf_[f][kk], sacc[jn][f], 0, 0, 0);
+                    }
+                }
+            } else {
+                // every K fragment of the tile is requested first (48-64 registers), then the MFMAs retire them in order: ONE LDS
+                // round trip on the tile's critical path instead of one per group of reads
+                bf16x8 kf[KK][4];
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) kf[kk][jn] = *(const bf16x8*)(cK + jn * 16 * ROWB + koff[kk]);
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                        for (int f = 0; f < QF; ++f)
+                            sacc[jn][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk][jn], qf_[f][kk], sacc[jn][f], 0, 0, 0);
             }
         }
+        // the refill of the stage tile t-1 was read from is issued BEHIND the MFMAs of this tile (the matrix pipe works through them
+        // while the wave spends its 100-180 issue cycles per DMA instruction), not in front of them on the tile's critical path
+        if (t + NST - 1 < ntiles) issue_tile(t + NST - 1);
+        if (!active) continue;
 
         // ---- mask (sequence end / causal diagonal) ----
         const bool need_mask = (key0 + KT > seqlen) || (CAUSAL && (key0 + KT - 1 > qw0));
@@ -530,8 +566,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
             for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[jn][f][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor16_max(mx);                              // v_permlane16_swap / v_permlane32_swap: no LDS round trips
+            mx = xor32_max(mx);
             const float m_new = fmaxf(m_run[f], mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run[f] - m_new) * c);   // raw v_exp_f32: arguments are <= 0
             const float mc = m_new * c;

@@ -213,10 +213,32 @@ class HipLlavaLlamaModel(nn.Module):
             ops.copy_rows(flat, out, None if plan.img_src_identity else plan.img_src.to(dev), plan.img_dst.to(dev), int(plan.img_dst.numel()))
         return out.view(B, S, H), plan.labels.to(dev), plan.mask.to(dev)
 
-    # llava_llama.py:94-159 (inference/eval form: loss without autograd; SFT fwd+bwd lives in vila_amd.train)
-    @torch.no_grad()
+    def enable_autograd(self, use_c_abi: Optional[bool] = None, group=None):
+        """Make the reference's own training call site work after the swap (llava/train/transformer_normalize_monkey_patch.py
+        :183-249: `loss = model(**inputs).loss` ... `accelerator.backward(loss)`): every parameter gets requires_grad, and in training
+        mode `forward(labels=...)` returns a loss that is attached to the autograd graph — its backward deposits the gradients the HIP
+        step computed into `.grad` (accumulating), so `loss.backward()`, gradient accumulation, `optimizer.step()` of any torch optimizer
+        and `zero_grad()` behave as with the reference's modules.  Parameters move into one flat buffer (vila_amd.train.FlatParams)."""
+        from .train import AutogradSeam
+        self._seam = AutogradSeam(self, use_c_abi=use_c_abi, group=group)
+        return self._seam
+
+    # llava_llama.py:94-159.  Inference / eval: loss without autograd.  Training mode with enable_autograd(): the SFT step behind autograd.
     def forward(self, input_ids=None, media=None, media_config=None, attention_mask=None, labels=None, packing: bool = True,
                 inputs_embeds=None, num_items_in_batch=None, **kw):
+        seam = getattr(self, "_seam", None)
+        if seam is not None and self.training and labels is not None and inputs_embeds is None and torch.is_grad_enabled():
+            if any(k != "image" and len(v) for k, v in (media or {}).items()):
+                raise NotImplementedError("training through the autograd seam takes image media (video frames train as images upstream)")
+            images = list((media or {}).get("image", []))
+            blocks = ((media_config or {}).get("image", {}) or {}).get("block_sizes")
+            from .modules import CausalLMOutput
+            return CausalLMOutput(loss=seam.loss(input_ids, images, labels, attention_mask, num_items_in_batch, blocks), logits=None,
+                                  past_key_values=None)
+        with torch.no_grad():
+            return self._forward_eval(input_ids, media, media_config, attention_mask, labels, inputs_embeds, num_items_in_batch)
+
+    def _forward_eval(self, input_ids, media, media_config, attention_mask, labels, inputs_embeds, num_items_in_batch):
         if inputs_embeds is None:
             # the reference truncates to tokenizer.model_max_length only in training mode (llava_arch.py:522)
             cut = getattr(self.tokenizer, "model_max_length", None) if (self.training and labels is not None) else None
