@@ -82,7 +82,9 @@ def test_chat_completions_endpoint_on_the_hip_model(served):
     Image.fromarray(arr).save(buf, format="PNG")
     url = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
     client = TestClient(serving.create_app(model, tok, model_name="NVILA-tiny"))
-    body = {"model": "NVILA-tiny", "max_tokens": 5,
+    # temperature 0 = greedy (do_sample = temperature > 0, server.py:185-187); a request WITHOUT the field samples at the reference's
+    # default temperature 0.2 / top_p 0.9 (server.py:101-102) — checked below
+    body = {"model": "NVILA-tiny", "max_tokens": 5, "temperature": 0.0,
             "messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": "describe the image"}]}]}
     r = client.post("/chat/completions", json=body)
     assert r.status_code == 200, r.text
@@ -93,6 +95,8 @@ def test_chat_completions_endpoint_on_the_hip_model(served):
     events = [l for l in r.text.split("\n\n") if l]
     assert events[-1] == "data: [DONE]"
     assert "".join(json.loads(ev[6:])["choices"][0]["delta"]["content"] for ev in events[:-1]).strip() == text
+    sampled = client.post("/chat/completions", json={k: v for k, v in body.items() if k != "temperature"})
+    assert sampled.status_code == 200 and isinstance(sampled.json()["choices"][0]["message"]["content"][0]["text"], str)
     # text-only request and a second image in one request also go through the HIP path
     r = client.post("/chat/completions", json={"model": "NVILA-tiny", "max_tokens": 3, "messages": [{"role": "user", "content": "what is this ?"}]})
     assert r.status_code == 200 and isinstance(r.json()["choices"][0]["message"]["content"][0]["text"], str)

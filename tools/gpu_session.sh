@@ -9,6 +9,10 @@ case $step in
   gemm_bwd)  timeout 300 tools/gemm_bench bwd > "$O/gemm_bench_bwd.log" 2>&1; tail -40 "$O/gemm_bench_bwd.log" ;;
   gemm_fwd)  timeout 300 tools/gemm_bench fwd > "$O/gemm_bench_fwd.log" 2>&1; tail -30 "$O/gemm_bench_fwd.log" ;;
   tests)     timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > "$O/pytest.log"; tail -30 "$O/pytest.log" ;;
+  tests_all) timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -40 > "$O/pytest_all.log"; tail -40 "$O/pytest_all.log" ;;
+  tests_rest) timeout 1500 python -m pytest tests/test_gpu_serving.py tests/test_gpu_train.py tests/test_gpu_w4.py tests/test_video_encoders.py tests/test_w8a8.py -m gpu -q 2>&1 | tail -40 > "$O/pytest_rest.log"; tail -40 "$O/pytest_rest.log" ;;
+  attn_bwd)  VILA_ATTN_BWD=v1 timeout 300 python tools/microbench.py attn_bwd > "$O/attn_bwd_v1.log" 2>&1; timeout 300 python tools/microbench.py attn_bwd > "$O/attn_bwd_new.log" 2>&1
+             paste -d'\n' "$O/attn_bwd_v1.log" "$O/attn_bwd_new.log" ;;
   tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
   tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;
   attn)      VILA_ATTN_FWD=v1 timeout 300 python tools/microbench.py attn > "$O/attn_v1.log" 2>&1; timeout 300 python tools/microbench.py attn > "$O/attn_new.log" 2>&1

@@ -117,6 +117,21 @@ def bench_attn():
         print(f"T={T:6d} Hq={Hq} Hkv={Hkv} D={D} causal={causal} nseq={nseq}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
 
 
+def bench_attn_bwd():
+    print("== attention bwd: delta + dQ + dK/dV (TFLOP/s, 10*T*T*D*H per sequence (x0.5 causal)) ==")
+    for n, nseq, Hq, Hkv, D, causal in [(769, 4, 28, 4, 128, True), (1024, 4, 16, 16, 72, False), (1024, 64, 16, 16, 72, False), (4096, 1, 28, 4, 128, True)]:
+        T = n * nseq
+        q, k, v, do = rnd(T, Hq, D), rnd(T, Hkv, D), rnd(T, Hkv, D), rnd(T, Hq, D)
+        cu = torch.arange(0, T + 1, n, dtype=torch.int32, device="cuda")
+        kw = dict(cu_seqlens=cu, max_seqlen=n) if causal else dict(n_seq=nseq)
+        o, lse = ops.attn_fwd(q, k, v, causal, return_lse=True, **kw)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        t = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, causal, dq, dk, dv, **kw), iters=10)
+        tf = timeit(lambda: ops.attn_fwd(q, k, v, causal, return_lse=True, **kw), iters=10)
+        fl = 10.0 * n * n * D * Hq * nseq * (0.5 if causal else 1.0)
+        print(f"n={n:5d} x{nseq:3d} Hq={Hq} Hkv={Hkv} D={D} causal={causal}: bwd {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s   (fwd {tf*1e6:8.1f} us  {0.4*fl/tf/1e12:7.1f} TF/s)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
@@ -132,3 +147,5 @@ if __name__ == "__main__":
         bench_w4()
     if what in ("attn", "all"):
         bench_attn()
+    if what in ("attn_bwd", "all"):
+        bench_attn_bwd()

@@ -13,10 +13,8 @@
 // Block = 4 waves x 32 query rows; KV tile = 64 keys, double-buffered in LDS, one barrier per tile.
 #include <stdlib.h>
 #include "kernels.h"
+#include "attn_common.h"
 
-#define NEG_BIG (-1.0e30f)
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
-typedef __attribute__((address_space(3))) bf16x4v lds_bf16x4;
 
 template <int HD, int QF, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_v1_kernel(AttnArgs p) {
@@ -288,67 +286,6 @@ static int launch_attn_v1_t(const AttnArgs& a, hipStream_t s) {
 //     heaviest (last query block) first;
 //   * P is packed with v_cvt_pk_bf16_f32; O is staged through LDS and stored as whole 16-B row chunks.
 // =================================================================================================================================
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-template <int HD> struct AttnDma {
-    static constexpr int CH = HD / 8;                       // valid 16-B chunks per K / V row
-    static constexpr int CHP = (HD == 72) ? 10 : CH;        // chunks per LDS row
-    static constexpr int ROWB = CHP * 16;                   // LDS row bytes
-    static constexpr int KK = (HD + 31) / 32, DN = (HD + 15) / 16;
-    static constexpr int KT = 64;
-    static constexpr int IMG = KT * ROWB;                   // one K or V image
-    static constexpr int STAGE = 2 * IMG;
-    static constexpr int NST = (HD == 128) ? 4 : 6;
-    static constexpr int PW = 16 * CHP;                     // DMA slots (16 B) per wave and tile: 2 * 64 * CHP / 8 waves
-    static constexpr int P = (PW + 63) / 64;                // DMA instructions per wave and tile (the last one may be partial)
-    static constexpr int OSTR = HD + 8;                     // O staging row stride (elements)
-    static_assert(HD == 64 || HD == 72 || HD == 128, "head dims of the path");
-    // position (16-B slot inside the LDS row) of chunk c of row r; an involution in c for fixed r
-    __device__ static __forceinline__ int swz_k(int r, int c) {
-        if (HD == 128) return c ^ (r & 15);
-        if (HD == 64) return c ^ ((r >> 1) & 7);
-        return c;
-    }
-    __device__ static __forceinline__ int swz_v(int r, int c) {
-        if (HD == 128) return (((c >> 1) ^ (r & 7)) << 1) | (c & 1);
-        if (HD == 64) return (((c >> 1) ^ ((r >> 1) & 3)) << 1) | (c & 1);
-        return c;
-    }
-};
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else static_assert(N < 0, "add the immediate");
-}
-
-// max over lane l and lane l ^ 16 (resp. l ^ 32) without the LDS crossbar: gfx950's row swaps.  v_permlane16_swap exchanges the odd
-// 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
-// of the second; fed the same value twice, the two results hold (x[l], x[l ^ 16]) resp. (x[l], x[l ^ 32]) in some order for every lane.
-__device__ __forceinline__ float xor16_max(float x) {
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xor32_max(float x) {
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-
 // retire `cnt` fragments (two 8-B halves each) of a P.V group: wait until at most N younger LDS reads are outstanding, registers tied
 template <int N, int cnt> __device__ __forceinline__ void pv_retire(u32x2 (&v)[4][2]) {
     if constexpr (cnt == 4) lds_wait<N>(v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]);
@@ -485,12 +422,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
 
     for (int t = 0; t < ntiles; ++t) {
         // tile t has landed once at most `ahead` younger tiles (P instructions each) are still in flight
-        const int ahead = (ntiles - 1 - t) < (NST - 2) ? (ntiles - 1 - t) : (NST - 2);
-        if (ahead >= NST - 2) wait_vmcnt<(NST - 2) * P>();
-        else if (NST > 3 && ahead == NST - 3) wait_vmcnt<(NST - 3) * P>();
-        else if (NST > 4 && ahead == NST - 4) wait_vmcnt<(NST > 4 ? (NST - 4) * P : 0)>();
-        else if (NST > 5 && ahead == NST - 5) wait_vmcnt<(NST > 5 ? (NST - 5) * P : 0)>();
-        else wait_vmcnt<0>();
+        wait_tiles_ahead<P, NST - 2>(ntiles - 1 - t);
         __builtin_amdgcn_s_barrier();                       // everyone's pieces of tile t are in; everyone is done with tile t-1
         asm volatile("" ::: "memory");
         const int key0 = t * KT;

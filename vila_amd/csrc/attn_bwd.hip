@@ -8,6 +8,7 @@
 //                query tiles: S = Q K^T, dP = dO V^T (A = Q, dO row-major from LDS; B = K, V fragments held in registers),
 //                P, dS in the C layout = B layout of  dV^T = dO^T . P,  dK^T = Q^T . dS  (A = transposed tiles from LDS)
 // P is recomputed from the saved log-sum-exp (natural log, fp32), as flash-attn does.
+#include <stdlib.h>
 #include "kernels.h"
 #include "train.h"
 
@@ -470,6 +471,17 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s, int parts) {
     VILA_REQUIRE(a.n_q_heads % a.n_kv_heads == 0, "attn_bwd: q heads must be a multiple of kv heads");
     VILA_REQUIRE(a.cu_seqlens != nullptr || (int64_t)a.n_seq * a.max_seqlen == a.total_tokens, "attn_bwd: uniform batches need total = n_seq*max_seqlen");
     VILA_REQUIRE(a.lse != nullptr && a.delta != nullptr, "attn_bwd: lse / delta workspace missing");
+    // VILA_ATTN_BWD=v1 keeps the round-1/2 dQ and dK / dV kernels of this file (A/B measurements); default: the DMA-ring kernels of
+    // attn_bwd_dma.hip for those two passes, delta from here
+    static int impl = -1;
+    if (impl < 0) { const char* e = getenv("VILA_ATTN_BWD"); impl = (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }
+    if (impl == 2 && (parts & 6)) {
+        if (parts & 1) {
+            hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.total_tokens * a.n_q_heads, 16)), dim3(256), 0, s, a);
+            VILA_LAUNCH_CHECK();
+        }
+        return launch_attn_bwd_dma(a, s, parts & 6);
+    }
     if (a.head_dim == 128) return a.causal ? launch_bwd_t<128, true>(a, s, parts) : launch_bwd_t<128, false>(a, s, parts);
     if (a.head_dim == 72) return a.causal ? launch_bwd_t<72, true>(a, s, parts) : launch_bwd_t<72, false>(a, s, parts);
     if (a.head_dim == 64) return a.causal ? launch_bwd_t<64, true>(a, s, parts) : launch_bwd_t<64, false>(a, s, parts);

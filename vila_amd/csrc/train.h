@@ -13,6 +13,7 @@ struct AttnBwdArgs {
     float* delta;         // [Hq][T] workspace
 };
 int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s, int parts = 7);   // parts: 1 delta | 2 dQ | 4 dK/dV
+int launch_attn_bwd_dma(const AttnBwdArgs& a, hipStream_t s, int parts);       // round-3 dQ / dK-dV kernels (attn_bwd_dma.hip)
 
 int launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, int64_t ldi, int64_t ldo, hipStream_t s);
 int launch_act_fwd(const bf16_t* z, bf16_t* y, int64_t n, int act, hipStream_t s);
