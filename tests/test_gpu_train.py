@@ -417,7 +417,8 @@ def test_autograd_seam_reference_training_call_site(use_c):
     for name, gref in ((k, v.grad) for k, v in wr.items()):
         got = params[name].grad
         assert got is not None and got.shape == params[name].shape, name
-        if float(gref.norm()) < 1e-6:
+        if gref is None or float(gref.norm()) < 1e-6:            # never reached by hidden_states[-2] (27th ViT layer, post_layernorm): zero here
+            assert float(got.float().norm()) < 1e-3, name
             continue
         cos = float(F.cosine_similarity(got.float().cpu().flatten(), gref.flatten(), dim=0))
         worst = min(worst, cos)

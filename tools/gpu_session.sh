@@ -13,6 +13,9 @@ case $step in
   tests_rest) timeout 1500 python -m pytest tests/test_gpu_serving.py tests/test_gpu_train.py tests/test_gpu_w4.py tests/test_video_encoders.py tests/test_w8a8.py -m gpu -q 2>&1 | tail -40 > "$O/pytest_rest.log"; tail -40 "$O/pytest_rest.log" ;;
   attn_bwd)  VILA_ATTN_BWD=v1 timeout 300 python tools/microbench.py attn_bwd > "$O/attn_bwd_v1.log" 2>&1; timeout 300 python tools/microbench.py attn_bwd > "$O/attn_bwd_new.log" 2>&1
              paste -d'\n' "$O/attn_bwd_v1.log" "$O/attn_bwd_new.log" ;;
+  decode_warm) for mb in 0 64 128 192 270; do VILA_DECODE_WARM_MB=$mb timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 64 --warmup 8 > "$O/warm_$mb.json" 2> "$O/warm_$mb.err"; python -c "
+import json; d=json.loads(open('$O/warm_$mb.json').read().strip().splitlines()[-1]); print('warm MB $mb: value', d['value'], 'ms/step', d['ms_per_step'])" || tail -3 "$O/warm_$mb.err"; done ;;
+  seam)      timeout 600 python -m pytest tests/test_gpu_train.py -m gpu -q -k "seam or per_bucket" 2>&1 | tail -8 ;;
   tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
   tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;
   attn)      VILA_ATTN_FWD=v1 timeout 300 python tools/microbench.py attn > "$O/attn_v1.log" 2>&1; timeout 300 python tools/microbench.py attn > "$O/attn_new.log" 2>&1
