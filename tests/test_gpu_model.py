@@ -231,10 +231,10 @@ def test_wide_llm_prefill_and_decode(wide):
     assert torch.equal(out[0].cpu()[decisive], ids_o[decisive])
 
 
-@pytest.mark.parametrize("S", [257, 260])
+@pytest.mark.parametrize("S", [257, 260, 272])
 def test_wide_llm_prefill_tail_rows_via_gemv(wide, S):
-    """S = k * 256 + (1..4): the MLP of the leftover rows runs through the decode GEMV kernels, the rest through the GEMMs — every row
-    must still match the oracle, the tail rows included."""
+    """S = k * 256 + (1..16): the leftover rows of the MLP GEMMs ride in the last 256-row tile as an extra fragment (round 3; rounds 1 / 2:
+    through the decode GEMV kernels, still the path under VILA_GEMM_EX=0) — every row must match the oracle, the leftover rows included."""
     cfg, w, model = wide
     g = torch.Generator().manual_seed(S)
     e = (torch.randn(1, S, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16)

@@ -403,3 +403,47 @@ def test_gemm_whole_rounds_plus_sliced_tail_tiles(ops):
     r2 = randn_bf16(4300, 4096, seed=48)
     dx = ops.gemm_t(dyy, ww, b_cm=True, residual=r2, ws=ws)
     assert rel_l2(dx, dyy.float() @ ww.float() + r2.float()) < 4e-3
+
+
+@pytest.mark.parametrize("M", [257, 260, 272, 769, 3076])
+def test_gemm256_leftover_rows_ride_in_the_last_row_tile(ops, M):
+    """M = 256 k + r, 1 <= r <= 16: the last 256-row tile carries the r rows as an extra 16-row fragment (gemm256_kernel.h, EX) in every
+    mode that can meet such a shape on the path: plain / bias / residual / GELU / fp32 out, fused gate/up (whole rounds + K-sliced tail
+    round), split-K slabs.  Every row — the leftover ones separately — against the fp32 reference; and equal to the policy-off result."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    K, N = 1024, 3584
+    a = randn_bf16(M, K, seed=71)
+    w, w2 = randn_bf16(N, K, seed=72, scale=K ** -0.5), randn_bf16(N, K, seed=73, scale=K ** -0.5)
+    bias, res = randn_bf16(N, seed=74), randn_bf16(M, N, seed=75)
+    ref = a.float() @ w.float().t()
+    lo = (M // 256) * 256
+    lib.vila_gemm_force_tile(4)                                    # pin the 256x256 kernel (the dispatcher would take other tiles for small M)
+    try:
+        for name, out, want, tol in (
+                ("plain+bias+res", ops.gemm(a, w, bias=bias, residual=res), ref + bias.float() + res.float(), 4e-3),
+                ("gelu", ops.gemm(a, w, bias=bias, epi=1), torch.nn.functional.gelu(ref + bias.float(), approximate="tanh"), 5e-3),
+                ("fp32", ops.gemm(a, w, out_f32=True), ref, 2e-5)):
+            assert rel_l2(out, want) < tol, f"{name}: rel={rel_l2(out, want):.3e}"
+            assert rel_l2(out[lo:], want[lo:]) < tol, f"{name}: leftover rows rel={rel_l2(out[lo:], want[lo:]):.3e}"
+            assert rel_l2(out[lo - 16:lo], want[lo - 16:lo]) < tol
+    finally:
+        lib.vila_gemm_force_tile(0)
+    # fused gate/up (N = 18944: whole rounds + tail round split over K with a workspace) and the split-K slabs (K = 18944)
+    F = 18944
+    wg, wu = randn_bf16(F, K, seed=76, scale=K ** -0.5), randn_bf16(F, K, seed=77, scale=K ** -0.5)
+    ws = torch.empty(8 * M * 4608, device="cuda", dtype=torch.float32)
+    g = a.float() @ wg.float().t()
+    want = torch.nn.functional.silu(g) * (a.float() @ wu.float().t())
+    lib.vila_gemm_force_tile(4)
+    try:
+        for kw in (dict(), dict(ws=ws)):
+            out = ops.gemm(a, wg, w2=wu, epi=3, **kw)
+            assert rel_l2(out, want) < 6e-3 and rel_l2(out[lo:], want[lo:]) < 6e-3, f"gate/up {list(kw)}: {rel_l2(out, want):.3e} / {rel_l2(out[lo:], want[lo:]):.3e}"
+    finally:
+        lib.vila_gemm_force_tile(0)
+    if M >= 512:
+        a2, wd = randn_bf16(M, F, seed=78, scale=0.5), randn_bf16(N, F, seed=79, scale=F ** -0.5)
+        want = a2.float() @ wd.float().t() + res.float()
+        out = ops.gemm(a2, wd, residual=res, ws=ws)                # under-filled grid + workspace -> K-sliced slabs + reduce
+        assert rel_l2(out, want) < 4e-3 and rel_l2(out[lo:], want[lo:]) < 4e-3, f"split-K: {rel_l2(out, want):.3e} / {rel_l2(out[lo:], want[lo:]):.3e}"

@@ -16,6 +16,8 @@ void vila_set_error(const char* fmt, ...) {
 extern "C" const char* vila_last_error(void) { return g_err; }
 extern "C" int vila_abi_version(void) { return 1; }
 
+int gemm256_tiles_m_of(int M);      // gemm256.hip
+
 namespace {
 struct Arena {
     char* base; size_t size, off;
@@ -278,7 +280,10 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     // only last-row logits wanted (generation): the last layer is finished for those rows alone (see below)
     const bool prune_last = final_hidden == nullptr && all_logits == nullptr && taps == nullptr && cache != nullptr && last_logits != nullptr &&
                             last_rows != nullptr && n_last >= 1 && n_last <= 4 && H % 8 == 0 && F % 8 == 0 && QS == H;
-    const int tail_rows = (T > 256 && T % 256 >= 1 && T % 256 <= 4 && H % 8 == 0 && F % 8 == 0) ? T % 256 : 0;
+    // 1..16 leftover rows (T = 256 k + r) ride in the last row tile of the 256^2 GEMMs as an extra fragment (gemm256_kernel.h, EX); only when
+    // that policy is switched off (VILA_GEMM_EX=0) do 1..4 leftover rows of the MLP go through the decode GEMVs as in rounds 1 / 2
+    const bool ex_rows = gemm256_tiles_m_of(T) < cdiv(T, 256);
+    const int tail_rows = (!ex_rows && T > 256 && T % 256 >= 1 && T % 256 <= 4 && H % 8 == 0 && F % 8 == 0) ? T % 256 : 0;
     const int Tg = T - tail_rows;     // rows of the gate/up and down GEMMs; the rest via GEMV
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];

@@ -206,6 +206,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 }
 
 bool gemm256_supported(const GemmArgs& a);
+int gemm256_tiles_m_of(int M);        // 256-row tiles under the extra-row-fragment policy (gemm256_kernel.h: M = 256 k + r, r <= 16 -> k tiles)
 int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
 bool gemm_ring_supported(const GemmArgs& a);
@@ -219,7 +220,7 @@ extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 template <int EPI, bool OUT_F32>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
     int sel = g_force_tile;
-    const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, (EPI == EPI_GATEUP) ? 128 : 256);
+    const int64_t tiles256 = (int64_t)gemm256_tiles_m_of(a.M) * cdiv(a.N, (EPI == EPI_GATEUP) ? 128 : 256);
     if (sel == 4 || (sel == 0 && tiles256 >= 150)) {
         if (gemm256_supported(a)) return launch_gemm256(a, s);
         if (sel == 4) sel = 0;

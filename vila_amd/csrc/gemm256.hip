@@ -140,6 +140,8 @@ static int try_hybrid(const GemmArgs& a, hipStream_t s) {
     return 1;
 }
 
+int gemm256_tiles_m_of(int M) { return gemm256_tiles_m(M); }       // for the dispatcher in gemm.hip
+
 bool gemm256_supported(const GemmArgs& a) {
     if (a.a_cm && (a.M % 8 != 0 || a.lda % 8 != 0)) return false;
     if (a.b_cm && (a.N % 8 != 0 || a.ldw % 8 != 0)) return false;
@@ -153,7 +155,8 @@ bool gemm256_supported(const GemmArgs& a) {
 // Gate/up with an under-filled LAST round (S = 769: 592 tiles = 2 full rounds of 256 + 80): the full rounds run fused as usual, the
 // tail tiles are sliced over K so the last round costs 1/splits of a tile time; raw gate / up sums meet in a small reduce kernel.
 static int launch_gateup(const GemmArgs& a, hipStream_t s) {
-    const int tiles_m = cdiv(a.M, 256), tiles_n = cdiv(a.N, 128), kt = cdiv(a.K, T256_BK);
+    const bool ex = gemm256_ex_rows(a.M) != 0;              // 1..16 leftover rows ride in the last row tile (EX kernels)
+    const int tiles_m = gemm256_tiles_m(a.M), tiles_n = cdiv(a.N, 128), kt = cdiv(a.K, T256_BK);
     const int slots = 256;                                   // one 512-thread block per CU
     const int full_tn = ((tiles_m * tiles_n) / slots) * slots / tiles_m;     // tile columns covered by whole rounds
     const int tail_tn = tiles_n - full_tn, tail_tiles = tail_tn * tiles_m;
@@ -164,10 +167,10 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
         splits = cdiv(kt, per);
         const int tc = tail_tn * 128 < a.N - full_tn * 128 ? tail_tn * 128 : a.N - full_tn * 128;      // output columns of the tail
         if (splits >= 2 && (size_t)splits * 2 * a.M * tc * 4 <= a.ws_bytes && tc % 4 == 0) {
-            VILA_TRY((launch256_t<2, EPI_NONE, false, false, T256_CC_SCHED>(a, s, 1, 0, full_tn * tiles_m)));
+            VILA_TRY((launch256_fwd<2, EPI_NONE>(a, s, ex, 1, 0, full_tn * tiles_m)));
             GemmArgs b = a;
             b.C = a.ws; b.ldc = tc;
-            VILA_TRY((launch256_t<4, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, full_tn * tiles_m, tail_tiles, full_tn * 128, per)));
+            VILA_TRY((launch256_fwd<4, EPI_NONE>(b, s, ex, splits, full_tn * tiles_m, tail_tiles, full_tn * 128, per)));
             const int64_t total = (int64_t)a.M * (tc / 4);
             const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             hipLaunchKernelGGL(splitk_gu_reduce_kernel, dim3(grid), dim3(256), 0, s, a.ws, splits, (bf16_t*)a.C, a.ldc, a.M, tc, full_tn * 128);
@@ -175,7 +178,7 @@ static int launch_gateup(const GemmArgs& a, hipStream_t s) {
             return 0;
         }
     }
-    return launch256_t<2, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
+    return launch256_fwd<2, EPI_NONE>(a, s, ex);
 }
 
 int launch_gemm256(const GemmArgs& a, hipStream_t s) {
@@ -186,13 +189,17 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
     if (a.a_cm || a.b_cm) return launch_gemm256_cm(a, s);
     if (g_gemm256_sched != 0 && a.epi == EPI_NONE && !a.out_f32) return launch_gemm256_sched(a, g_gemm256_sched, s);
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
-    if (a.out_f32) return launch256_t<1, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
+    const bool ex = gemm256_ex_rows(a.M) != 0;
+    if (a.out_f32) return launch256_fwd<1, EPI_NONE>(a, s, ex);
     switch (a.epi) {
         case EPI_NONE:
+            // (a shape with leftover rows takes the EX kernel when that saves a whole round of tiles over the best other tiling)
+            if (ex && cdiv(gemm256_tiles_m(a.M) * cdiv(a.N, 256), 256) < cdiv(cdiv(a.M, 256) * cdiv(a.N, 256), 256) &&
+                !prefer_bm192(a.M, a.N, g_gemm256_bm)) return launch256_fwd<0, EPI_NONE>(a, s, true);
             if (prefer_bm192(a.M, a.N, g_gemm256_bm)) return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED, 192>(a, s);
-            return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s);
-        case EPI_GELU_TANH: return launch256_t<0, EPI_GELU_TANH, false, false, T256_CC_SCHED>(a, s);
-        case EPI_GELU_ERF: return launch256_t<0, EPI_GELU_ERF, false, false, T256_CC_SCHED>(a, s);
+            return launch256_fwd<0, EPI_NONE>(a, s, ex);
+        case EPI_GELU_TANH: return launch256_fwd<0, EPI_GELU_TANH>(a, s, ex);
+        case EPI_GELU_ERF: return launch256_fwd<0, EPI_GELU_ERF>(a, s, ex);
     }
     VILA_FAIL(-1, "gemm256: unsupported epilogue %d", a.epi);
 }
@@ -205,7 +212,7 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
     GemmArgs b = a;
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
     if (a.a_cm || a.b_cm) VILA_TRY(launch_gemm256_cm_splitk(b, splits, slab, per, s));
-    else VILA_TRY((launch256_t<3, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, 0, -1, 0, per)));      // the last slice takes the remainder
+    else VILA_TRY((launch256_fwd<3, EPI_NONE>(b, s, gemm256_ex_rows(a.M) != 0, splits, 0, -1, 0, per)));      // the last slice takes the remainder
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,

@@ -24,6 +24,7 @@
 //   7  role split with TWO phases of 32 MFMAs per K-tile (4 barriers): the default
 //   9  ablation: schedule 0 without any DMA inside the loop (wrong results; bounds what hiding the loads completely would buy)
 #pragma once
+#include <stdlib.h>
 #include "kernels.h"
 
 #define T256_BK 64
@@ -46,9 +47,15 @@ static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   /
 // half-tile slots (rows 96..127 of a half are loaded and not used), each wave owns 96 rows = 6 A fragments.  Measured: the K-loop's pace
 // is set by its barrier intervals more than by its MFMA count, so 3/4 of the MFMAs buy 2-9 % (o_proj 92 -> 84 us, down_proj 424 -> 417 us),
 // not 25 %; used for the forward layout only.
-template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256>
+// EX ("ninth A fragment", round 3): M = 256 k + r with 1 <= r <= 16 is tiled as k row tiles, and the LAST row tile carries the r leftover
+// rows as a 17th 16-row fragment: its blocks stage 16 more A rows per K-tile (2 KB, one extra LDS-DMA instruction on waves 0 and 1) and every
+// wave spends 4 more MFMAs per K-tile on two of its four B fragments (wave row wr takes fragments wr and wr + 2, so the fused gate/up
+// pairing stays inside a wave).  The prompt of the benchmark is 3 x 256 + 1 tokens: without this, one row costs either a fourth row-tile
+// round or a second pass over the MLP weights through the decode GEMVs (round 1/2: 1.9 ms of an 18.4 ms TTFT).
+template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256, bool EX = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
     static_assert(BM == 256 || (BM == 192 && !ACM && (SCHED == 5 || SCHED == 6 || SCHED == 7) && MODE == 0), "192-row tiles: role-split schedules, forward-layout A");
+    static_assert(!EX || (!ACM && SCHED == 7 && BM == 256 && MODE != 5), "the extra row fragment: forward-layout A, default schedule, 256-row tiles");
     constexpr int NA = BM / 64;                        // A fragments per quadrant (4, or 3 with 192-row tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF_BYTES = 128 * 64 * 2;           // 16 KB
@@ -64,6 +71,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     const int tm = id % tiles_m, tn = id / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN_OUT;
     const int M = p.M, N = p.N;
+    const bool has9 = EX && (tm == tiles_m - 1) && (M > tiles_m * 256);        // block-uniform: this row tile carries rows m0 + 256 .. M - 1
+    constexpr int A9_BASE = 2 * 4 * 128 * 64 * 2;                               // behind the two K-tile buffers: 2 x [16 rows][64 k] bf16
 
     // ---- DMA source offsets ----
     // CC: thread's chunk c = tid + 512*i of a half-tile: row = c >> 3 (+64 i), LDS slot = c & 7 holds global k-chunk (c&7) ^ ((row>>1)&7)
@@ -126,11 +135,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
         char* dst = smem + buf * BUF_BYTES + lds_lane_base + ((is_b ? 2 : 0) + h) * HALF_BYTES + i * 8192;
         __builtin_amdgcn_global_load_lds((gbl_void*)piece_src(k0, is_b, h, i), (lds_void*)dst, 16, 0, 0);
     };
+    // the extra fragment's 16 rows x 64 k = 128 chunks: one DMA instruction on wave 0 and one on wave 1, same slot swizzle as a half-tile
+    uint32_t a9off = 0; int a9kch = 0;
+    if constexpr (EX) {
+        const int c9 = (wave & 1) * 64 + lane, row9 = c9 >> 3;
+        a9kch = (c9 & 7) ^ ((row9 >> 1) & 7);
+        int gm9 = m0 + 256 + row9; gm9 = gm9 < M ? gm9 : M - 1;
+        a9off = (uint32_t)gm9 * (uint32_t)p.lda + a9kch * 8;
+    }
+    const int a9_lane_base = __builtin_amdgcn_readfirstlane((wave & 1) * 1024);
+    auto issue_a9 = [&](int t, int buf) {
+        if constexpr (EX) {
+            if (has9 && wave < 2) {
+                const int k0 = (kt0 + t) * T256_BK;
+                const bf16_t* src = p.A + a9off + k0;
+                if (k0 + T256_BK > p.K) src = (k0 + a9kch * 8 < p.K) ? src : zero_src;
+                char* dst = smem + A9_BASE + buf * 2048 + a9_lane_base;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+            }
+        }
+    };
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) { issue_piece(t, buf, false, h, i); issue_piece(t, buf, true, h, i); }
+        issue_a9(t, buf);
     };
 
     // ---- fragment read offsets (bytes inside a half-tile) ----
@@ -148,6 +178,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc9[2];                                     // EX: the extra fragment x this wave's B fragments (wr, wr + 2)
+    acc9[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc9[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment f (16 rows at row16 = f) of a half-tile at `base`, k-step ks
     auto frag_cc = [&](const char* base, int row0, int ks) -> bf16x8 { return *(const bf16x8*)(base + row0 * 128 + foff[ks]); };
@@ -343,13 +376,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
                 for (int i = 0; i < NA; ++i) af[i][ks] = fragA7(cA, i * 16, ksc);
             });
+            bf16x8 a9[2];
+            if constexpr (EX) {
+                if (has9) {
+                    const char* c9 = smem + A9_BASE + buf * 2048;
+                    a9[0] = frag_cc(c9, 0, 0); a9[1] = frag_cc(c9, 0, 1);
+                }
+            }
             if (t >= 1 && t + 1 < nt) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) issue_piece(t + 1, buf ^ 1, false, h, i);
+                issue_a9(t + 1, buf ^ 1);                  // with the A halves: older than the B halves the counted wait leaves in flight
             }
-            enter_mfma(true); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2); leave_mfma();
+            enter_mfma(true); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2);
+            if constexpr (EX) {
+                if (has9) {                                  // 4 MFMAs: the extra 16 rows x this wave's B fragments wr and wr + 2
+                    if (wr == 0) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a9[ks], bf0[0][ks], acc9[0], 0, 0, 0);
+                            acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a9[ks], bf1[0][ks], acc9[1], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a9[ks], bf0[1][ks], acc9[0], 0, 0, 0);
+                            acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a9[ks], bf1[1][ks], acc9[1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            leave_mfma();
             // phase 1: A rows 64..127; the B halves of tile t+2 into THIS buffer, then the counted wait for tile t+1
             static_for<0, 2>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
@@ -645,6 +704,76 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
         __builtin_amdgcn_wave_barrier();
     }
     }
+    // ---- EX: the extra fragment's 16 rows; this wave holds B fragments f0 = wr and f1 = wr + 2 of its 64 B rows ----
+    if constexpr (EX) {
+        if (has9) {
+            const int f0 = wr, f1 = wr + 2;
+            if constexpr (GU) {
+                // gate fragment f0, up fragment f1 of the same 16 output columns (MODE 2: silu(g) * u; MODE 4: the two raw planes)
+#pragma unroll
+                for (int pl = 0; pl < PASSES; ++pl) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (MODE == 4) ? acc9[pl][r] : silu_f(acc9[0][r]) * acc9[1][r];
+                        wst[(lg * 4 + r) * T256_STG + l15] = v;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    const int rr = lane >> 2, c4 = (lane & 3) * 4;
+                    const int gm = m0 + 256 + rr, gc = ncol0 + f0 * 16 + c4;
+                    if (gm < M && gc < N) {
+                        const f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
+                        if (MODE == 4) {
+                            *(f32x4*)(slab + (int64_t)pl * M * p.ldc + (int64_t)gm * p.ldc + (gc - col0)) = v;
+                        } else {
+                            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+                            *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int f = jj ? f1 : f0;
+                    const float bvv = wr == 0 ? (jj ? bv[2] : bv[0]) : (jj ? bv[3] : bv[1]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc9[jj][r] + bvv;
+                        if constexpr (EPI == EPI_GELU_TANH) v = gelu_tanh_f(v);
+                        if constexpr (EPI == EPI_GELU_ERF) v = gelu_erf_f(v);
+                        wst[(lg * 4 + r) * T256_STG + f * 16 + l15] = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int rr = it * 8 + (lane >> 3), g8 = lane & 7;
+                    const int c4 = (g8 < 4 ? f0 : f1) * 16 + (g8 & 3) * 4;
+                    const int gm = m0 + 256 + rr, gc = ncol0 + c4;
+                    if (gm < M && gc < N) {
+                        f32x4 v = *(const f32x4*)(wst + rr * T256_STG + c4);
+                        if (MODE == 3) {
+                            *(f32x4*)(slab + (int64_t)gm * p.ldc + gc) = v;
+                        } else {
+                            if (p.residual != nullptr) {
+                                const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
+                                v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+                            }
+                            if constexpr (MODE == 1) {
+                                *(f32x4*)((float*)p.C + (int64_t)gm * p.ldc + gc) = v;
+                            } else {
+                                u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+                                *(u32x2*)((bf16_t*)p.C + (int64_t)gm * p.ldc + gc) = o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // 192-row tiles (BM) when they need fewer tile-times than 256-row tiles: rounds(tiles) x work per tile, a 192-row tile priced at 0.78 of a
@@ -656,21 +785,39 @@ static inline bool prefer_bm192(int M, int N, int force) {
     return 0.78 * cdiv(t192, 256) < 0.97 * cdiv(t256, 256);
 }
 
+// rows the LAST 256-row tile carries as an extra 16-row fragment (EX kernels): M = 256 k + r, k >= 1, 1 <= r <= 16; else 0.
+// VILA_GEMM_EX=0 switches the policy off (A/B measurements: the callers then see cdiv(M, 256) row tiles again)
+static inline int gemm256_ex_rows(int M) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VILA_GEMM_EX"); on = (e && e[0] == '0') ? 0 : 1; }
+    const int r = M % 256;
+    return (on && M > 256 && r >= 1 && r <= 16) ? r : 0;
+}
+// 256-row tiles of an M-row output under that policy (what every launch policy must count with when it hands tile ranges to EX launches)
+static inline int gemm256_tiles_m(int M) { return gemm256_ex_rows(M) ? M / 256 : cdiv(M, 256); }
+
 // tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
-template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256>
+template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256, bool EX = false>
 static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
     const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
-    const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, bn);
+    const int tiles_m = EX ? a.M / 256 : cdiv(a.M, BM), tiles_n = cdiv(a.N, bn);
     if (n_tiles < 0) n_tiles = tiles_m * tiles_n;
-    const size_t lds = 2 * 4 * 128 * 64 * 2;   // 131072 >= 8 waves x 32 x 68 x 4 staging
+    const size_t lds = 2 * 4 * 128 * 64 * 2 + (EX ? 4096 : 0);   // 131072 >= 8 waves x 32 x 68 x 4 staging (+ the extra fragment's two 2-KB buffers)
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int kt = cdiv(a.K, T256_BK);
     if (per <= 0) per = kt / splits;
-    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
     VILA_LAUNCH_CHECK();
     return 0;
+}
+// forward-layout launch that takes the EX kernel when the shape has 1..16 leftover rows (ex = gemm256_ex_rows(a.M) != 0, decided by the caller
+// so that its tile ranges and this launch agree)
+template <int MODE, int EPI>
+static int launch256_fwd(const GemmArgs& a, hipStream_t s, bool ex, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
+    if (ex) return launch256_t<MODE, EPI, false, false, T256_CC_SCHED, 256, true>(a, s, splits, tile0, n_tiles, col0, per);
+    return launch256_t<MODE, EPI, false, false, T256_CC_SCHED>(a, s, splits, tile0, n_tiles, col0, per);
 }
