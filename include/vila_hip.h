@@ -206,18 +206,7 @@ int vila_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, co
 int vila_gemm_bf16_t(const void* A, int64_t lda, int a_cm, const void* W, int64_t ldw, int b_cm, const void* bias,
                      const void* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, void* ws, size_t ws_bytes,
                      vila_stream_t stream);
-/* tuning hook for the 256x256 kernel's K-loop schedule (gemm256_kernel.h SCHED): 0 = each layout's default, 1 / 2 / 3 / 5 / 6 = that schedule,
- * 9 = ablation without DMA (timing only), 10 = the round-1 schedule (SCHED 0) */
-void vila_gemm_force_sched(int sched);
-/* tuning hook for the launch policy fed by a workspace: whole rounds of 256x256 tiles + K-sliced tail tiles (1 = on, default; 0 = off) */
-void vila_gemm_force_hybrid(int on);
-/* tuning hook for the decode step's attention (caches up to 2048 positions): 2 (default) / 1 = per-head blocks over 256-key slices with the
- * merge in the o_proj GEMV's prologue (512 / 256 o_proj blocks), 0 = one block per query head over the whole context + plain o_proj */
-void vila_decode_force_attn(int mode);
-/* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
-void vila_gemm_force_bm(int bm);
-/* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */
-void vila_gemm_force_tile(int tile);
+/* (process-global tuning / test switches of the kernels live in include/vila_hip_tuning.h: they are NOT part of the drop-in boundary) */
 int vila_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, vila_stream_t stream);
 int vila_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, float eps, vila_stream_t stream);
 int vila_space_to_depth_bf16(const void* x, void* y, int n_images, int grid, int channels, int k, vila_stream_t stream);

@@ -1,0 +1,28 @@
+/* vila_hip_tuning.h — tuning and test switches of libvila_hip.so.  NOT part of the drop-in boundary (include/vila_hip.h):
+ * these are PROCESS-GLOBAL, not thread-safe, and exist for the A/B measurements under tools/ and for the parity tests that pin one
+ * kernel variant (tests/test_gpu_ops.py).  A product binding never calls them; every switch defaults to the measured-best policy.
+ * Environment equivalents read once at first use: VILA_GEMM_EX, VILA_ATTN_FWD=v1, VILA_ATTN_BWD=v1, VILA_DECODE_ATTN. */
+#ifndef VILA_HIP_TUNING_H
+#define VILA_HIP_TUNING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* tuning hook for the 256x256 kernel's K-loop schedule (gemm256_kernel.h SCHED): 0 = each layout's default, 1 / 2 / 3 / 5 / 6 = that schedule,
+ * 9 = ablation without DMA (timing only), 10 = the round-1 schedule (SCHED 0) */
+void vila_gemm_force_sched(int sched);
+/* tuning hook for the launch policy fed by a workspace: whole rounds of 256x256 tiles + K-sliced tail tiles (1 = on, default; 0 = off) */
+void vila_gemm_force_hybrid(int on);
+/* tuning hook for the decode step's attention (caches up to 2048 positions): 2 (default) / 1 = per-head blocks over 256-key slices with the
+ * merge in the o_proj GEMV's prologue (512 / 256 o_proj blocks), 0 = one block per query head over the whole context + plain o_proj */
+void vila_decode_force_attn(int mode);
+/* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
+void vila_gemm_force_bm(int bm);
+/* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */
+void vila_gemm_force_tile(int tile);
+/* leftover rows (M = 256 k + r, 1 <= r <= 16) as an extra fragment of the last 256-row tile (gemm256_kernel.h, EX): -1 = VILA_GEMM_EX from the
+ * environment (default 1), 0 = off, 1 = when it saves a round of tiles (and in every K-sliced launch), 2 = whenever the rows fit (tests) */
+void vila_gemm_force_ex(int mode);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -419,6 +419,7 @@ def test_gemm256_leftover_rows_ride_in_the_last_row_tile(ops, M):
     ref = a.float() @ w.float().t()
     lo = (M // 256) * 256
     lib.vila_gemm_force_tile(4)                                    # pin the 256x256 kernel (the dispatcher would take other tiles for small M)
+    lib.vila_gemm_force_ex(2)                                      # ... and its extra-fragment variant (default policy: only when it saves a round)
     try:
         for name, out, want, tol in (
                 ("plain+bias+res", ops.gemm(a, w, bias=bias, residual=res), ref + bias.float() + res.float(), 4e-3),
@@ -429,6 +430,7 @@ def test_gemm256_leftover_rows_ride_in_the_last_row_tile(ops, M):
             assert rel_l2(out[lo - 16:lo], want[lo - 16:lo]) < tol
     finally:
         lib.vila_gemm_force_tile(0)
+        lib.vila_gemm_force_ex(-1)
     # fused gate/up (N = 18944: whole rounds + tail round split over K with a workspace) and the split-K slabs (K = 18944)
     F = 18944
     wg, wu = randn_bf16(F, K, seed=76, scale=K ** -0.5), randn_bf16(F, K, seed=77, scale=K ** -0.5)

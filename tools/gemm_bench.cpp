@@ -12,6 +12,7 @@
 #include <string.h>
 #include <vector>
 #include "../include/vila_hip.h"
+#include "../include/vila_hip_tuning.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 

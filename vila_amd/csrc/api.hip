@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/vila_hip.h"
+#include "../../include/vila_hip_tuning.h"
 #include "kernels.h"
 #include "train.h"
 #include "w4.h"
@@ -30,7 +31,32 @@ struct Arena {
     }
     bool ok() const { return off <= size; }
 };
-inline hipStream_t S(vila_stream_t s) { return (hipStream_t)s; }
+}  // namespace
+hipStream_t vila_stream_enter(void* s);      // (kernels.h) the same for the other translation units
+namespace {
+// Every entry point takes its device from the stream handle (backward runs on autograd worker threads whose thread-local HIP
+// device need not be the caller's): a non-default stream names its device, and the calling thread is switched to it before anything is
+// launched.  The lookup is cached per thread and stream, so the steady state costs one compare.
+inline hipStream_t S(vila_stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    if (st != nullptr) {
+        static thread_local hipStream_t last = nullptr;
+        static thread_local int last_dev = -1;
+        if (st != last) {
+            hipDevice_t dev = 0;
+            if (hipStreamGetDevice(st, &dev) == hipSuccess) { last = st; last_dev = (int)dev; }
+            else (void)hipGetLastError();
+        }
+        if (st == last && last_dev >= 0) {
+            int cur = -1;
+            if (hipGetDevice(&cur) == hipSuccess && cur != last_dev) (void)hipSetDevice(last_dev);
+        }
+    }
+    return st;
+}
+}  // namespace
+hipStream_t vila_stream_enter(void* s) { return S((vila_stream_t)s); }
+namespace {
 inline const bf16_t* B(const void* p) { return (const bf16_t*)p; }
 inline bf16_t* B(void* p) { return (bf16_t*)p; }
 

@@ -104,6 +104,8 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       /
 int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
 int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s);
 int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s);
+int g_gemm256_ex = -1;             // tuning hook (vila_gemm_force_ex): see gemm256_kernel.h
+extern "C" void vila_gemm_force_ex(int mode) { g_gemm256_ex = mode; }
 int g_gemm256_bm = 0;              // tuning hook (vila_gemm_force_bm): 0 = prefer_bm192's rule, 192 / 256 = force that tile height
 extern "C" void vila_gemm_force_bm(int bm) { g_gemm256_bm = bm; }
 static int g_gemm256_hybrid = 1;   // tuning hook: 0 = never cut a GEMM into whole rounds + K-sliced tail
@@ -155,8 +157,9 @@ bool gemm256_supported(const GemmArgs& a) {
 // Gate/up with an under-filled LAST round (S = 769: 592 tiles = 2 full rounds of 256 + 80): the full rounds run fused as usual, the
 // tail tiles are sliced over K so the last round costs 1/splits of a tile time; raw gate / up sums meet in a small reduce kernel.
 static int launch_gateup(const GemmArgs& a, hipStream_t s) {
-    const bool ex = gemm256_ex_rows(a.M) != 0;              // 1..16 leftover rows ride in the last row tile (EX kernels)
-    const int tiles_m = gemm256_tiles_m(a.M), tiles_n = cdiv(a.N, 128), kt = cdiv(a.K, T256_BK);
+    const int tiles_n = cdiv(a.N, 128), kt = cdiv(a.K, T256_BK);
+    const bool ex = gemm256_ex_saves_round(a.M, tiles_n);   // 1..16 leftover rows ride in the last row tile (EX kernels)
+    const int tiles_m = ex ? a.M / 256 : cdiv(a.M, 256);
     const int slots = 256;                                   // one 512-thread block per CU
     const int full_tn = ((tiles_m * tiles_n) / slots) * slots / tiles_m;     // tile columns covered by whole rounds
     const int tail_tn = tiles_n - full_tn, tail_tiles = tail_tn * tiles_m;
@@ -189,13 +192,10 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
     if (a.a_cm || a.b_cm) return launch_gemm256_cm(a, s);
     if (g_gemm256_sched != 0 && a.epi == EPI_NONE && !a.out_f32) return launch_gemm256_sched(a, g_gemm256_sched, s);
     if (a.epi == EPI_GATEUP) return launch_gateup(a, s);
-    const bool ex = gemm256_ex_rows(a.M) != 0;
+    const bool ex = gemm256_ex_saves_round(a.M, cdiv(a.N, 256));
     if (a.out_f32) return launch256_fwd<1, EPI_NONE>(a, s, ex);
     switch (a.epi) {
         case EPI_NONE:
-            // (a shape with leftover rows takes the EX kernel when that saves a whole round of tiles over the best other tiling)
-            if (ex && cdiv(gemm256_tiles_m(a.M) * cdiv(a.N, 256), 256) < cdiv(cdiv(a.M, 256) * cdiv(a.N, 256), 256) &&
-                !prefer_bm192(a.M, a.N, g_gemm256_bm)) return launch256_fwd<0, EPI_NONE>(a, s, true);
             if (prefer_bm192(a.M, a.N, g_gemm256_bm)) return launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED, 192>(a, s);
             return launch256_fwd<0, EPI_NONE>(a, s, ex);
         case EPI_GELU_TANH: return launch256_fwd<0, EPI_GELU_TANH>(a, s, ex);

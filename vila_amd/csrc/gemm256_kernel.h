@@ -787,14 +787,25 @@ static inline bool prefer_bm192(int M, int N, int force) {
 
 // rows the LAST 256-row tile carries as an extra 16-row fragment (EX kernels): M = 256 k + r, k >= 1, 1 <= r <= 16; else 0.
 // VILA_GEMM_EX=0 switches the policy off (A/B measurements: the callers then see cdiv(M, 256) row tiles again)
+extern int g_gemm256_ex;      // gemm256.hip: -1 = VILA_GEMM_EX from the environment (default 1), 0 = off, 1 = the policy below, 2 = whenever the rows fit (tests)
+static inline int gemm256_ex_mode() {
+    if (g_gemm256_ex < 0) { const char* e = getenv("VILA_GEMM_EX"); g_gemm256_ex = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+    return g_gemm256_ex;
+}
 static inline int gemm256_ex_rows(int M) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VILA_GEMM_EX"); on = (e && e[0] == '0') ? 0 : 1; }
     const int r = M % 256;
-    return (on && M > 256 && r >= 1 && r <= 16) ? r : 0;
+    return (gemm256_ex_mode() != 0 && M > 256 && r >= 1 && r <= 16) ? r : 0;
 }
 // 256-row tiles of an M-row output under that policy (what every launch policy must count with when it hands tile ranges to EX launches)
 static inline int gemm256_tiles_m(int M) { return gemm256_ex_rows(M) ? M / 256 : cdiv(M, 256); }
+// Whole-grid launches take the EX kernel only when dropping the extra row tile saves a ROUND of 256 blocks: its last-row blocks do 12.5 %
+// more MFMAs and the kernel carries 16-28 more registers, measured 5-10 % slower than the plain kernel on grids with the same number of
+// rounds (M = 3076 x N = 4608: 92 -> 101 us, profiles/r03_gemm_bench_fwd_ex.log); K-sliced launches always take it (fewer tiles = more slices)
+static inline bool gemm256_ex_saves_round(int M, int tiles_n) {
+    if (gemm256_ex_rows(M) == 0) return false;
+    if (gemm256_ex_mode() == 2) return true;
+    return cdiv((M / 256) * tiles_n, 256) < cdiv(cdiv(M, 256) * tiles_n, 256);
+}
 
 // tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
 template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256, bool EX = false>

@@ -2,6 +2,9 @@
 #pragma once
 #include "common.h"
 
+// stream handle of the C-ABI -> hipStream_t, with the calling thread switched to the stream's device (api.hip)
+hipStream_t vila_stream_enter(void* stream);
+
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_GATEUP = 3 };
 
 // C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]);  bf16 in, fp32 accumulate, bf16 (or fp32) out.

@@ -426,6 +426,6 @@ extern "C" int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights*
     const size_t slab = kSlabBytes;
     if (sft_debug()) fprintf(stderr, "sft: workspace %p bytes %zu need %zu\n", workspace, workspace_bytes, need);
     Ws w{(char*)workspace + slab, 0, false};
-    Ctx c{(hipStream_t)stream, &w, false, (float*)workspace, slab};
+    Ctx c{vila_stream_enter((void*)stream), &w, false, (float*)workspace, slab};
     return run(vit, vit_grad, proj, proj_grad, llm, llm_grad, batch, loss_out, c, cb, cb_arg);
 }
