@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--w4", action="store_true", help="W4A16 decode (int4 group-128 decoder projections; BASELINE configs[4], SURVEY 8f row 3)")
     ap.add_argument("--w8-vit", action="store_true", help="W8A8 vision tower (int8 x int8 per-channel ViT GEMMs; BASELINE configs[4])")
     ap.add_argument("--dynamic-s2", action="store_true", help="full NVILA-8B recipe: 14 tiles (448/896/1344) -> 2304 image tokens (SURVEY 8f row 1)")
+    ap.add_argument("--batch", type=int, default=1, help="decode mode: sequences per weight pass (2..16 = the batched decode step, value = aggregate tokens/s)")
     ap.add_argument("--selftest", action="store_true", help="harness only (gloo, no GPU): rendezvous + barrier + max-over-ranks + JSON line")
     return ap.parse_args(argv)
 
@@ -418,9 +419,58 @@ def video_main(a, rank, dev):
 # ----------------------------------------------------------------------------------------------------------------------
 # decode (the BASELINE metric)
 # ----------------------------------------------------------------------------------------------------------------------
+def batch_decode_main(a, rank, world, dev, dist):
+    """Serving throughput: `--batch B` sequences (1 image + prompt each) decoded by ONE weight pass per step (vila_llm_decode_step_batch,
+    hipGraph replay); value = aggregate generated tokens / s over the timed steps."""
+    import ctypes as C
+    from vila_amd import _lib, configs, ops, synthetic
+    from vila_amd._lib import check
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.reduced_8b(3, 4)
+    model = build_model(cfg, seed=0, device=dev)
+    llm = model.llm
+    Bn = a.batch
+    pixels = synthetic.make_pixels(cfg, Bn, 0, device=dev, dtype=torch.bfloat16)
+    ids = torch.stack([synthetic.make_prompt(cfg, a.prompt_tokens, 1, i) for i in range(Bn)], 0).to(dev)
+    e, _, m = model._embed(ids, {"image": [pixels[i] for i in range(Bn)]})
+    S = e.shape[1]
+    max_new = a.steps + a.warmup + 2
+    t0 = time.perf_counter()
+    out = llm.generate(inputs_embeds=e, attention_mask=m, max_new_tokens=max_new, eos_token_id=-1)      # builds the session, captures the graph
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    st = llm._bdecode
+    assert st is not None and st.graph is not None and out.shape == (Bn, max_new)
+    st.pos.fill_(S); st.n_out.zero_()
+
+    def one():
+        check(lib.vila_graph_launch(st.graph, st.stream.cuda_stream), "graph_launch")
+    with torch.cuda.stream(st.stream):
+        for _ in range(a.warmup):
+            one()
+        elapsed = timed_region(dist, dev, a.steps, one, torch.cuda.synchronize)
+    if rank == 0:
+        step_s = elapsed / a.steps
+        byt = decode_bytes_per_token(cfg, S + a.warmup + a.steps // 2) + (Bn - 1) * 2 * cfg.llm.kv_size * 2 * cfg.llm.num_hidden_layers * (S + a.warmup + a.steps // 2)
+        print(json.dumps({
+            "metric": f"batched decode tokens/sec, NVILA-8B, {Bn} sequences per weight pass", "value": round(world * Bn * a.steps / elapsed, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} bf16, {Bn} x (1x448^2 image + {a.prompt_tokens}-token prompt, S={S}), greedy, one hipGraph replay per step for the whole batch",
+                       "parallelism": f"replicas x{world}" if world > 1 else "single GPU", "batch": Bn},
+            "roofline": {"bound": "hbm", "achieved": round(byt / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byt / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "note": "whole step: weight bytes once + every row's KV cache"},
+            "first_generate_s": round(gen_s, 3)}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def decode_main(a, rank, world, dev, dist):
     from vila_amd import _lib, configs, ops, synthetic
     from vila_amd.vlm import build_model
+    if a.batch > 1:
+        return batch_decode_main(a, rank, world, dev, dist)
     lib = _lib.load()
     cfg = configs.nvila_8b() if a.config == "nvila_8b" else configs.nvila_lite_3b() if a.config == "nvila_lite_3b" else configs.reduced_8b(3, 4)
     n_tiles, media_cfg = 1, {}

@@ -179,6 +179,23 @@ int vila_sample_f32(const float* logits, int n, const VilaSampling* sp, const in
 int vila_llm_decode_step_sample(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
                                 void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream);
 
+/* Batched greedy decode step (serving: llava_arch.py:823-833 called with a batch, server.py:171-290 serving concurrent requests): ONE pass
+ * over the weights advances n <= 16 sequences.  Row i lives in KV-cache slot i (cache->n_slots >= n, filled by vila_llm_prefill with
+ * seq_of_tok = slot), consumes token[i] at position pos[i] and leaves its next token in token[i] / out_ids[i][n_out[i]++], pos[i]++.
+ * Rows that hit EOS keep stepping (the host ignores what they produce).  head_dim 128, caches up to 2048 positions. */
+typedef struct {
+    int n;               /* sequences */
+    int32_t* pos;        /* [n] */
+    int64_t* token;      /* [n] */
+    int64_t* out_ids;    /* [n][max_out] */
+    int32_t* n_out;      /* [n] */
+    int max_out;
+    float* logits;       /* [n][vocab] fp32 logits of the last step */
+} VilaDecodeBatch;
+size_t vila_llm_decode_batch_workspace_bytes(const VilaLlmShape* s, int n);
+int vila_llm_decode_step_batch(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeBatch* st,
+                               void* workspace, size_t workspace_bytes, vila_stream_t stream);
+
 /* hipGraph helpers: capture whatever is enqueued on `stream` between begin/end, replay it later. */
 int vila_graph_begin(vila_stream_t stream);
 int vila_graph_end(vila_stream_t stream, void** graph_exec_out);

@@ -20,6 +20,9 @@ import json; d=json.loads(open('$O/warm_$mb.json').read().strip().splitlines()[-
              for e in 0 1; do VILA_GEMM_EX=$e timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ex_$e.json" 2> "$O/ex_$e.err"; python -c "
 import json; d=json.loads(open('$O/ex_$e.json').read().strip().splitlines()[-1]); print('EX=$e: ttft', d['ttft_ms'], 'value', d['value'])" || tail -3 "$O/ex_$e.err"; done
              for e in 0 1; do VILA_GEMM_EX=$e timeout 300 tools/gemm_bench fwd > "$O/gemm_fwd_ex$e.log" 2>&1; grep -E "sched=0 " "$O/gemm_fwd_ex$e.log" | head -24; done ;;
+  batch)     timeout 900 python -m pytest tests/test_gpu_batch_decode.py -m gpu -q 2>&1 | tail -25
+             for b in 2 4 8 16; do timeout 300 python bench.py --batch $b --steps 48 --warmup 8 > "$O/batch_$b.json" 2> "$O/batch_$b.err"; python -c "
+import json; d=json.loads(open('$O/batch_$b.json').read().strip().splitlines()[-1]); print('batch $b: aggregate', d['value'], 'tok/s  ms/step', d['ms_per_step'], 'hbm frac', d['roofline']['frac'])" || tail -3 "$O/batch_$b.err"; done ;;
   tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
   tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;
   attn)      VILA_ATTN_FWD=v1 timeout 300 python tools/microbench.py attn > "$O/attn_v1.log" 2>&1; timeout 300 python tools/microbench.py attn > "$O/attn_new.log" 2>&1

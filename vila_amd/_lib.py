@@ -58,6 +58,11 @@ class VilaKvCache(C.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int), ("n_slots", c_int)]
 
 
+class VilaDecodeBatch(C.Structure):
+    _fields_ = [("n", c_int), ("pos", c_void_p), ("token", c_void_p), ("out_ids", c_void_p), ("n_out", c_void_p), ("max_out", c_int),
+                ("logits", c_void_p)]
+
+
 class VilaSampling(C.Structure):
     _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", C.c_uint64), ("seed_dev", c_void_p)]
 
@@ -108,6 +113,8 @@ PROTOTYPES = {
     "vila_sample_f32": (c_int, [c_void_p, c_int, C.POINTER(VilaSampling), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vila_llm_decode_step_sample": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeState),
                                             c_void_p, c_size_t, C.POINTER(VilaSampling), c_void_p]),
+    "vila_llm_decode_batch_workspace_bytes": (c_size_t, [C.POINTER(VilaLlmShape), c_int]),
+    "vila_llm_decode_step_batch": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaKvCache), C.POINTER(VilaDecodeBatch), c_void_p, c_size_t, c_void_p]),
     "vila_graph_begin": (c_int, [c_void_p]),
     "vila_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "vila_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -1,6 +1,7 @@
 // C-ABI of libvila_hip.so (include/vila_hip.h): model-level chaining of the kernels on the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 #include "../../include/vila_hip.h"
 #include "../../include/vila_hip_tuning.h"
 #include "kernels.h"
@@ -509,6 +510,31 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
     VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
     return 0;
+}
+
+// =================================================================================================
+// Batched decode step (decode_batch.hip)
+// =================================================================================================
+extern "C" size_t vila_llm_decode_batch_workspace_bytes(const VilaLlmShape* s, int n) {
+    return bdecode_workspace_bytes(s->hidden, s->inter, s->q_heads * s->head_dim, s->head_dim, n);
+}
+extern "C" int vila_llm_decode_step_batch(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeBatch* st,
+                                          void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    VILA_REQUIRE(w != nullptr && cache != nullptr && st != nullptr && workspace != nullptr, "llm_decode_batch: NULL argument");
+    const VilaLlmShape& sh = w->shape;
+    hipStream_t s = S(stream);
+    const int hd = sh.head_dim, QS = sh.q_heads * hd, KS = sh.kv_heads * hd, H = sh.hidden;
+    std::vector<BLayer> layers(sh.n_layers);
+    for (int l = 0; l < sh.n_layers; ++l) {
+        const VilaLlmLayer& L = w->layers[l];
+        const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
+                           (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
+        VILA_REQUIRE(fused, "llm_decode_batch: q/k/v projection weights and biases must be views of one fused [q+2kv, hidden] buffer");
+        layers[l] = BLayer{L.ln1_w, L.wq, L.bq, L.wo, L.ln2_w, L.w_gate, L.w_up, L.w_down};
+    }
+    BDecodeArgs m{w->embed, w->norm_w, w->lm_head, sh.hidden, sh.inter, sh.n_layers, sh.q_heads, sh.kv_heads, sh.head_dim, sh.vocab, sh.rms_eps, sh.rope_theta};
+    return bdecode_step(m, layers.data(), B(cache->k), B(cache->v), cache->max_ctx, cache->n_slots, st->n, st->pos, st->token, st->out_ids, st->n_out,
+                        st->max_out, st->logits, workspace, workspace_bytes, s);
 }
 
 // =================================================================================================

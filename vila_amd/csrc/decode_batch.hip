@@ -1,0 +1,368 @@
+// Batched decode (the serving side of generate — llava/model/llava_arch.py:823-833 with a batch, server.py:171-290
+// serving concurrent requests): ONE pass over the weights serves up to 16 sequences.  The batch-1 GEMVs (gemv.hip) become skinny GEMMs on
+// the matrix cores: C[batch 16][n 16] += X[batch][k] . W[n][k] with v_mfma_f32_16x16x32_bf16, A = the activations (rows = sequences, zero
+// rows beyond the batch), B = 16 weight rows straight from HBM.  The roofline stays HBM (the weight bytes of a token step are read once
+// for the whole batch); what changes is the FMA engine: a VALU dot product costs one lane-op per weight element AND sequence.
+//
+//   * lane (l15, lg) of a wave loads 2 x 16 B = 32 contiguous bytes of weight row n0 + l15 per 64-wide k-block (k = lg*16 .. +15): the four
+//     lane groups cover one full 128-B line per row, and the two 16-B halves feed two MFMAs whose k-slot order (lg, j) <-> k = lg*16 + h*8 + j
+//     is applied to the activation fragments as well (a contraction does not care about the order of its terms);
+//   * a block = 8 waves = one work item (16 output rows, or a pair of 16-row tiles: gate + up, the rotate-half partners of RoPE) with the
+//     k-blocks dealt round-robin to the waves (consecutive waves read consecutive lines of a row); partial sums meet in LDS, wave 0 runs the
+//     epilogue while the others already stream the next item (one barrier per item, double-buffered exchange area);
+//   * activations: [16][K] bf16 in LDS with the preceding RMSNorm fused in (HF rounding order, per sequence) when they fit (K <= 3832: every
+//     GEMM of the layer but down_proj), else fragments straight from global memory (L2-resident: 16 x 18944 x 2 B);
+//   * epilogues mirror gemv.hip's rounding exactly: bias, residual, silu(gate) * up, RoPE with the row's own position + KV-cache append into
+//     the row's own cache slot, fp32 logits.
+// Attention, argmax and the state advance reuse the batch-1 kernels with a row dimension on the grid.
+#include "kernels.h"
+#include "gemv_common.h"
+
+__device__ __forceinline__ u32x4 bd_ldg_nt(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+
+struct BGemmArgs {
+    const bf16_t* x; int64_t ldx;            // [n][K] activations
+    const bf16_t* norm_w; float eps;         // optional RMSNorm in front (needs the LDS-resident variant)
+    const bf16_t* W; const bf16_t* W2;       // [N][K]; W2: up_proj rows (mode 1)
+    const bf16_t* bias;                      // [N] optional
+    const bf16_t* residual; int64_t ldr;     // [n][N] optional
+    bf16_t* y; int64_t ldy;                  // [n][N] bf16 out
+    float* y_f32; int64_t ldf;               // [n][N] fp32 out (logits)
+    int n, N, K, mode;                       // mode 0 plain, 1 gate/up, 2 qkv (+bias, RoPE, cache append)
+    // mode 2
+    bf16_t* q_out; int64_t ldq;              // [n][nq*hd]
+    bf16_t* kcache; bf16_t* vcache;          // this layer's [slots][nkv][max_ctx][hd]; row i uses slot i
+    int64_t slot_stride;
+    const int32_t* pos;                      // [n]
+    const float* rope_cs;                    // [n][hd]: cos | sin of each row's position
+    int nq, nkv, hd, max_ctx;
+};
+
+template <int MODE, bool XLDS>
+__global__ __launch_bounds__(512) void bgemm_kernel(BGemmArgs p, int n_items) {
+    constexpr bool TWO = (MODE == 1 || MODE == 2);           // two 16-row tiles per item
+    constexpr int NT = TWO ? 2 : 1;
+    constexpr int U = 4;                                     // k-blocks in flight per wave: U x NT x 2 loads of 16 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int K = p.K, xs = K + 8;                           // LDS row stride of the staged activations (elements)
+    bf16_t* sx = (bf16_t*)smem;
+    float* red = (float*)(smem + (XLDS ? (size_t)16 * xs * 2 : 0));      // [2 parities][8 waves][NT][64 lanes] f32x4
+    const int nkb = K >> 6;                                  // 64-wide k-blocks
+
+    // ---- stage the activations (optionally RMS-normalised) : 32 threads per sequence ----
+    if constexpr (XLDS) {
+        const int row = tid >> 5, sub = tid & 31;
+        const int nch = K >> 3;
+        constexpr int MAXC = 15;                             // chunks per thread: K <= 32 * 15 * 8 = 3840
+        u32x4 v[MAXC];
+        float ss = 0.f;
+        const bool live = row < p.n;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = sub + 32 * i;
+            v[i] = (live && c < nch) ? *(const u32x4*)(p.x + (int64_t)row * p.ldx + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float a = lo_bf(v[i][k]), b = hi_bf(v[i][k]); ss += a * a + b * b; }
+        }
+        if (p.norm_w != nullptr) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);          // the 32 threads of a row are one half-wave
+            const float rstd = rsqrtf(ss / K + p.eps);
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = sub + 32 * i;
+                if (c < nch) {
+                    const u32x4 g = *(const u32x4*)(p.norm_w + c * 8);
+                    u32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(v[i][k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(v[i][k]) * rstd));
+                    *(u32x4*)(sx + row * xs + c * 8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = sub + 32 * i;
+                if (c < nch) *(u32x4*)(sx + row * xs + c * 8) = v[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // rows of the item's tiles
+    const int half = p.hd >> 1, gph = half >> 4;             // mode 2: pair groups per head
+    auto tile_rows = [&](int item, int (&r0)[NT]) {
+        if constexpr (MODE == 2) {
+            const int head = item / gph, j = item % gph;
+            r0[0] = head * p.hd + j * 16; r0[1] = r0[0] + half;
+        } else if constexpr (MODE == 1) {
+            r0[0] = item * 16; r0[1] = item * 16;            // same rows of gate_proj and up_proj
+        } else {
+            r0[0] = item * 16;
+        }
+    };
+
+    int parity = 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x, parity ^= 1) {
+        int r0[NT];
+        tile_rows(item, r0);
+        const bf16_t* wrow[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int n = r0[t] + l15; n = n < p.N ? n : p.N - 1;
+            wrow[t] = ((MODE == 1 && t == 1) ? p.W2 : p.W) + (int64_t)n * K + lg * 16;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // k-blocks wave, wave + 8, ... in batches of U
+        for (int kb0 = wave; kb0 < nkb; kb0 += 8 * U) {
+            u32x4 wv[U][NT][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kb = kb0 + 8 * u;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (kb < nkb) { wv[u][t][0] = bd_ldg_nt(wrow[t] + kb * 64); wv[u][t][1] = bd_ldg_nt(wrow[t] + kb * 64 + 8); }
+                    else { wv[u][t][0] = (u32x4){0u, 0u, 0u, 0u}; wv[u][t][1] = (u32x4){0u, 0u, 0u, 0u}; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kb = kb0 + 8 * u;
+                if (kb < nkb) {
+                    u32x4 xa, xb;
+                    if constexpr (XLDS) {
+                        const bf16_t* xp = sx + l15 * xs + kb * 64 + lg * 16;
+                        xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
+                    } else {
+                        xa = (u32x4){0u, 0u, 0u, 0u}; xb = xa;
+                        if (l15 < p.n) {
+                            const bf16_t* xp = p.x + (int64_t)l15 * p.ldx + kb * 64 + lg * 16;
+                            xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wv[u][t][0]), acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xb), __builtin_bit_cast(bf16x8, wv[u][t][1]), acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- the 8 partial sums meet in LDS; wave 0 finishes the item while the others go on ----
+        float* rp = red + (size_t)parity * 8 * NT * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4*)(rp + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+        __syncthreads();
+        if (wave != 0) continue;
+        f32x4 sum[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const f32x4 a = *(const f32x4*)(rp + ((w * NT + t) * 64 + lane) * 4);
+                sum[t][0] += a[0]; sum[t][1] += a[1]; sum[t][2] += a[2]; sum[t][3] += a[3];
+            }
+        }
+        // C layout: sequence m = lg*4 + r, output feature n = r0 + l15
+        if constexpr (MODE == 1) {
+            const int n = r0[0] + l15;
+            if (n < p.N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = lg * 4 + r;
+                    if (m < p.n) {
+                        const float gv = bfround(sum[0][r]), uv = bfround(sum[1][r]);            // HF: every tensor rounded to bf16
+                        p.y[(int64_t)m * p.ldy + n] = f2bf(bfround(silu_f(gv)) * uv);
+                    }
+                }
+            }
+        } else if constexpr (MODE == 2) {
+            const int head = item / gph, j = item % gph;
+            const bool is_v = head >= p.nq + p.nkv, is_q = head < p.nq;
+            const int gi = j * 16 + l15;                                                         // index inside the half head
+            const int na = r0[0] + l15, nb = r0[1] + l15;
+            const float ba = p.bias != nullptr ? bf2f(p.bias[na]) : 0.f, bb = p.bias != nullptr ? bf2f(p.bias[nb]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = lg * 4 + r;
+                if (m >= p.n) continue;
+                const float lo = bfround(sum[0][r] + ba), hi = bfround(sum[1][r] + bb);
+                float oa = lo, ob = hi;
+                if (!is_v) {
+                    const float c = p.rope_cs[m * p.hd + gi], sn = p.rope_cs[m * p.hd + half + gi];
+                    oa = bfround(bfround(lo * c) + bfround(-hi * sn));
+                    ob = bfround(bfround(hi * c) + bfround(lo * sn));
+                }
+                if (is_q) {
+                    p.q_out[(int64_t)m * p.ldq + na] = f2bf(oa);
+                    p.q_out[(int64_t)m * p.ldq + nb] = f2bf(ob);
+                } else {
+                    const int ps = p.pos[m];
+                    if (ps < p.max_ctx) {
+                        const int kvh = is_v ? head - p.nq - p.nkv : head - p.nq;
+                        bf16_t* dst = (is_v ? p.vcache : p.kcache) + (int64_t)m * p.slot_stride + ((int64_t)kvh * p.max_ctx + ps) * p.hd;
+                        dst[gi] = f2bf(oa);
+                        dst[half + gi] = f2bf(ob);
+                    }
+                }
+            }
+        } else {
+            const int n = r0[0] + l15;
+            if (n < p.N) {
+                const float bv = p.bias != nullptr ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = lg * 4 + r;
+                    if (m >= p.n) continue;
+                    float v = sum[0][r] + bv;
+                    if (p.y_f32 != nullptr) p.y_f32[(int64_t)m * p.ldf + n] = v;
+                    if (p.y != nullptr) {
+                        if (p.residual != nullptr) v = bfround(v) + bf2f(p.residual[(int64_t)m * p.ldr + n]);
+                        p.y[(int64_t)m * p.ldy + n] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, bool XLDS>
+static int launch_bgemm_t(const BGemmArgs& a, int n_items, hipStream_t s) {
+    const size_t lds = (XLDS ? (size_t)16 * (a.K + 8) * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4;
+    static size_t attr = 0;
+    if (lds > attr) {
+        VILA_HIP(hipFuncSetAttribute((const void*)bgemm_kernel<MODE, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const int grid = n_items < 256 ? n_items : 256;
+    hipLaunchKernelGGL((bgemm_kernel<MODE, XLDS>), dim3(grid), dim3(512), lds, s, a, n_items);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_bgemm(const BGemmArgs& a, hipStream_t s) {
+    VILA_REQUIRE(a.n >= 1 && a.n <= 16, "batched decode: 1..16 sequences (got %d)", a.n);
+    VILA_REQUIRE(a.K % 64 == 0 && a.K > 0 && a.N > 0, "batched decode GEMM: K (%d) must be a positive multiple of 64", a.K);
+    VILA_REQUIRE((uintptr_t)a.W % 16 == 0 && (uintptr_t)a.x % 16 == 0 && a.ldx % 8 == 0, "batched decode GEMM: operand alignment");
+    const bool xlds = a.K <= 3832;
+    VILA_REQUIRE(xlds || a.norm_w == nullptr, "batched decode GEMM: a fused RMSNorm needs K <= 3832 (got %d)", a.K);
+    if (a.mode == 1) {
+        VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr, "batched decode GEMM: gate/up needs W2 and a bf16 output");
+        return xlds ? launch_bgemm_t<1, true>(a, cdiv(a.N, 16), s) : launch_bgemm_t<1, false>(a, cdiv(a.N, 16), s);
+    }
+    if (a.mode == 2) {
+        VILA_REQUIRE(a.hd % 32 == 0 && a.N == (a.nq + 2 * a.nkv) * a.hd && a.q_out && a.kcache && a.vcache && a.pos && a.rope_cs,
+                     "batched decode GEMM: qkv mode needs head_dim %% 32 == 0 and its outputs");
+        const int items = (a.nq + 2 * a.nkv) * (a.hd / 32);
+        return xlds ? launch_bgemm_t<2, true>(a, items, s) : launch_bgemm_t<2, false>(a, items, s);
+    }
+    return xlds ? launch_bgemm_t<0, true>(a, cdiv(a.N, 16), s) : launch_bgemm_t<0, false>(a, cdiv(a.N, 16), s);
+}
+
+// ---- per-row prologue / pick / advance -------------------------------------------------------------------------------------------
+// x[row] = embed[token[row]]; rope table of the row's position: cs[row][0:hd/2] = cos, [hd/2:hd] = sin, rounded to bf16 like HF
+__global__ void bdec_prologue_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ tok, bf16_t* __restrict__ out, int H, int64_t vocab,
+                                     const int32_t* __restrict__ pos, float* __restrict__ rope_cs, int hd, float theta) {
+    const int row = blockIdx.y;
+    int64_t id = tok[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < (H >> 3); c += gridDim.x * blockDim.x)
+        *(u32x4*)(out + (int64_t)row * H + c * 8) = *(const u32x4*)(table + id * H + c * 8);
+    if (blockIdx.x == 0 && (int)threadIdx.x < (hd >> 1)) {
+        const int d = threadIdx.x;
+        const float inv = 1.0f / powf(theta, (float)(2 * d) / (float)hd);
+        const float ang = (float)pos[row] * inv;
+        rope_cs[row * hd + d] = bfround(cosf(ang));
+        rope_cs[row * hd + (hd >> 1) + d] = bfround(sinf(ang));
+    }
+}
+// greedy pick per row (first index of the maximum, like argmax_stage1/2) and the state advance, one block per row
+__global__ __launch_bounds__(1024) void bdec_pick_kernel(const float* __restrict__ logits, int V, int64_t* __restrict__ token, int32_t* __restrict__ pos,
+                                                         int64_t* __restrict__ out_ids, int32_t* __restrict__ n_out, int max_out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int row = blockIdx.x;
+    const float* lr = logits + (int64_t)row * V;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 1024) { const float v = lr[i]; if (v > best || (v == best && i < bi)) { best = v; bi = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o, 64); const int i2 = __shfl_xor(bi, o, 64);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        token[row] = (int64_t)bi;
+        const int n = n_out[row];
+        if (n < max_out) out_ids[(int64_t)row * max_out + n] = (int64_t)bi;
+        n_out[row] = n + 1;
+        pos[row] = pos[row] + 1;
+    }
+}
+
+// ---- the step ---------------------------------------------------------------------------------------------------------------------
+size_t bdecode_workspace_bytes(int H, int F, int QS, int hd, int n) {
+    size_t b = 0;
+    b += 2 * align_up((size_t)n * H * 2, 256) + 2 * align_up((size_t)n * QS * 2, 256) + align_up((size_t)n * F * 2, 256);
+    b += align_up((size_t)n * hd * 4, 256);
+    return b + 4096;
+}
+
+int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf16_t* vcache, int max_ctx, int n_slots, int n, int32_t* pos, int64_t* token,
+                 int64_t* out_ids, int32_t* n_out, int max_out, float* logits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    const int H = m.hidden, F = m.inter, hd = m.head_dim, QS = m.q_heads * hd, KS = m.kv_heads * hd;
+    VILA_REQUIRE(n >= 1 && n <= 16 && n <= n_slots, "batched decode: %d sequences need 1..16 KV-cache slots (cache has %d)", n, n_slots);
+    VILA_REQUIRE(QS == H, "batched decode: q_heads*head_dim (%d) must equal hidden (%d)", QS, H);
+    VILA_REQUIRE(hd == 128 && max_ctx <= 2048, "batched decode: head_dim 128 and caches up to 2048 positions (got %d, %d)", hd, max_ctx);
+    VILA_REQUIRE(workspace_bytes >= bdecode_workspace_bytes(H, F, QS, hd, n), "batched decode: workspace too small");
+    char* wp = (char*)workspace; size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); void* r = wp + off; off += bytes; return r; };
+    bf16_t* x = (bf16_t*)take((size_t)n * H * 2);
+    bf16_t* x2 = (bf16_t*)take((size_t)n * H * 2);
+    bf16_t* q = (bf16_t*)take((size_t)n * QS * 2);
+    bf16_t* ao = (bf16_t*)take((size_t)n * QS * 2);
+    bf16_t* act = (bf16_t*)take((size_t)n * F * 2);
+    float* rope_cs = (float*)take((size_t)n * hd * 4);
+    hipLaunchKernelGGL(bdec_prologue_kernel, dim3(cdiv(H / 8, 256), n), dim3(256), 0, s, (const bf16_t*)m.embed, token, x, H, (int64_t)m.vocab, pos, rope_cs, hd, m.rope_theta);
+    VILA_LAUNCH_CHECK();
+    const int64_t per_layer = (int64_t)n_slots * m.kv_heads * max_ctx * hd, slot_stride = (int64_t)m.kv_heads * max_ctx * hd;
+    bf16_t* cur = x; bf16_t* nxt = x2;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const BLayer& L = layers[l];
+        bf16_t* kc = kcache + l * per_layer; bf16_t* vc = vcache + l * per_layer;
+        BGemmArgs qa{};
+        qa.x = cur; qa.ldx = H; qa.norm_w = (const bf16_t*)L.ln1_w; qa.eps = m.rms_eps; qa.W = (const bf16_t*)L.wqkv; qa.bias = (const bf16_t*)L.bqkv;
+        qa.n = n; qa.N = QS + 2 * KS; qa.K = H; qa.mode = 2; qa.q_out = q; qa.ldq = QS; qa.kcache = kc; qa.vcache = vc; qa.slot_stride = slot_stride;
+        qa.pos = pos; qa.rope_cs = rope_cs; qa.nq = m.q_heads; qa.nkv = m.kv_heads; qa.hd = hd; qa.max_ctx = max_ctx;
+        VILA_TRY(launch_bgemm(qa, s));
+        AttnDecodeArgs ad{};
+        ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.pos_ptr = pos; ad.nq = m.q_heads; ad.nkv = m.kv_heads; ad.hd = hd; ad.max_ctx = max_ctx;
+        ad.n_splits = cdiv(max_ctx, 64); ad.scale = 1.0f / sqrtf((float)hd);
+        VILA_TRY(launch_attn_decode_rows(ad, n, QS, QS, slot_stride, s));
+        BGemmArgs o{};
+        o.x = ao; o.ldx = QS; o.W = (const bf16_t*)L.wo; o.residual = cur; o.ldr = H; o.y = nxt; o.ldy = H; o.n = n; o.N = H; o.K = QS; o.mode = 0;
+        VILA_TRY(launch_bgemm(o, s));
+        BGemmArgs gu{};
+        gu.x = nxt; gu.ldx = H; gu.norm_w = (const bf16_t*)L.ln2_w; gu.eps = m.rms_eps; gu.W = (const bf16_t*)L.w_gate; gu.W2 = (const bf16_t*)L.w_up;
+        gu.y = act; gu.ldy = F; gu.n = n; gu.N = F; gu.K = H; gu.mode = 1;
+        VILA_TRY(launch_bgemm(gu, s));
+        BGemmArgs dn{};
+        dn.x = act; dn.ldx = F; dn.W = (const bf16_t*)L.w_down; dn.residual = nxt; dn.ldr = H; dn.y = cur; dn.ldy = H; dn.n = n; dn.N = H; dn.K = F; dn.mode = 0;
+        VILA_TRY(launch_bgemm(dn, s));
+    }
+    BGemmArgs lm{};
+    lm.x = cur; lm.ldx = H; lm.norm_w = (const bf16_t*)m.norm_w; lm.eps = m.rms_eps; lm.W = (const bf16_t*)m.lm_head; lm.y_f32 = logits; lm.ldf = m.vocab;
+    lm.n = n; lm.N = m.vocab; lm.K = H; lm.mode = 0;
+    VILA_TRY(launch_bgemm(lm, s));
+    hipLaunchKernelGGL(bdec_pick_kernel, dim3(n), dim3(1024), 0, s, logits, m.vocab, token, pos, out_ids, n_out, max_out);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}

@@ -447,7 +447,10 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, kvh = h / (p.nq / p.nkv);
     const int key_lo = SPLIT ? blockIdx.y * 256 : 0;
-    const int nkeys_all = *p.pos_ptr + 1;
+    const int row = blockIdx.z;                                  // batched decode: sequence = cache slot (0 for the batch-1 step)
+    p.q += row * p.q_row_stride; p.kcache += row * p.slot_stride; p.vcache += row * p.slot_stride;
+    if (!SPLIT) p.o += row * p.o_row_stride;
+    const int nkeys_all = p.pos_ptr[row] + 1;
     if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
     const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
     const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
@@ -542,6 +545,17 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
             p.o[h * 128 + tid] = f2bf(acc / L);
         }
     }
+}
+
+// batched decode: one block per (query head, sequence) over the sequence's whole context (caches up to 2048 positions)
+int launch_attn_decode_rows(const AttnDecodeArgs& a0, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s) {
+    AttnDecodeArgs a = a0;
+    VILA_REQUIRE(a.hd == 128 && a.o != nullptr && a.max_ctx <= 2048 && n_rows >= 1, "attn_decode_rows: head_dim 128, caches up to 2048 positions");
+    VILA_REQUIRE(a.nq % a.nkv == 0, "attn_decode_rows: q heads must be a multiple of kv heads");
+    a.q_row_stride = q_row_stride; a.o_row_stride = o_row_stride; a.slot_stride = slot_stride;
+    hipLaunchKernelGGL(attn_decode_head<false>, dim3(a.nq, 1, n_rows), dim3(1024), 0, s, a);
+    VILA_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {

@@ -111,8 +111,20 @@ struct AttnDecodeArgs {
     int nq, nkv, hd, max_ctx, n_splits; float scale;
     int force_split;                 // 1: always use the split-KV + merge pair (default: single-launch per-head kernel when max_ctx <= 2048)
     int split256;                    // 1: per-head blocks over 256-key slices, partials only (merged in the o_proj GEMV prologue)
+    // batched decode (decode_batch.hip): row = blockIdx.z reads q + row * q_row_stride, cache slot row (+ row * slot_stride), pos_ptr[row]
+    int64_t q_row_stride, o_row_stride, slot_stride;
 };
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int launch_attn_decode_rows(const AttnDecodeArgs& a, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s);
+// batched decode step (decode_batch.hip)
+struct BDecodeArgs {
+    const void* embed; const void* norm_w; const void* lm_head;
+    int hidden, inter, n_layers, q_heads, kv_heads, head_dim, vocab; float rms_eps, rope_theta;
+};
+struct BLayer { const void *ln1_w, *wqkv, *bqkv, *wo, *ln2_w, *w_gate, *w_up, *w_down; };
+size_t bdecode_workspace_bytes(int H, int F, int QS, int hd, int n);
+int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf16_t* vcache, int max_ctx, int n_slots, int n, int32_t* pos, int64_t* token,
+                 int64_t* out_ids, int32_t* n_out, int max_out, float* logits, void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
                            int hd, float theta, hipStream_t s);
 int launch_decode_advance(int32_t* pos, const int64_t* tok, int64_t* out_ids, int32_t* n_out, int max_out, hipStream_t s);

@@ -86,6 +86,11 @@ class _HipModule(nn.Module):
                 _lib.load().vila_graph_destroy(st.graph)
                 st.graph = None
             self._decode = None
+        bst = getattr(self, "_bdecode", None)
+        if bst is not None:
+            if getattr(bst, "graph", None) is not None:
+                _lib.load().vila_graph_destroy(bst.graph)
+            self._bdecode = None
 
     def refuse(self) -> None:
         """Re-establish the fused q/k/v storage after an op that re-allocated parameters (.to(), .half(), ...)."""
@@ -472,6 +477,109 @@ class HipQwen2ForCausalLM(_HipModule):
         check(lib.vila_llm_decode_step(C.byref(self._struct()), C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
                                        ops._stream()), "vila_llm_decode_step")
 
+    # ---- batched greedy generate: one weight pass per step for up to 16 sequences (vila_llm_decode_step_batch) -----------------------
+    def _can_batch_decode(self, inputs_embeds, attention_mask, max_new_tokens, do_sample, forced_ids, return_logits, cache) -> bool:
+        c = self.lcfg
+        Bn, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
+        return (not do_sample and forced_ids is None and not return_logits and cache is None and getattr(self, "_w4", None) is None and
+                2 <= Bn <= 16 and c.head_dim == 128 and c.hidden_size % 64 == 0 and c.intermediate_size % 64 == 0 and
+                c.hidden_size <= 3832 and ((S + max_new_tokens + 255) // 256) * 256 <= 2048)
+
+    def _batch_session(self, n: int, max_ctx: int, max_new_tokens: int):
+        key = (n, max_ctx, max_new_tokens, self.model.embed_tokens.weight.data_ptr(), _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr())
+        st = getattr(self, "_bdecode", None)
+        if st is not None and st.key == key:
+            return st
+        if st is not None and st.graph is not None:
+            _lib.load().vila_graph_destroy(st.graph)
+        dev, lib, w = self.device, _lib.load(), self._struct()
+        st = SimpleNamespace(key=key, graph=None)
+        with torch.inference_mode(False):
+            st.cache = self.new_cache(max_ctx, n_slots=n)
+            st.pos = torch.zeros(n, device=dev, dtype=torch.int32)
+            st.token = torch.zeros(n, device=dev, dtype=torch.int64)
+            st.out_ids = torch.zeros((n, max(max_new_tokens, 1)), device=dev, dtype=torch.int64)
+            st.n_out = torch.zeros(n, device=dev, dtype=torch.int32)
+            st.logits = torch.zeros((n, self.lcfg.vocab_size), device=dev, dtype=torch.float32)
+            st.ws = torch.empty((lib.vila_llm_decode_batch_workspace_bytes(C.byref(w.shape), n),), device=dev, dtype=torch.uint8)
+        st.c = _lib.VilaDecodeBatch(n, st.pos.data_ptr(), st.token.data_ptr(), st.out_ids.data_ptr(), st.n_out.data_ptr(), max(max_new_tokens, 1),
+                                    st.logits.data_ptr())
+        st.stream = torch.cuda.Stream(device=dev)
+        self._bdecode = st
+        return st
+
+    def _batch_step(self, st) -> None:
+        check(_lib.load().vila_llm_decode_step_batch(C.byref(self._struct()), C.byref(st.cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
+                                                     ops._stream()), "vila_llm_decode_step_batch")
+
+    def _generate_batch(self, inputs_embeds, attention_mask, max_new_tokens, eos_token_id, pad_token_id, use_graph: bool = True):
+        """The padded batch as ONE packed prefill (every row into its own KV-cache slot) + batched decode steps: the weights are streamed
+        once per step for all rows.  Returns [B, n_new] right-padded with pad_token_id behind each row's EOS, like HF."""
+        ops._need(inputs_embeds, dtype=None, name="inputs_embeds")
+        Bn, S, H = inputs_embeds.shape
+        dev = inputs_embeds.device
+        mask = attention_mask.bool() if attention_mask is not None else torch.ones((Bn, S), dtype=torch.bool, device=dev)
+        lens = [int(v) for v in mask.sum(1).tolist()]
+        packed = inputs_embeds.reshape(Bn * S, H)[mask.reshape(-1)].to(self.dtype).contiguous()
+        cu_h = [0]
+        for n in lens:
+            cu_h.append(cu_h[-1] + n)
+        cu = torch.tensor(cu_h, device=dev, dtype=torch.int32)
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).to(dev)
+        seq = torch.cat([torch.full((n,), b, dtype=torch.int32) for b, n in enumerate(lens)]).to(dev)
+        last = torch.tensor([c - 1 for c in cu_h[1:]], device=dev, dtype=torch.int32)
+        max_ctx = ((max(lens) + max_new_tokens + 255) // 256) * 256
+        st = self._batch_session(Bn, max_ctx, max_new_tokens)
+        r = self.prefill_packed(packed, pos, cu, max(lens), cache=st.cache, seq_of_tok=seq, last_rows=last)
+        first = torch.cat([ops.argmax(r.last_logits[b]) for b in range(Bn)])
+        st.pos.copy_(torch.tensor(lens, dtype=torch.int32))
+        st.n_out.zero_()
+        st.token.copy_(first)
+        eos = self.lcfg.eos_token_id if eos_token_id is None else eos_token_id
+        eos_set = set(eos) if isinstance(eos, (list, tuple)) else {eos}
+        n_steps = max_new_tokens - 1
+        lib = _lib.load()
+        if use_graph and st.graph is None and n_steps > 0:
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(st.stream):
+                self._batch_step(st)                                   # warm-up outside capture (kernel attributes), then restore the state
+                st.stream.synchronize()
+                st.pos.copy_(torch.tensor(lens, dtype=torch.int32)); st.n_out.zero_(); st.token.copy_(first)
+                check(lib.vila_graph_begin(st.stream.cuda_stream), "graph_begin")
+                self._batch_step(st)
+                g = C.c_void_p()
+                check(lib.vila_graph_end(st.stream.cuda_stream, C.byref(g)), "graph_end")
+                st.graph = g
+                st.stream.synchronize()
+        first_h = first.tolist()
+        done_rows = [t in eos_set for t in first_h]
+        done = 0
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(st.stream):
+            while done < n_steps and not all(done_rows):
+                chunk = min(16, n_steps - done)
+                for _ in range(chunk):
+                    if use_graph:
+                        check(lib.vila_graph_launch(st.graph, st.stream.cuda_stream), "graph_launch")
+                    else:
+                        self._batch_step(st)
+                done += chunk
+                got = st.out_ids[:, :done].tolist()                 # one sync per 16 steps
+                done_rows = [first_h[b] in eos_set or any(t in eos_set for t in got[b]) for b in range(Bn)]
+        st.stream.synchronize()
+        toks = torch.cat([first[:, None], st.out_ids[:, :done]], 1)
+        eos1 = eos[0] if isinstance(eos, (list, tuple)) else eos
+        pad = pad_token_id if pad_token_id is not None else (eos1 if eos1 is not None else self.lcfg.eos_token_id)
+        rows = []
+        for b, row in enumerate(toks.tolist()):
+            cut = next((i + 1 for i, t in enumerate(row) if t in eos_set), len(row))      # HF stops a row AFTER emitting eos
+            rows.append(row[:cut])
+        n = max(len(r) for r in rows)
+        out = torch.full((Bn, n), int(pad), dtype=torch.int64, device=dev)
+        for b, r_ in enumerate(rows):
+            out[b, :len(r_)] = torch.tensor(r_, dtype=torch.int64, device=dev)
+        return out
+
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: Optional[int] = None,
                  eos_token_id=None, do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
@@ -496,6 +604,8 @@ class HipQwen2ForCausalLM(_HipModule):
             raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float, otherwise your next token scores will be invalid.")
         if do_sample and not (1 <= top_k <= 64):
             raise NotImplementedError(f"do_sample: top_k must be in 1..64 (got {top_k}); HF's default 50 is what the reference's server uses")
+        if inputs_embeds.shape[0] > 1 and self._can_batch_decode(inputs_embeds, attention_mask, max_new_tokens, do_sample, forced_ids, return_logits, cache):
+            return self._generate_batch(inputs_embeds, attention_mask, max_new_tokens, eos_token_id, pad_token_id, use_graph)
         if inputs_embeds.shape[0] > 1:
             rows = []
             for b in range(inputs_embeds.shape[0]):
