@@ -17,6 +17,7 @@ def _rows_vs_solo(model, e, m, n_new, tol_rel=1.5e-2):
     both = llm.generate(inputs_embeds=e, attention_mask=m, max_new_tokens=n_new, eos_token_id=-1)
     assert getattr(llm, "_bdecode", None) is not None, "the batched path was not taken"
     assert both.shape == (e.shape[0], n_new)
+    last_logits = llm._bdecode.logits.clone()          # (the solo runs below build another session, which drops this one)
     worst = 0.0
     for b in range(e.shape[0]):
         ids, lg = llm.generate(inputs_embeds=e[b:b + 1], attention_mask=m[b:b + 1], max_new_tokens=n_new, return_logits=True, use_graph=False,
@@ -30,7 +31,7 @@ def _rows_vs_solo(model, e, m, n_new, tol_rel=1.5e-2):
                 assert float(margin[t]) <= err_bound, f"row {b} step {t}: ids {got.tolist()} vs solo {want.tolist()} at a decisive step (margin {float(margin[t]):.3f})"
                 break
         worst = max(worst, float((got != want).float().mean()))
-    return both, worst
+    return both, worst, last_logits
 
 
 def test_batched_generate_rows_equal_solo_rows_tiny():
@@ -43,7 +44,7 @@ def test_batched_generate_rows_equal_solo_rows_tiny():
     ids = torch.randint(0, 900, (3, L), generator=g)
     mask = torch.ones(3, L, dtype=torch.bool); mask[1, 13:] = False; mask[2, 5:] = False
     e = model.llm.embed_tokens(ids.cuda())
-    both, _ = _rows_vs_solo(model, e, mask.cuda(), 10)
+    both, _, _ = _rows_vs_solo(model, e, mask.cuda(), 10)
     # graph replay == eager launches of the batched step
     eager = model.llm._generate_batch(e, mask.cuda(), 10, -1, None, use_graph=False)
     assert torch.equal(eager, both)
@@ -78,10 +79,8 @@ def test_batched_decode_step_logits_at_8b_widths():
     for b in range(Bn):
         mask[b, L - 3 * b:] = False
     e = llm.embed_tokens(ids.cuda())
-    both, frac = _rows_vs_solo(model, e, mask.cuda(), 8)
-    # logits of the LAST batched step vs the solo runs' last-step logits
-    st = llm._bdecode
-    blog = st.logits.clone()
+    both, frac, blog = _rows_vs_solo(model, e, mask.cuda(), 8)
+    # logits of the LAST batched step vs the solo runs' last-step logits (teacher-forced on the batch's ids)
     for b in (0, 3, 7):
         _, lg = llm.generate(inputs_embeds=e[b:b + 1], attention_mask=mask[b:b + 1].cuda(), max_new_tokens=8, return_logits=True, use_graph=False,
                              eos_token_id=-1, forced_ids=both[b])

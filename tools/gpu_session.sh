@@ -23,6 +23,9 @@ import json; d=json.loads(open('$O/ex_$e.json').read().strip().splitlines()[-1])
   batch)     timeout 900 python -m pytest tests/test_gpu_batch_decode.py -m gpu -q 2>&1 | tail -25
              for b in 2 4 8 16; do timeout 300 python bench.py --batch $b --steps 48 --warmup 8 > "$O/batch_$b.json" 2> "$O/batch_$b.err"; python -c "
 import json; d=json.loads(open('$O/batch_$b.json').read().strip().splitlines()[-1]); print('batch $b: aggregate', d['value'], 'tok/s  ms/step', d['ms_per_step'], 'hbm frac', d['roofline']['frac'])" || tail -3 "$O/batch_$b.err"; done ;;
+  prof_batch) timeout 600 bash tools/profile.sh batch8 --batch 8 --steps 32 --warmup 4 | tail -2
+             python tools/rocpd_summary.py "$GRAFT_REPO_ROOT/gpurun_out/prof_batch8/trace_results.db" "$O/batch8_kernel_stats.csv"; head -14 "$O/batch8_kernel_stats.csv"; rm -f "$GRAFT_REPO_ROOT/gpurun_out/prof_batch8/trace_results.db" ;;
+  batch_test) timeout 900 python -m pytest tests/test_gpu_batch_decode.py -m gpu -q 2>&1 | tail -8 ;;
   tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
   tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;
   attn)      VILA_ATTN_FWD=v1 timeout 300 python tools/microbench.py attn > "$O/attn_v1.log" 2>&1; timeout 300 python tools/microbench.py attn > "$O/attn_new.log" 2>&1

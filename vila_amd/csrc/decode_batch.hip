@@ -6,7 +6,8 @@
 //
 //   * lane (l15, lg) of a wave loads 2 x 16 B = 32 contiguous bytes of weight row n0 + l15 per 64-wide k-block (k = lg*16 .. +15): the four
 //     lane groups cover one full 128-B line per row, and the two 16-B halves feed two MFMAs whose k-slot order (lg, j) <-> k = lg*16 + h*8 + j
-//     is applied to the activation fragments as well (a contraction does not care about the order of its terms);
+//     is applied to the activation fragments as well (a contraction does not care about the order of its terms).  (Measured and rejected:
+//     row-contiguous loads — four consecutive lanes = 64 B of one row — re-dealt into the operand layout with ds_bpermute_b32: 15-80 % slower.)
 //   * a block = 8 waves = one work item (16 output rows, or a pair of 16-row tiles: gate + up, the rotate-half partners of RoPE) with the
 //     k-blocks dealt round-robin to the waves (consecutive waves read consecutive lines of a row); partial sums meet in LDS, wave 0 runs the
 //     epilogue while the others already stream the next item (one barrier per item, double-buffered exchange area);
@@ -17,8 +18,13 @@
 // Attention, argmax and the state advance reuse the batch-1 kernels with a row dimension on the grid.
 #include "kernels.h"
 #include "gemv_common.h"
+#include "attn_common.h"
+#include <cstdlib>
+#include <cstring>
 
-__device__ __forceinline__ u32x4 bd_ldg_nt(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+// (plain loads, not non-temporal: the two 16-B halves a lane reads share a 128-B line, and a streaming hint makes the second one miss the
+// vector cache again — 4.5 vs 5.5 TB/s for this access pattern in tools/exp/stream_bench.hip)
+__device__ __forceinline__ u32x4 bd_ldg_nt(const bf16_t* p) { return *(const u32x4*)p; }
 
 struct BGemmArgs {
     const bf16_t* x; int64_t ldx;            // [n][K] activations
@@ -38,17 +44,88 @@ struct BGemmArgs {
     int nq, nkv, hd, max_ctx;
 };
 
+// The finishing step of one work item, run by one wave on the block-reduced sums (C layout of v_mfma_f32_16x16x32: sequence m = lg*4 + r,
+// output feature n = r0 + l15).  Rounding mirrors gemv.hip / HF: every tensor rounded to bf16.
+template <int MODE, int NT>
+__device__ __forceinline__ void bgemm_epilogue(const BGemmArgs& p, int item, const int (&r0)[NT], const f32x4 (&sum)[NT], int lane) {
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int half = p.hd >> 1, gph = half >> 4;
+    (void)half; (void)gph; (void)item;
+    // C layout: sequence m = lg*4 + r, output feature n = r0 + l15
+    if constexpr (MODE == 1) {
+        const int n = r0[0] + l15;
+        if (n < p.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = lg * 4 + r;
+                if (m < p.n) {
+                    const float gv = bfround(sum[0][r]), uv = bfround(sum[1][r]);            // HF: every tensor rounded to bf16
+                    p.y[(int64_t)m * p.ldy + n] = f2bf(bfround(silu_f(gv)) * uv);
+                }
+            }
+        }
+    } else if constexpr (MODE == 2) {
+        const int head = item / gph, j = item % gph;
+        const bool is_v = head >= p.nq + p.nkv, is_q = head < p.nq;
+        const int gi = j * 16 + l15;                                                         // index inside the half head
+        const int na = r0[0] + l15, nb = r0[1] + l15;
+        const float ba = p.bias != nullptr ? bf2f(p.bias[na]) : 0.f, bb = p.bias != nullptr ? bf2f(p.bias[nb]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = lg * 4 + r;
+            if (m >= p.n) continue;
+            const float lo = bfround(sum[0][r] + ba), hi = bfround(sum[1][r] + bb);
+            float oa = lo, ob = hi;
+            if (!is_v) {
+                const float c = p.rope_cs[m * p.hd + gi], sn = p.rope_cs[m * p.hd + half + gi];
+                oa = bfround(bfround(lo * c) + bfround(-hi * sn));
+                ob = bfround(bfround(hi * c) + bfround(lo * sn));
+            }
+            if (is_q) {
+                p.q_out[(int64_t)m * p.ldq + na] = f2bf(oa);
+                p.q_out[(int64_t)m * p.ldq + nb] = f2bf(ob);
+            } else {
+                const int ps = p.pos[m];
+                if (ps < p.max_ctx) {
+                    const int kvh = is_v ? head - p.nq - p.nkv : head - p.nq;
+                    bf16_t* dst = (is_v ? p.vcache : p.kcache) + (int64_t)m * p.slot_stride + ((int64_t)kvh * p.max_ctx + ps) * p.hd;
+                    dst[gi] = f2bf(oa);
+                    dst[half + gi] = f2bf(ob);
+                }
+            }
+        }
+    } else {
+        const int n = r0[0] + l15;
+        if (n < p.N) {
+            const float bv = p.bias != nullptr ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = lg * 4 + r;
+                if (m >= p.n) continue;
+                float v = sum[0][r] + bv;
+                if (p.y_f32 != nullptr) p.y_f32[(int64_t)m * p.ldf + n] = v;
+                if (p.y != nullptr) {
+                    if (p.residual != nullptr) v = bfround(v) + bf2f(p.residual[(int64_t)m * p.ldr + n]);
+                    p.y[(int64_t)m * p.ldy + n] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
 template <int MODE, bool XLDS>
 __global__ __launch_bounds__(512) void bgemm_kernel(BGemmArgs p, int n_items) {
     constexpr bool TWO = (MODE == 1 || MODE == 2);           // two 16-row tiles per item
     constexpr int NT = TWO ? 2 : 1;
-    constexpr int U = 4;                                     // k-blocks in flight per wave: U x NT x 2 loads of 16 B
+    constexpr int U = (TWO || !XLDS) ? 4 : 8;                // k-blocks per batch and wave: 16 loads of 16 B per lane and batch, two batches in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int K = p.K, xs = K + 8;                           // LDS row stride of the staged activations (elements)
     bf16_t* sx = (bf16_t*)smem;
     float* red = (float*)(smem + (XLDS ? (size_t)16 * xs * 2 : 0));      // [2 parities][8 waves][NT][64 lanes] f32x4
+    const bf16_t* zero = (const bf16_t*)(smem + (XLDS ? (size_t)16 * xs * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4);   // 32 zero bytes
+    if (tid < 8) ((uint32_t*)zero)[tid] = 0u;                // (made visible by the barrier below)
     const int nkb = K >> 6;                                  // 64-wide k-blocks
 
     // ---- stage the activations (optionally RMS-normalised) : 32 threads per sequence ----
@@ -105,60 +182,74 @@ __global__ __launch_bounds__(512) void bgemm_kernel(BGemmArgs p, int n_items) {
         }
     };
 
+    // The weight stream is software-pipelined over (item, batch of U k-blocks per wave): the loads of the NEXT batch — of the next item at
+    // an item's end — are in flight while the current batch is multiplied, reduced and finished, so the HBM queue of a wave never runs dry
+    // at an item boundary (first version: two exposed round trips + a barrier per item, 3.8 TB/s on gate/up at batch 8).
+    const int nb = (((nkb + 7) >> 3) + U - 1) / U;           // batches per item (uniform over the waves)
+    struct Cur { int item, j; };
+    auto advance = [&](Cur c) { Cur n = c; if (++n.j == nb) { n.j = 0; n.item += gridDim.x; } return n; };
+    // issue() and the multiply part of consume() are BRANCH-FREE: a k-block beyond K (or a batch beyond the block's last item) still issues its
+    // loads, at the first bytes of W (one L2-resident line for the whole wave), and multiplies them by a zero activation fragment.  With a
+    // branch per load the compiler's wait-count bookkeeping gives up and drains the queue (s_waitcnt vmcnt(0)) before every use and before
+    // every new batch — the first two versions of this kernel never had more than one batch in flight.
+    struct Buf { u32x4 w[U][NT][2]; u32x4 x[XLDS ? 1 : U][2]; };
+    auto issue = [&](Cur c, Buf& b) {
+        const bool item_ok = true;                            // (callers only issue batches of real items)
+        int r0[NT];
+        tile_rows(item_ok ? c.item : 0, r0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kb = wave + 8 * (c.j * U + u);
+            const bool ok = item_ok && kb < nkb;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int n = r0[t] + l15; n = n < p.N ? n : p.N - 1;
+                const bf16_t* wbase = (MODE == 1 && t == 1) ? p.W2 : p.W;
+                const bf16_t* src = ok ? wbase + (int64_t)n * K + kb * 64 + lg * 16 : wbase;
+                b.w[u][t][0] = bd_ldg_nt(src); b.w[u][t][1] = bd_ldg_nt(src + 8);
+            }
+            if constexpr (!XLDS) {
+                const int m = l15 < p.n ? l15 : p.n - 1;
+                const bf16_t* xp = p.x + (int64_t)m * p.ldx + (ok ? kb * 64 + lg * 16 : 0);
+                b.x[u][0] = *(const u32x4*)xp; b.x[u][1] = *(const u32x4*)(xp + 8);
+            }
+        }
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int parity = 0;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x, parity ^= 1) {
+    auto consume = [&](Cur c, Buf& b) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kb = wave + 8 * (c.j * U + u);
+            const bool ok = kb < nkb;                        // (a batch beyond the last item is never consumed)
+            u32x4 xa, xb;
+            if constexpr (XLDS) {
+                const bf16_t* xp = ok ? sx + l15 * xs + kb * 64 + lg * 16 : zero;
+                xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
+            } else {
+                const bool live = ok && l15 < p.n;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xa[k] = live ? b.x[u][0][k] : 0u; xb[k] = live ? b.x[u][1][k] : 0u; }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, b.w[u][t][0]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xb), __builtin_bit_cast(bf16x8, b.w[u][t][1]), acc[t], 0, 0, 0);
+            }
+        }
+        if (c.j != nb - 1) return;
+        // ---- end of the item: the 8 partial sums meet in LDS; wave 0 finishes it while the others go on (their next loads are already in flight) ----
+        const int item = c.item;
         int r0[NT];
         tile_rows(item, r0);
-        const bf16_t* wrow[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int n = r0[t] + l15; n = n < p.N ? n : p.N - 1;
-            wrow[t] = ((MODE == 1 && t == 1) ? p.W2 : p.W) + (int64_t)n * K + lg * 16;
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // k-blocks wave, wave + 8, ... in batches of U
-        for (int kb0 = wave; kb0 < nkb; kb0 += 8 * U) {
-            u32x4 wv[U][NT][2];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int kb = kb0 + 8 * u;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (kb < nkb) { wv[u][t][0] = bd_ldg_nt(wrow[t] + kb * 64); wv[u][t][1] = bd_ldg_nt(wrow[t] + kb * 64 + 8); }
-                    else { wv[u][t][0] = (u32x4){0u, 0u, 0u, 0u}; wv[u][t][1] = (u32x4){0u, 0u, 0u, 0u}; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int kb = kb0 + 8 * u;
-                if (kb < nkb) {
-                    u32x4 xa, xb;
-                    if constexpr (XLDS) {
-                        const bf16_t* xp = sx + l15 * xs + kb * 64 + lg * 16;
-                        xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
-                    } else {
-                        xa = (u32x4){0u, 0u, 0u, 0u}; xb = xa;
-                        if (l15 < p.n) {
-                            const bf16_t* xp = p.x + (int64_t)l15 * p.ldx + kb * 64 + lg * 16;
-                            xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wv[u][t][0]), acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xb), __builtin_bit_cast(bf16x8, wv[u][t][1]), acc[t], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // ---- the 8 partial sums meet in LDS; wave 0 finishes the item while the others go on ----
         float* rp = red + (size_t)parity * 8 * NT * 256;
+        parity ^= 1;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) *(f32x4*)(rp + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+        for (int t = 0; t < NT; ++t) { *(f32x4*)(rp + ((wave * NT + t) * 64 + lane) * 4) = acc[t]; acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         __syncthreads();
-        if (wave != 0) continue;
+        if (wave != 0) return;
         f32x4 sum[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -169,72 +260,27 @@ __global__ __launch_bounds__(512) void bgemm_kernel(BGemmArgs p, int n_items) {
                 sum[t][0] += a[0]; sum[t][1] += a[1]; sum[t][2] += a[2]; sum[t][3] += a[3];
             }
         }
-        // C layout: sequence m = lg*4 + r, output feature n = r0 + l15
-        if constexpr (MODE == 1) {
-            const int n = r0[0] + l15;
-            if (n < p.N) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = lg * 4 + r;
-                    if (m < p.n) {
-                        const float gv = bfround(sum[0][r]), uv = bfround(sum[1][r]);            // HF: every tensor rounded to bf16
-                        p.y[(int64_t)m * p.ldy + n] = f2bf(bfround(silu_f(gv)) * uv);
-                    }
-                }
-            }
-        } else if constexpr (MODE == 2) {
-            const int head = item / gph, j = item % gph;
-            const bool is_v = head >= p.nq + p.nkv, is_q = head < p.nq;
-            const int gi = j * 16 + l15;                                                         // index inside the half head
-            const int na = r0[0] + l15, nb = r0[1] + l15;
-            const float ba = p.bias != nullptr ? bf2f(p.bias[na]) : 0.f, bb = p.bias != nullptr ? bf2f(p.bias[nb]) : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = lg * 4 + r;
-                if (m >= p.n) continue;
-                const float lo = bfround(sum[0][r] + ba), hi = bfround(sum[1][r] + bb);
-                float oa = lo, ob = hi;
-                if (!is_v) {
-                    const float c = p.rope_cs[m * p.hd + gi], sn = p.rope_cs[m * p.hd + half + gi];
-                    oa = bfround(bfround(lo * c) + bfround(-hi * sn));
-                    ob = bfround(bfround(hi * c) + bfround(lo * sn));
-                }
-                if (is_q) {
-                    p.q_out[(int64_t)m * p.ldq + na] = f2bf(oa);
-                    p.q_out[(int64_t)m * p.ldq + nb] = f2bf(ob);
-                } else {
-                    const int ps = p.pos[m];
-                    if (ps < p.max_ctx) {
-                        const int kvh = is_v ? head - p.nq - p.nkv : head - p.nq;
-                        bf16_t* dst = (is_v ? p.vcache : p.kcache) + (int64_t)m * p.slot_stride + ((int64_t)kvh * p.max_ctx + ps) * p.hd;
-                        dst[gi] = f2bf(oa);
-                        dst[half + gi] = f2bf(ob);
-                    }
-                }
-            }
-        } else {
-            const int n = r0[0] + l15;
-            if (n < p.N) {
-                const float bv = p.bias != nullptr ? bf2f(p.bias[n]) : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = lg * 4 + r;
-                    if (m >= p.n) continue;
-                    float v = sum[0][r] + bv;
-                    if (p.y_f32 != nullptr) p.y_f32[(int64_t)m * p.ldf + n] = v;
-                    if (p.y != nullptr) {
-                        if (p.residual != nullptr) v = bfround(v) + bf2f(p.residual[(int64_t)m * p.ldr + n]);
-                        p.y[(int64_t)m * p.ldy + n] = f2bf(v);
-                    }
-                }
-            }
-        }
+        bgemm_epilogue<MODE, NT>(p, item, r0, sum, lane);
+    };
+    Buf bufA, bufB;
+    Cur c{(int)blockIdx.x, 0};
+    if (c.item >= n_items) return;
+    issue(c, bufA);
+    for (;;) {                                               // (the last batch of the block is consumed with nothing behind it: no dummy batch)
+        const Cur n1 = advance(c);
+        if (n1.item >= n_items) { consume(c, bufA); break; }
+        issue(n1, bufB);
+        consume(c, bufA);
+        const Cur n2 = advance(n1);
+        if (n2.item >= n_items) { consume(n1, bufB); break; }
+        issue(n2, bufA);
+        consume(n1, bufB);
+        c = n2;
     }
 }
-
 template <int MODE, bool XLDS>
 static int launch_bgemm_t(const BGemmArgs& a, int n_items, hipStream_t s) {
-    const size_t lds = (XLDS ? (size_t)16 * (a.K + 8) * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4;
+    const size_t lds = (XLDS ? (size_t)16 * (a.K + 8) * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4 + 64;
     static size_t attr = 0;
     if (lds > attr) {
         VILA_HIP(hipFuncSetAttribute((const void*)bgemm_kernel<MODE, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -246,10 +292,171 @@ static int launch_bgemm_t(const BGemmArgs& a, int n_items, hipStream_t s) {
     return 0;
 }
 
+// ---- the weight stream through LDS (the kernel the step uses) ------------------------------------------------------------------------
+// The MFMA operand layout (lane = row & 15, 16 B per lane) is the wrong shape to LOAD in: one instruction touches 16 rows x 64 B, every
+// 128-B line is fetched by two instructions, and with 8 waves x 16+ loads in flight the second one no longer finds it in the 32-KB vector
+// cache (tools/exp/stream_bench.hip: 4.5 TB/s, 5.5 without the streaming hint; the register kernel above reaches 3.5-3.9).  Whole lines —
+// 8 adjacent lanes x 16 B = one 128-B line, 8 rows per instruction — stream at 6.2 TB/s, but put a row's chunks in 8 different lanes.
+// So the lines go through LDS: `global_load_lds` (no VGPRs, lane-linear 1-KB image per instruction) with the XOR swizzle applied to the
+// SOURCE chunk (slot s of row r holds chunk s ^ ((r >> 1) & 7)), and ds_read_b128 hands each lane its operand (conflict-free under
+// gfx950's b128 lane groups {0-3,12-15,20-27},...: 16 distinct rows per group, 8 of them one k-group further).  The activations take the
+// same road (an [XR][128 B] slice per k-block, L2-resident), so the kernel has no staging phase and no K limit; the RMSNorm in front
+// becomes its own small launch.  Each wave owns a private ring of NS slots (one slot = one 64-wide k-block: NT x 2 KB of weights +
+// XR x 128 B of activations), refilled as soon as a slot is consumed, counted s_waitcnt vmcnt; the only block-wide event is the
+// exchange of the 8 partial sums at an item's end (raw s_barrier: __syncthreads() would drain the rings).
+template <int MODE, int XR>
+__global__ __launch_bounds__(512) void bgemm_dma_kernel(BGemmArgs p, int n_items) {
+    constexpr int NT = (MODE == 1 || MODE == 2) ? 2 : 1;
+    constexpr int XI = XR / 8;                               // DMA instructions per activation slice
+    constexpr int DPS = NT * 2 + XI;                         // DMA instructions per slot
+    constexpr int SLOT = DPS * 1024;
+    constexpr int RING = 16384;                              // per wave
+    constexpr int NS = RING / SLOT;                          // 3 (two tiles, 8 rows) .. 5 (one tile, 8 rows); 2 for two tiles at 16 rows
+    static_assert(NS >= 2 && NS <= 5, "ring depth");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int K = p.K, nkb = K >> 6;
+    char* ring = smem + wave * RING;
+    float* red = (float*)(smem + 8 * RING);                  // [2 parities][8 waves][NT][64 lanes] f32x4
+    const int nkw = nkb > wave ? (nkb - wave + 7) >> 3 : 0;  // this wave's k-blocks: wave, wave + 8, ...
+    const int half = p.hd >> 1, gph = half >> 4;
+    auto tile_rows = [&](int item, int (&r0)[NT]) {
+        if constexpr (MODE == 2) {
+            const int head = item / gph, j = item % gph;
+            r0[0] = head * p.hd + j * 16; r0[1] = r0[0] + half;
+        } else if constexpr (MODE == 1) {
+            r0[0] = item * 16; r0[1] = item * 16;
+        } else {
+            r0[0] = item * 16;
+        }
+    };
+    // DMA side: lane = (row8 = lane >> 3, slot = lane & 7) of an 8-row x 128-B piece; the swizzle picks the source chunk
+    const int d_row = lane >> 3, d_slot = lane & 7;
+    const bf16_t* xsrc[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int m = 8 * j + d_row, mc = m < p.n ? m : p.n - 1;                   // (rows beyond the batch: a copy of the last one, never stored)
+        xsrc[j] = p.x + (int64_t)mc * p.ldx + ((d_slot ^ ((m >> 1) & 7)) << 3);
+    }
+    struct Cur { int item, i; };
+    auto issue = [&](Cur c, int slot) {
+        const int kb = wave + 8 * c.i;
+        int r0[NT];
+        tile_rows(c.item, r0);
+        char* dst = ring + slot * SLOT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16_t* wbase = (MODE == 1 && t == 1) ? p.W2 : p.W;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rl = 8 * j + d_row;
+                int n = r0[t] + rl; n = n < p.N ? n : p.N - 1;
+                const bf16_t* src = wbase + (int64_t)n * K + kb * 64 + ((d_slot ^ ((rl >> 1) & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (t * 2 + j) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(xsrc[j] + kb * 64), (lds_void_t*)(dst + (NT * 2 + j) * 1024), 16, 0, 0);
+    };
+    auto advance = [&](Cur& c) { if (++c.i >= nkw) { c.i = 0; c.item += gridDim.x; } };
+    // read side: lane (n = l15, k-group lg) wants chunk h*4 + lg of row n for the h-th MFMA of the k-block
+    const int offB = (l15 >> 3) * 1024 + (l15 & 7) * 128 + ((lg ^ ((l15 >> 1) & 7)) << 4);
+    const int mA = l15 & (XR - 1);
+    const int offA = NT * 2048 + (mA >> 3) * 1024 + (mA & 7) * 128 + ((lg ^ ((mA >> 1) & 7)) << 4);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Cur ci{(int)blockIdx.x, 0};
+    int in_flight = 0, islot = 0, cslot = 0, parity = 0;
+    if (nkw > 0) {
+#pragma unroll 1
+        for (int k = 0; k < NS - 1 && ci.item < n_items; ++k) {
+            issue(ci, islot); advance(ci); ++in_flight; if (++islot == NS) islot = 0;
+        }
+    }
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+#pragma unroll 1
+        for (int i = 0; i < nkw; ++i) {
+            if (ci.item < n_items) { issue(ci, islot); advance(ci); ++in_flight; if (++islot == NS) islot = 0; }
+            wait_tiles_ahead<DPS, NS - 1>(in_flight - 1);
+            --in_flight;
+            const char* sp = ring + cslot * SLOT;
+            if (++cslot == NS) cslot = 0;
+            const u32x4 xa = *(const u32x4*)(sp + offA), xb = *(const u32x4*)(sp + (offA ^ 64));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const u32x4 wa = *(const u32x4*)(sp + t * 2048 + offB), wb = *(const u32x4*)(sp + t * 2048 + (offB ^ 64));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, wa), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xb), __builtin_bit_cast(bf16x8, wb), acc[t], 0, 0, 0);
+            }
+        }
+        // ---- the 8 partial sums meet in LDS; wave 0 finishes the item while the others stream the next one ----
+        float* rp = red + (size_t)parity * 8 * NT * 256;
+        parity ^= 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { *(f32x4*)(rp + ((wave * NT + t) * 64 + lane) * 4) = acc[t]; acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0) {
+            int r0[NT];
+            tile_rows(item, r0);
+            f32x4 sum[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const f32x4 a = *(const f32x4*)(rp + ((w * NT + t) * 64 + lane) * 4);
+                    sum[t][0] += a[0]; sum[t][1] += a[1]; sum[t][2] += a[2]; sum[t][3] += a[3];
+                }
+            }
+            bgemm_epilogue<MODE, NT>(p, item, r0, sum, lane);
+        }
+    }
+}
+template <int MODE, int XR>
+static int launch_bgemm_dma_t(const BGemmArgs& a, int n_items, hipStream_t s) {
+    constexpr int NT = (MODE == 1 || MODE == 2) ? 2 : 1;
+    const size_t lds = (size_t)8 * 16384 + (size_t)2 * 8 * NT * 256 * 4;
+    static bool attr = false;
+    if (!attr) {
+        VILA_HIP(hipFuncSetAttribute((const void*)bgemm_dma_kernel<MODE, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int grid = n_items < 256 ? n_items : 256;
+    hipLaunchKernelGGL((bgemm_dma_kernel<MODE, XR>), dim3(grid), dim3(512), lds, s, a, n_items);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+static int bdec_use_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_BDEC"); v = (e != nullptr && strcmp(e, "v1") == 0) ? 1 : 0; }
+    return v;
+}
+
 static int launch_bgemm(const BGemmArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.n >= 1 && a.n <= 16, "batched decode: 1..16 sequences (got %d)", a.n);
     VILA_REQUIRE(a.K % 64 == 0 && a.K > 0 && a.N > 0, "batched decode GEMM: K (%d) must be a positive multiple of 64", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0 && (uintptr_t)a.x % 16 == 0 && a.ldx % 8 == 0, "batched decode GEMM: operand alignment");
+    if (!bdec_use_v1()) {
+        VILA_REQUIRE(a.norm_w == nullptr, "batched decode GEMM: the RMSNorm in front is its own launch on this path");
+        const bool x8 = a.n <= 8;
+        if (a.mode == 1) {
+            VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr, "batched decode GEMM: gate/up needs W2 and a bf16 output");
+            return x8 ? launch_bgemm_dma_t<1, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<1, 16>(a, cdiv(a.N, 16), s);
+        }
+        if (a.mode == 2) {
+            VILA_REQUIRE(a.hd % 32 == 0 && a.N == (a.nq + 2 * a.nkv) * a.hd && a.q_out && a.kcache && a.vcache && a.pos && a.rope_cs,
+                         "batched decode GEMM: qkv mode needs head_dim %% 32 == 0 and its outputs");
+            const int items = (a.nq + 2 * a.nkv) * (a.hd / 32);
+            return x8 ? launch_bgemm_dma_t<2, 8>(a, items, s) : launch_bgemm_dma_t<2, 16>(a, items, s);
+        }
+        return x8 ? launch_bgemm_dma_t<0, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<0, 16>(a, cdiv(a.N, 16), s);
+    }
     const bool xlds = a.K <= 3832;
     VILA_REQUIRE(xlds || a.norm_w == nullptr, "batched decode GEMM: a fused RMSNorm needs K <= 3832 (got %d)", a.K);
     if (a.mode == 1) {
@@ -311,7 +518,7 @@ __global__ __launch_bounds__(1024) void bdec_pick_kernel(const float* __restrict
 // ---- the step ---------------------------------------------------------------------------------------------------------------------
 size_t bdecode_workspace_bytes(int H, int F, int QS, int hd, int n) {
     size_t b = 0;
-    b += 2 * align_up((size_t)n * H * 2, 256) + 2 * align_up((size_t)n * QS * 2, 256) + align_up((size_t)n * F * 2, 256);
+    b += 3 * align_up((size_t)n * H * 2, 256) + 2 * align_up((size_t)n * QS * 2, 256) + align_up((size_t)n * F * 2, 256);
     b += align_up((size_t)n * hd * 4, 256);
     return b + 4096;
 }
@@ -327,6 +534,14 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
     auto take = [&](size_t bytes) { off = align_up(off, 256); void* r = wp + off; off += bytes; return r; };
     bf16_t* x = (bf16_t*)take((size_t)n * H * 2);
     bf16_t* x2 = (bf16_t*)take((size_t)n * H * 2);
+    bf16_t* xn = (bf16_t*)take((size_t)n * H * 2);           // the normalised activations in front of qkv / gate-up / lm_head
+    const bool fused_norm = bdec_use_v1() != 0;              // (the register kernel stages the activations itself and norms them on the way)
+    auto normed = [&](BGemmArgs& g, const bf16_t* src, const void* w) -> int {
+        if (fused_norm) { g.x = src; g.norm_w = (const bf16_t*)w; g.eps = m.rms_eps; return 0; }
+        VILA_TRY(launch_rmsnorm(src, (const bf16_t*)w, xn, n, H, m.rms_eps, s));
+        g.x = xn; g.norm_w = nullptr;
+        return 0;
+    };
     bf16_t* q = (bf16_t*)take((size_t)n * QS * 2);
     bf16_t* ao = (bf16_t*)take((size_t)n * QS * 2);
     bf16_t* act = (bf16_t*)take((size_t)n * F * 2);
@@ -339,7 +554,8 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
         const BLayer& L = layers[l];
         bf16_t* kc = kcache + l * per_layer; bf16_t* vc = vcache + l * per_layer;
         BGemmArgs qa{};
-        qa.x = cur; qa.ldx = H; qa.norm_w = (const bf16_t*)L.ln1_w; qa.eps = m.rms_eps; qa.W = (const bf16_t*)L.wqkv; qa.bias = (const bf16_t*)L.bqkv;
+        VILA_TRY(normed(qa, cur, L.ln1_w));
+        qa.ldx = H; qa.W = (const bf16_t*)L.wqkv; qa.bias = (const bf16_t*)L.bqkv;
         qa.n = n; qa.N = QS + 2 * KS; qa.K = H; qa.mode = 2; qa.q_out = q; qa.ldq = QS; qa.kcache = kc; qa.vcache = vc; qa.slot_stride = slot_stride;
         qa.pos = pos; qa.rope_cs = rope_cs; qa.nq = m.q_heads; qa.nkv = m.kv_heads; qa.hd = hd; qa.max_ctx = max_ctx;
         VILA_TRY(launch_bgemm(qa, s));
@@ -351,7 +567,8 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
         o.x = ao; o.ldx = QS; o.W = (const bf16_t*)L.wo; o.residual = cur; o.ldr = H; o.y = nxt; o.ldy = H; o.n = n; o.N = H; o.K = QS; o.mode = 0;
         VILA_TRY(launch_bgemm(o, s));
         BGemmArgs gu{};
-        gu.x = nxt; gu.ldx = H; gu.norm_w = (const bf16_t*)L.ln2_w; gu.eps = m.rms_eps; gu.W = (const bf16_t*)L.w_gate; gu.W2 = (const bf16_t*)L.w_up;
+        VILA_TRY(normed(gu, nxt, L.ln2_w));
+        gu.ldx = H; gu.W = (const bf16_t*)L.w_gate; gu.W2 = (const bf16_t*)L.w_up;
         gu.y = act; gu.ldy = F; gu.n = n; gu.N = F; gu.K = H; gu.mode = 1;
         VILA_TRY(launch_bgemm(gu, s));
         BGemmArgs dn{};
@@ -359,7 +576,8 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
         VILA_TRY(launch_bgemm(dn, s));
     }
     BGemmArgs lm{};
-    lm.x = cur; lm.ldx = H; lm.norm_w = (const bf16_t*)m.norm_w; lm.eps = m.rms_eps; lm.W = (const bf16_t*)m.lm_head; lm.y_f32 = logits; lm.ldf = m.vocab;
+    VILA_TRY(normed(lm, cur, m.norm_w));
+    lm.ldx = H; lm.W = (const bf16_t*)m.lm_head; lm.y_f32 = logits; lm.ldf = m.vocab;
     lm.n = n; lm.N = m.vocab; lm.K = H; lm.mode = 0;
     VILA_TRY(launch_bgemm(lm, s));
     hipLaunchKernelGGL(bdec_pick_kernel, dim3(n), dim3(1024), 0, s, logits, m.vocab, token, pos, out_ids, n_out, max_out);
