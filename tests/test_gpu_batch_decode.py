@@ -64,8 +64,8 @@ def test_batched_generate_rows_equal_solo_rows_tiny():
 
 
 def test_batched_decode_step_logits_at_8b_widths():
-    """NVILA-8B widths, 2 layers, batch 8 with different context lengths: K = 3584 (LDS-resident activations, fused RMSNorm) and K = 18944
-    (fragments from global memory), N = 4608 / 3584 / 18944 / 32000; the step's logits of every row against the batch-1 decode step of the
+    """NVILA-8B widths, 2 layers, batch 8 (8-row activation slices) with different context lengths: K = 3584 and K = 18944,
+    N = 4608 / 3584 / 18944 / 32000, GQA group 7; the step's logits of every row against the batch-1 decode step of the
     same row (rel-L2 <= 1.5e-2: the tolerance of decode-vs-prefill), ids under the margin rule, 8 steps."""
     from vila_amd.vlm import build_model
     cfg = configs.reduced_8b(layers_v=2, layers_l=2, vocab=32000)
@@ -86,3 +86,27 @@ def test_batched_decode_step_logits_at_8b_widths():
                              eos_token_id=-1, forced_ids=both[b])
         assert rel_l2(blog[b], lg[-1]) < 1.5e-2, f"row {b}: step logits rel={rel_l2(blog[b], lg[-1]):.3e} max={max_abs(blog[b], lg[-1]):.3e}"
     print(f"batch-8 decode at 8B widths: fraction of differing ids vs solo rows {frac:.3f}")
+
+
+def test_batched_decode_twelve_rows_contexts_across_slices():
+    """Batch 12 (the 16-row activation slices, two-slot rings) with contexts of 250 .. 580 keys: the attention of a row spans one, two or
+    three 256-key slices, so the slice merge launch sees every count; logits of three rows against their solo decode steps."""
+    from vila_amd.vlm import build_model
+    cfg = configs.reduced_8b(layers_v=2, layers_l=2, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    model = build_model(cfg, seed=9)
+    llm = model.llm
+    g = torch.Generator().manual_seed(9)
+    Bn, L = 12, 580
+    ids = torch.randint(0, 31000, (Bn, L), generator=g)
+    mask = torch.ones(Bn, L, dtype=torch.bool)
+    for b in range(Bn):
+        mask[b, L - 30 * b:] = False                              # 580, 550, ..., 250 keys
+    e = llm.embed_tokens(ids.cuda())
+    out = llm.generate(inputs_embeds=e, attention_mask=mask.cuda(), max_new_tokens=4, eos_token_id=-1)
+    assert getattr(llm, "_bdecode", None) is not None, "the batched path was not taken"
+    blog = llm._bdecode.logits.clone()
+    for b in (0, 4, 11):
+        _, lg = llm.generate(inputs_embeds=e[b:b + 1], attention_mask=mask[b:b + 1].cuda(), max_new_tokens=4, return_logits=True, use_graph=False,
+                             eos_token_id=-1, forced_ids=out[b])
+        assert rel_l2(blog[b], lg[-1]) < 1.5e-2, f"row {b} ({int(mask[b].sum())} keys): step logits rel={rel_l2(blog[b], lg[-1]):.3e}"

@@ -4,31 +4,25 @@
 // rows beyond the batch), B = 16 weight rows straight from HBM.  The roofline stays HBM (the weight bytes of a token step are read once
 // for the whole batch); what changes is the FMA engine: a VALU dot product costs one lane-op per weight element AND sequence.
 //
-//   * lane (l15, lg) of a wave loads 2 x 16 B = 32 contiguous bytes of weight row n0 + l15 per 64-wide k-block (k = lg*16 .. +15): the four
-//     lane groups cover one full 128-B line per row, and the two 16-B halves feed two MFMAs whose k-slot order (lg, j) <-> k = lg*16 + h*8 + j
-//     is applied to the activation fragments as well (a contraction does not care about the order of its terms).  (Measured and rejected:
-//     row-contiguous loads — four consecutive lanes = 64 B of one row — re-dealt into the operand layout with ds_bpermute_b32: 15-80 % slower.)
 //   * a block = 8 waves = one work item (16 output rows, or a pair of 16-row tiles: gate + up, the rotate-half partners of RoPE) with the
-//     k-blocks dealt round-robin to the waves (consecutive waves read consecutive lines of a row); partial sums meet in LDS, wave 0 runs the
-//     epilogue while the others already stream the next item (one barrier per item, double-buffered exchange area);
-//   * activations: [16][K] bf16 in LDS with the preceding RMSNorm fused in (HF rounding order, per sequence) when they fit (K <= 3832: every
-//     GEMM of the layer but down_proj), else fragments straight from global memory (L2-resident: 16 x 18944 x 2 B);
+//     64-wide k-blocks dealt round-robin to the waves (consecutive waves read consecutive 128-B lines of a row); partial sums meet in LDS,
+//     wave 0 runs the epilogue while the others already stream the next item (one raw barrier per item, double-buffered exchange area);
+//   * weights AND activations reach the matrix core through per-wave LDS-DMA rings in whole 128-B lines (bgemm_dma_kernel's header has the
+//     why and the numbers); the RMSNorm in front of qkv / gate-up / lm_head is its own launch (elementwise.hip, HF rounding order);
 //   * epilogues mirror gemv.hip's rounding exactly: bias, residual, silu(gate) * up, RoPE with the row's own position + KV-cache append into
-//     the row's own cache slot, fp32 logits.
-// Attention, argmax and the state advance reuse the batch-1 kernels with a row dimension on the grid.
+//     the row's own cache slot, fp32 logits;
+//   * attention: one block per (kv head, 256-key slice, sequence) serving the whole GQA group from one K/V read (bdec_attn_kernel).
+// History (round 3, batch 8, NVILA-8B, ms per step on one MI355X): register kernel with operand-shaped loads 5.17 -> software-pipelined
+// 5.14 -> row-contiguous loads re-dealt by ds_bpermute 6.30 (rejected) -> LDS-DMA rings 3.74 -> GQA-sliced attention 3.59.
 #include "kernels.h"
 #include "gemv_common.h"
 #include "attn_common.h"
 #include <cstdlib>
 #include <cstring>
 
-// (plain loads, not non-temporal: the two 16-B halves a lane reads share a 128-B line, and a streaming hint makes the second one miss the
-// vector cache again — 4.5 vs 5.5 TB/s for this access pattern in tools/exp/stream_bench.hip)
-__device__ __forceinline__ u32x4 bd_ldg_nt(const bf16_t* p) { return *(const u32x4*)p; }
 
 struct BGemmArgs {
     const bf16_t* x; int64_t ldx;            // [n][K] activations
-    const bf16_t* norm_w; float eps;         // optional RMSNorm in front (needs the LDS-resident variant)
     const bf16_t* W; const bf16_t* W2;       // [N][K]; W2: up_proj rows (mode 1)
     const bf16_t* bias;                      // [N] optional
     const bf16_t* residual; int64_t ldr;     // [n][N] optional
@@ -113,189 +107,10 @@ __device__ __forceinline__ void bgemm_epilogue(const BGemmArgs& p, int item, con
     }
 }
 
-template <int MODE, bool XLDS>
-__global__ __launch_bounds__(512) void bgemm_kernel(BGemmArgs p, int n_items) {
-    constexpr bool TWO = (MODE == 1 || MODE == 2);           // two 16-row tiles per item
-    constexpr int NT = TWO ? 2 : 1;
-    constexpr int U = (TWO || !XLDS) ? 4 : 8;                // k-blocks per batch and wave: 16 loads of 16 B per lane and batch, two batches in flight
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int K = p.K, xs = K + 8;                           // LDS row stride of the staged activations (elements)
-    bf16_t* sx = (bf16_t*)smem;
-    float* red = (float*)(smem + (XLDS ? (size_t)16 * xs * 2 : 0));      // [2 parities][8 waves][NT][64 lanes] f32x4
-    const bf16_t* zero = (const bf16_t*)(smem + (XLDS ? (size_t)16 * xs * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4);   // 32 zero bytes
-    if (tid < 8) ((uint32_t*)zero)[tid] = 0u;                // (made visible by the barrier below)
-    const int nkb = K >> 6;                                  // 64-wide k-blocks
-
-    // ---- stage the activations (optionally RMS-normalised) : 32 threads per sequence ----
-    if constexpr (XLDS) {
-        const int row = tid >> 5, sub = tid & 31;
-        const int nch = K >> 3;
-        constexpr int MAXC = 15;                             // chunks per thread: K <= 32 * 15 * 8 = 3840
-        u32x4 v[MAXC];
-        float ss = 0.f;
-        const bool live = row < p.n;
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = sub + 32 * i;
-            v[i] = (live && c < nch) ? *(const u32x4*)(p.x + (int64_t)row * p.ldx + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float a = lo_bf(v[i][k]), b = hi_bf(v[i][k]); ss += a * a + b * b; }
-        }
-        if (p.norm_w != nullptr) {
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);          // the 32 threads of a row are one half-wave
-            const float rstd = rsqrtf(ss / K + p.eps);
-#pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = sub + 32 * i;
-                if (c < nch) {
-                    const u32x4 g = *(const u32x4*)(p.norm_w + c * 8);
-                    u32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(v[i][k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(v[i][k]) * rstd));
-                    *(u32x4*)(sx + row * xs + c * 8) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = sub + 32 * i;
-                if (c < nch) *(u32x4*)(sx + row * xs + c * 8) = v[i];
-            }
-        }
-        __syncthreads();
-    }
-
-    // rows of the item's tiles
-    const int half = p.hd >> 1, gph = half >> 4;             // mode 2: pair groups per head
-    auto tile_rows = [&](int item, int (&r0)[NT]) {
-        if constexpr (MODE == 2) {
-            const int head = item / gph, j = item % gph;
-            r0[0] = head * p.hd + j * 16; r0[1] = r0[0] + half;
-        } else if constexpr (MODE == 1) {
-            r0[0] = item * 16; r0[1] = item * 16;            // same rows of gate_proj and up_proj
-        } else {
-            r0[0] = item * 16;
-        }
-    };
-
-    // The weight stream is software-pipelined over (item, batch of U k-blocks per wave): the loads of the NEXT batch — of the next item at
-    // an item's end — are in flight while the current batch is multiplied, reduced and finished, so the HBM queue of a wave never runs dry
-    // at an item boundary (first version: two exposed round trips + a barrier per item, 3.8 TB/s on gate/up at batch 8).
-    const int nb = (((nkb + 7) >> 3) + U - 1) / U;           // batches per item (uniform over the waves)
-    struct Cur { int item, j; };
-    auto advance = [&](Cur c) { Cur n = c; if (++n.j == nb) { n.j = 0; n.item += gridDim.x; } return n; };
-    // issue() and the multiply part of consume() are BRANCH-FREE: a k-block beyond K (or a batch beyond the block's last item) still issues its
-    // loads, at the first bytes of W (one L2-resident line for the whole wave), and multiplies them by a zero activation fragment.  With a
-    // branch per load the compiler's wait-count bookkeeping gives up and drains the queue (s_waitcnt vmcnt(0)) before every use and before
-    // every new batch — the first two versions of this kernel never had more than one batch in flight.
-    struct Buf { u32x4 w[U][NT][2]; u32x4 x[XLDS ? 1 : U][2]; };
-    auto issue = [&](Cur c, Buf& b) {
-        const bool item_ok = true;                            // (callers only issue batches of real items)
-        int r0[NT];
-        tile_rows(item_ok ? c.item : 0, r0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kb = wave + 8 * (c.j * U + u);
-            const bool ok = item_ok && kb < nkb;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int n = r0[t] + l15; n = n < p.N ? n : p.N - 1;
-                const bf16_t* wbase = (MODE == 1 && t == 1) ? p.W2 : p.W;
-                const bf16_t* src = ok ? wbase + (int64_t)n * K + kb * 64 + lg * 16 : wbase;
-                b.w[u][t][0] = bd_ldg_nt(src); b.w[u][t][1] = bd_ldg_nt(src + 8);
-            }
-            if constexpr (!XLDS) {
-                const int m = l15 < p.n ? l15 : p.n - 1;
-                const bf16_t* xp = p.x + (int64_t)m * p.ldx + (ok ? kb * 64 + lg * 16 : 0);
-                b.x[u][0] = *(const u32x4*)xp; b.x[u][1] = *(const u32x4*)(xp + 8);
-            }
-        }
-    };
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int parity = 0;
-    auto consume = [&](Cur c, Buf& b) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kb = wave + 8 * (c.j * U + u);
-            const bool ok = kb < nkb;                        // (a batch beyond the last item is never consumed)
-            u32x4 xa, xb;
-            if constexpr (XLDS) {
-                const bf16_t* xp = ok ? sx + l15 * xs + kb * 64 + lg * 16 : zero;
-                xa = *(const u32x4*)xp; xb = *(const u32x4*)(xp + 8);
-            } else {
-                const bool live = ok && l15 < p.n;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { xa[k] = live ? b.x[u][0][k] : 0u; xb[k] = live ? b.x[u][1][k] : 0u; }
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa), __builtin_bit_cast(bf16x8, b.w[u][t][0]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xb), __builtin_bit_cast(bf16x8, b.w[u][t][1]), acc[t], 0, 0, 0);
-            }
-        }
-        if (c.j != nb - 1) return;
-        // ---- end of the item: the 8 partial sums meet in LDS; wave 0 finishes it while the others go on (their next loads are already in flight) ----
-        const int item = c.item;
-        int r0[NT];
-        tile_rows(item, r0);
-        float* rp = red + (size_t)parity * 8 * NT * 256;
-        parity ^= 1;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { *(f32x4*)(rp + ((wave * NT + t) * 64 + lane) * 4) = acc[t]; acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        __syncthreads();
-        if (wave != 0) return;
-        f32x4 sum[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const f32x4 a = *(const f32x4*)(rp + ((w * NT + t) * 64 + lane) * 4);
-                sum[t][0] += a[0]; sum[t][1] += a[1]; sum[t][2] += a[2]; sum[t][3] += a[3];
-            }
-        }
-        bgemm_epilogue<MODE, NT>(p, item, r0, sum, lane);
-    };
-    Buf bufA, bufB;
-    Cur c{(int)blockIdx.x, 0};
-    if (c.item >= n_items) return;
-    issue(c, bufA);
-    for (;;) {                                               // (the last batch of the block is consumed with nothing behind it: no dummy batch)
-        const Cur n1 = advance(c);
-        if (n1.item >= n_items) { consume(c, bufA); break; }
-        issue(n1, bufB);
-        consume(c, bufA);
-        const Cur n2 = advance(n1);
-        if (n2.item >= n_items) { consume(n1, bufB); break; }
-        issue(n2, bufA);
-        consume(n1, bufB);
-        c = n2;
-    }
-}
-template <int MODE, bool XLDS>
-static int launch_bgemm_t(const BGemmArgs& a, int n_items, hipStream_t s) {
-    const size_t lds = (XLDS ? (size_t)16 * (a.K + 8) * 2 : 0) + (size_t)2 * 8 * 2 * 256 * 4 + 64;
-    static size_t attr = 0;
-    if (lds > attr) {
-        VILA_HIP(hipFuncSetAttribute((const void*)bgemm_kernel<MODE, XLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
-    const int grid = n_items < 256 ? n_items : 256;
-    hipLaunchKernelGGL((bgemm_kernel<MODE, XLDS>), dim3(grid), dim3(512), lds, s, a, n_items);
-    VILA_LAUNCH_CHECK();
-    return 0;
-}
-
 // ---- the weight stream through LDS (the kernel the step uses) ------------------------------------------------------------------------
 // The MFMA operand layout (lane = row & 15, 16 B per lane) is the wrong shape to LOAD in: one instruction touches 16 rows x 64 B, every
 // 128-B line is fetched by two instructions, and with 8 waves x 16+ loads in flight the second one no longer finds it in the 32-KB vector
-// cache (tools/exp/stream_bench.hip: 4.5 TB/s, 5.5 without the streaming hint; the register kernel above reaches 3.5-3.9).  Whole lines —
+// cache (tools/exp/stream_bench.hip: 4.5 TB/s, 5.5 without the streaming hint; the round's first kernel, which loaded that way, reached 3.5-3.9).  Whole lines —
 // 8 adjacent lanes x 16 B = one 128-B line, 8 rows per instruction — stream at 6.2 TB/s, but put a row's chunks in 8 different lanes.
 // So the lines go through LDS: `global_load_lds` (no VGPRs, lane-linear 1-KB image per instruction) with the XOR swizzle applied to the
 // SOURCE chunk (slot s of row r holds chunk s ^ ((r >> 1) & 7)), and ds_read_b128 hands each lane its operand (conflict-free under
@@ -432,44 +247,23 @@ static int launch_bgemm_dma_t(const BGemmArgs& a, int n_items, hipStream_t s) {
     VILA_LAUNCH_CHECK();
     return 0;
 }
-static int bdec_use_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_BDEC"); v = (e != nullptr && strcmp(e, "v1") == 0) ? 1 : 0; }
-    return v;
-}
 
 static int launch_bgemm(const BGemmArgs& a, hipStream_t s) {
     VILA_REQUIRE(a.n >= 1 && a.n <= 16, "batched decode: 1..16 sequences (got %d)", a.n);
     VILA_REQUIRE(a.K % 64 == 0 && a.K > 0 && a.N > 0, "batched decode GEMM: K (%d) must be a positive multiple of 64", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0 && (uintptr_t)a.x % 16 == 0 && a.ldx % 8 == 0, "batched decode GEMM: operand alignment");
-    if (!bdec_use_v1()) {
-        VILA_REQUIRE(a.norm_w == nullptr, "batched decode GEMM: the RMSNorm in front is its own launch on this path");
-        const bool x8 = a.n <= 8;
-        if (a.mode == 1) {
-            VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr, "batched decode GEMM: gate/up needs W2 and a bf16 output");
-            return x8 ? launch_bgemm_dma_t<1, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<1, 16>(a, cdiv(a.N, 16), s);
-        }
-        if (a.mode == 2) {
-            VILA_REQUIRE(a.hd % 32 == 0 && a.N == (a.nq + 2 * a.nkv) * a.hd && a.q_out && a.kcache && a.vcache && a.pos && a.rope_cs,
-                         "batched decode GEMM: qkv mode needs head_dim %% 32 == 0 and its outputs");
-            const int items = (a.nq + 2 * a.nkv) * (a.hd / 32);
-            return x8 ? launch_bgemm_dma_t<2, 8>(a, items, s) : launch_bgemm_dma_t<2, 16>(a, items, s);
-        }
-        return x8 ? launch_bgemm_dma_t<0, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<0, 16>(a, cdiv(a.N, 16), s);
-    }
-    const bool xlds = a.K <= 3832;
-    VILA_REQUIRE(xlds || a.norm_w == nullptr, "batched decode GEMM: a fused RMSNorm needs K <= 3832 (got %d)", a.K);
+    const bool x8 = a.n <= 8;
     if (a.mode == 1) {
         VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr, "batched decode GEMM: gate/up needs W2 and a bf16 output");
-        return xlds ? launch_bgemm_t<1, true>(a, cdiv(a.N, 16), s) : launch_bgemm_t<1, false>(a, cdiv(a.N, 16), s);
+        return x8 ? launch_bgemm_dma_t<1, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<1, 16>(a, cdiv(a.N, 16), s);
     }
     if (a.mode == 2) {
         VILA_REQUIRE(a.hd % 32 == 0 && a.N == (a.nq + 2 * a.nkv) * a.hd && a.q_out && a.kcache && a.vcache && a.pos && a.rope_cs,
                      "batched decode GEMM: qkv mode needs head_dim %% 32 == 0 and its outputs");
         const int items = (a.nq + 2 * a.nkv) * (a.hd / 32);
-        return xlds ? launch_bgemm_t<2, true>(a, items, s) : launch_bgemm_t<2, false>(a, items, s);
+        return x8 ? launch_bgemm_dma_t<2, 8>(a, items, s) : launch_bgemm_dma_t<2, 16>(a, items, s);
     }
-    return xlds ? launch_bgemm_t<0, true>(a, cdiv(a.N, 16), s) : launch_bgemm_t<0, false>(a, cdiv(a.N, 16), s);
+    return x8 ? launch_bgemm_dma_t<0, 8>(a, cdiv(a.N, 16), s) : launch_bgemm_dma_t<0, 16>(a, cdiv(a.N, 16), s);
 }
 
 // ---- per-row prologue / pick / advance -------------------------------------------------------------------------------------------
@@ -515,11 +309,171 @@ __global__ __launch_bounds__(1024) void bdec_pick_kernel(const float* __restrict
     }
 }
 
+// ---- attention of the batch: one block per (kv head, 256-key slice, sequence) -------------------------------------------------------------
+// The batch-1 kernel (gemv.hip attn_decode_head) gives every QUERY head its own block, so the 7 heads of a GQA group each pull the same
+// K/V rows through L2, and a row's whole context is one block's serial loop (19.6 us per layer at 8 x 1045 keys).  Here the K/V chunk a
+// wave loads (16 keys) serves all G query heads of its kv head (scores on the matrix core: S[16 keys][16 heads] = K . Q^T in 4 MFMAs; P.V on
+// the VALU with the probabilities fetched by DPP row broadcasts, reductions by row swaps — the __shfl_xor formulation, 30 ds_bpermute per
+// head, took 69 us), a slice is one chunk per wave (no loop), and the slices are merged by a second small launch.  Merging inside the launch
+// (last-arriving block, agent-scope release/acquire by one lane) measured the same 16-17 us total and needs counters; with EVERY wave
+// fencing it was 59 us (an agent fence is an L2 write-back + invalidate on this multi-XCD part).
+// sum over lane l and lane l ^ 16 (resp. l ^ 32) with gfx950's row swaps (see attn_common.h xor16_max): no LDS crossbar, no lgkmcnt
+__device__ __forceinline__ float bd_xor16_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float bd_xor32_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+struct BAttnArgs {
+    const bf16_t* q; bf16_t* o;                 // [rows][nq*128]
+    const bf16_t* kcache; const bf16_t* vcache; // this layer's [slots][nkv][max_ctx][128]
+    const int32_t* pos;                         // [rows]: keys 0 .. pos inclusive
+    float* part_o; float* part_ml;              // [rows][nkv][NSL][G][128], [rows][nkv][NSL][G][2]
+    int nq, nkv, max_ctx, nsl; int64_t row_stride, slot_stride; float scale;
+};
+template <int G>
+__global__ __launch_bounds__(1024) void bdec_attn_kernel(BAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* so = (float*)smem;                   // [16 waves][G][128]
+    float* sml = so + 16 * G * 128;             // [16][G][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kvh = blockIdx.x, slice = blockIdx.y, row = blockIdx.z;
+    const int nkeys_all = p.pos[row] + 1;
+    const int active = (nkeys_all + 255) >> 8;
+    if (slice >= active) return;                                 // block-uniform
+    const int key_lo = slice * 256;
+    const int nkeys = nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256;
+    const bf16_t* kb = p.kcache + (int64_t)row * p.slot_stride + (int64_t)kvh * p.max_ctx * 128;
+    const bf16_t* vb = p.vcache + (int64_t)row * p.slot_stride + (int64_t)kvh * p.max_ctx * 128;
+    const bf16_t* qrow = p.q + (int64_t)row * p.row_stride + kvh * G * 128;
+    const int l15 = lane & 15, lg = lane >> 4;      // scores: MFMA A rows = keys, B rows = query heads; C: key lg*4 + r, head l15
+    const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup (= the C layout's row group), d chunk
+    // the wave's 16 keys: everything is issued before anything is used
+    const int k0 = key_lo + wave * 16;
+    u32x4 kc[4], qc[4], vc[4];
+    {
+        const int key = k0 + l15;
+        const bool kok = key < nkeys, qok = l15 < G;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kc[ks] = kok ? *(const u32x4*)(kb + (int64_t)key * 128 + ks * 32 + lg * 8) : (u32x4){0u, 0u, 0u, 0u};
+            qc[ks] = qok ? *(const u32x4*)(qrow + l15 * 128 + ks * 32 + lg * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int vk = k0 + sg * 4 + j;
+            vc[j] = (vk < nkeys) ? *(const u32x4*)(vb + (int64_t)vk * 128 + dc * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    // S[key][head] on the matrix core: 4 MFMAs replace G x (64 FMAs + a 4-lane reduction)
+    f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kc[ks]), __builtin_bit_cast(bf16x8, qc[ks]), sc, 0, 0, 0);
+    float pr[4], m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = (k0 + lg * 4 + r < nkeys) ? sc[r] * p.scale : -INFINITY; m = fmaxf(m, pr[r]); }
+    m = xor32_max(xor16_max(m));                                 // over the 16 keys of the chunk (lanes l15, l15 + 16, + 32, + 48)
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = (m == -INFINITY) ? 0.f : __expf(pr[r] - m); l += pr[r]; }
+    l = bd_xor32_sum(bd_xor16_sum(l));
+    if (lg == 0 && l15 < G) { sml[(wave * G + l15) * 2] = m; sml[(wave * G + l15) * 2 + 1] = l; }
+    // P.V on the VALU: the probability of (key sg*4 + j, head g) sits in lane 16*sg + g, register j — one DPP row broadcast away
+    static_for<0, G>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pj = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(pr[j]), 0x150 + g, 0xf, 0xf, false));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] = fmaf(pj, lo_bf(vc[j][e]), o[2 * e]);
+                o[2 * e + 1] = fmaf(pj, hi_bf(vc[j][e]), o[2 * e + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bd_xor32_sum(bd_xor16_sum(o[e]));
+        if (sg == 0) {
+            float* dst = so + (wave * G + g) * 128 + dc * 8;
+            *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
+            *(f32x4*)(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        }
+    });
+    __syncthreads();
+    // ---- the 16 waves' partials -> the slice's partial ----
+    const int64_t pbase = ((int64_t)(row * p.nkv + kvh) * p.nsl + slice) * G;
+    const int g = tid >> 7, d = tid & 127;
+    if (g < G) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) M = fmaxf(M, sml[(w * G + g) * 2]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float mw = sml[(w * G + g) * 2];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            L = fmaf(sml[(w * G + g) * 2 + 1], f, L);
+            O = fmaf(so[(w * G + g) * 128 + d], f, O);
+        }
+        p.part_o[(pbase + g) * 128 + d] = O;
+        if (d == 0) { p.part_ml[(pbase + g) * 2] = M; p.part_ml[(pbase + g) * 2 + 1] = L; }
+    }
+}
+// the slices of a (sequence, query head) -> the bf16 attention output; the launch boundary is the publish (no fences)
+__global__ __launch_bounds__(128) void bdec_attn_merge_kernel(BAttnArgs p, int G) {
+    const int h = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+    const int kvh = h / G, g = h % G;
+    const int active = (p.pos[row] + 1 + 255) >> 8;
+    const int64_t b0 = (int64_t)(row * p.nkv + kvh) * p.nsl * G;
+    float M = -INFINITY;
+    for (int sl = 0; sl < active; ++sl) M = fmaxf(M, p.part_ml[(b0 + sl * G + g) * 2]);
+    float L = 0.f, O = 0.f;
+    for (int sl = 0; sl < active; ++sl) {
+        const float f = __expf(p.part_ml[(b0 + sl * G + g) * 2] - M);
+        L = fmaf(p.part_ml[(b0 + sl * G + g) * 2 + 1], f, L);
+        O = fmaf(p.part_o[(b0 + sl * G + g) * 128 + d], f, O);
+    }
+    p.o[(int64_t)row * p.row_stride + h * 128 + d] = f2bf(O / L);
+}
+template <int G>
+static int launch_bdec_attn_t(const BAttnArgs& a, int rows, hipStream_t s) {
+    const size_t lds = (size_t)(16 * G * 128 + 16 * G * 2) * 4;
+    static bool attr = false;
+    if (!attr) {
+        VILA_HIP(hipFuncSetAttribute((const void*)bdec_attn_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((bdec_attn_kernel<G>), dim3(a.nkv, a.nsl, rows), dim3(1024), lds, s, a);
+    VILA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bdec_attn_merge_kernel, dim3(a.nq, rows), dim3(128), 0, s, a, G);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+// returns 1 when the GQA group size has no instantiation (the caller falls back to the per-head kernel)
+static int launch_bdec_attn(const BAttnArgs& a, int rows, hipStream_t s) {
+    switch (a.nq / a.nkv) {
+        case 1: return launch_bdec_attn_t<1>(a, rows, s);
+        case 2: return launch_bdec_attn_t<2>(a, rows, s);
+        case 4: return launch_bdec_attn_t<4>(a, rows, s);
+        case 7: return launch_bdec_attn_t<7>(a, rows, s);
+        case 8: return launch_bdec_attn_t<8>(a, rows, s);
+        default: return 1;
+    }
+}
+
 // ---- the step ---------------------------------------------------------------------------------------------------------------------
 size_t bdecode_workspace_bytes(int H, int F, int QS, int hd, int n) {
     size_t b = 0;
     b += 3 * align_up((size_t)n * H * 2, 256) + 2 * align_up((size_t)n * QS * 2, 256) + align_up((size_t)n * F * 2, 256);
     b += align_up((size_t)n * hd * 4, 256);
+    b += align_up((size_t)n * (QS / hd) * 8 * (hd + 2) * 4, 256) + 256;   // attention slice partials
     return b + 4096;
 }
 
@@ -535,17 +489,19 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
     bf16_t* x = (bf16_t*)take((size_t)n * H * 2);
     bf16_t* x2 = (bf16_t*)take((size_t)n * H * 2);
     bf16_t* xn = (bf16_t*)take((size_t)n * H * 2);           // the normalised activations in front of qkv / gate-up / lm_head
-    const bool fused_norm = bdec_use_v1() != 0;              // (the register kernel stages the activations itself and norms them on the way)
     auto normed = [&](BGemmArgs& g, const bf16_t* src, const void* w) -> int {
-        if (fused_norm) { g.x = src; g.norm_w = (const bf16_t*)w; g.eps = m.rms_eps; return 0; }
         VILA_TRY(launch_rmsnorm(src, (const bf16_t*)w, xn, n, H, m.rms_eps, s));
-        g.x = xn; g.norm_w = nullptr;
+        g.x = xn;
         return 0;
     };
     bf16_t* q = (bf16_t*)take((size_t)n * QS * 2);
     bf16_t* ao = (bf16_t*)take((size_t)n * QS * 2);
     bf16_t* act = (bf16_t*)take((size_t)n * F * 2);
     float* rope_cs = (float*)take((size_t)n * hd * 4);
+    const int nsl = cdiv(max_ctx, 256);
+    float* part_o = (float*)take((size_t)n * m.q_heads * nsl * hd * 4);
+    float* part_ml = (float*)take((size_t)n * m.q_heads * nsl * 2 * 4);
+    VILA_REQUIRE(off <= workspace_bytes, "batched decode: workspace layout");
     hipLaunchKernelGGL(bdec_prologue_kernel, dim3(cdiv(H / 8, 256), n), dim3(256), 0, s, (const bf16_t*)m.embed, token, x, H, (int64_t)m.vocab, pos, rope_cs, hd, m.rope_theta);
     VILA_LAUNCH_CHECK();
     const int64_t per_layer = (int64_t)n_slots * m.kv_heads * max_ctx * hd, slot_stride = (int64_t)m.kv_heads * max_ctx * hd;
@@ -562,7 +518,12 @@ int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf1
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.pos_ptr = pos; ad.nq = m.q_heads; ad.nkv = m.kv_heads; ad.hd = hd; ad.max_ctx = max_ctx;
         ad.n_splits = cdiv(max_ctx, 64); ad.scale = 1.0f / sqrtf((float)hd);
-        VILA_TRY(launch_attn_decode_rows(ad, n, QS, QS, slot_stride, s));
+        BAttnArgs ba{};
+        ba.q = q; ba.o = ao; ba.kcache = kc; ba.vcache = vc; ba.pos = pos; ba.part_o = part_o; ba.part_ml = part_ml;
+        ba.nq = m.q_heads; ba.nkv = m.kv_heads; ba.max_ctx = max_ctx; ba.nsl = nsl; ba.row_stride = QS; ba.slot_stride = slot_stride; ba.scale = ad.scale;
+        const int rc = (m.q_heads % m.kv_heads == 0) ? launch_bdec_attn(ba, n, s) : 1;
+        if (rc < 0) return rc;
+        if (rc == 1) VILA_TRY(launch_attn_decode_rows(ad, n, QS, QS, slot_stride, s));       // group size without an instantiation: one block per query head
         BGemmArgs o{};
         o.x = ao; o.ldx = QS; o.W = (const bf16_t*)L.wo; o.residual = cur; o.ldr = H; o.y = nxt; o.ldy = H; o.n = n; o.N = H; o.K = QS; o.mode = 0;
         VILA_TRY(launch_bgemm(o, s));
