@@ -25,6 +25,8 @@ import json; d=json.loads(open('$O/ex_$e.json').read().strip().splitlines()[-1])
 import json; d=json.loads(open('$O/batch_$b.json').read().strip().splitlines()[-1]); print('batch $b: aggregate', d['value'], 'tok/s  ms/step', d['ms_per_step'], 'hbm frac', d['roofline']['frac'])" || tail -3 "$O/batch_$b.err"; done ;;
   prof_batch) timeout 600 bash tools/profile.sh batch8 --batch 8 --steps 32 --warmup 4 | tail -2
              python tools/rocpd_summary.py "$GRAFT_REPO_ROOT/gpurun_out/prof_batch8/trace_results.db" "$O/batch8_kernel_stats.csv"; head -14 "$O/batch8_kernel_stats.csv"; rm -f "$GRAFT_REPO_ROOT/gpurun_out/prof_batch8/trace_results.db" ;;
+  tower)     cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/prof_tower" -o trace -- python "$GRAFT_REPO_ROOT/tools/microbench.py" tower 2>&1 | grep -i "tower" ; cd "$GRAFT_REPO_ROOT"
+             python tools/rocpd_summary.py "$O/prof_tower/trace_results.db" "$O/tower_kernel_stats.csv"; head -16 "$O/tower_kernel_stats.csv"; rm -f "$O/prof_tower/trace_results.db" ;;
   batch_test) timeout 900 python -m pytest tests/test_gpu_batch_decode.py -m gpu -q 2>&1 | tail -8 ;;
   tests_new) timeout 1200 python -m pytest tests/test_gpu_baseline_configs.py tests/test_dynamic_s2.py tests/test_gpu_sampling.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_new.log"; tail -30 "$O/pytest_new.log" ;;
   tests_ops) timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -m gpu -q 2>&1 | tail -30 > "$O/pytest_ops.log"; tail -30 "$O/pytest_ops.log" ;;

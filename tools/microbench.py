@@ -132,6 +132,19 @@ def bench_attn_bwd():
         print(f"n={n:5d} x{nseq:3d} Hq={Hq} Hkv={Hkv} D={D} causal={causal}: bwd {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s   (fwd {tf*1e6:8.1f} us  {0.4*fl/tf/1e12:7.1f} TF/s)")
 
 
+def bench_tower():
+    """The SigLIP tower + projector of NVILA-8B on 1 / 8 images, weights read cold every pass (0.8 GB > the 256-MB infinity cache)."""
+    from vila_amd import configs
+    from vila_amd.vlm import build_model
+    cfg = configs.nvila_8b()
+    cfg.llm.num_hidden_layers = 1
+    m = build_model(cfg, seed=0)
+    for n in (1, 8):
+        px = torch.randn(n, 3, 448, 448, device="cuda").to(torch.bfloat16)
+        t = timeit(lambda: m.encode_images(px), iters=10, warm=2)
+        print(f"tower+projector, {n} image(s): {t*1e3:8.3f} ms")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(torch.cuda.get_device_name(0))
@@ -147,5 +160,7 @@ if __name__ == "__main__":
         bench_w4()
     if what in ("attn", "all"):
         bench_attn()
+    if what in ("tower",):
+        bench_tower()
     if what in ("attn_bwd", "all"):
         bench_attn_bwd()

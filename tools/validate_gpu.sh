@@ -31,6 +31,16 @@ for line in open("gpurun_out/val_other_modes.jsonl"):
     except Exception as e:
         print("bad line", e)
 P
+: > "$O/val_batch_decode.jsonl"
+for b in 2 4 8 16; do
+  timeout 300 python bench.py --batch $b --steps 32 --warmup 4 2>>"$O/val_batch_decode.err" | tail -1 >> "$O/val_batch_decode.jsonl"
+done
+python -c "
+import json
+for line in open('gpurun_out/val_batch_decode.jsonl'):
+    d = json.loads(line); print('batch decode', d['config']['workload'][:40], '|', d['value'], d['unit'], '| ms/step', d['ms_per_step'])
+"
+timeout 400 python bench.py --mode sft --dynamic-s2 --micro-batch 1 --steps 3 --warmup 1 2>"$O/val_sft_s2.err" | tee "$O/val_sft_s2.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft dynamic_s2 ->', d['ms_per_step'], 'ms')"
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tail -1
 cp "$O/pmc_mfma_val_sft/summary.txt" "$O/val_pmc_mfma_sft_step.txt" 2>/dev/null

@@ -77,6 +77,9 @@ int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* b
 // =================================================================================================
 static inline int vit_kp(const VilaVitShape* s) { return (int)align_up((size_t)s->channels * s->patch * s->patch, 8); }
 
+// fc2 (K = 4304) of one or two images is 20-40 tiles of 256^2: its weights arrive cold from HBM and a tile's K loop runs at memory latency,
+// so it is sliced over K (8 slices of one image: 45.6 -> 33.7 us, tools/gemm_bench precold); beyond 2048 rows the tiles fill the chip
+static size_t vit_splitk_rows(size_t M) { return M <= 2048 ? M : 0; }
 extern "C" size_t vila_vit_workspace_bytes(const VilaVitShape* s, int n_images) {
     const size_t g = s->image / s->patch, M = (size_t)n_images * g * g, D = s->hidden, F = s->inter, Kp = vit_kp(s);
     size_t b = 0;
@@ -84,6 +87,7 @@ extern "C" size_t vila_vit_workspace_bytes(const VilaVitShape* s, int n_images) 
     b += 2 * align_up(M * D * 2, 256);                               // x, h
     b += align_up(M * 3 * D * 2, 256);                               // qkv
     b += align_up(M * F * 2, 256);                                   // mlp hidden
+    b += align_up(vit_splitk_rows(M) * D * 4 * 8, 256);              // fp32 K-slices of fc2 when its 256^2 tiles cannot fill the chip
     return b + 4096;
 }
 
@@ -104,6 +108,8 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
     bf16_t* h = a.take<bf16_t>((size_t)M * D);
     bf16_t* qkv = a.take<bf16_t>((size_t)M * 3 * D);
     bf16_t* f = a.take<bf16_t>((size_t)M * F);
+    const size_t sk_bytes = vit_splitk_rows(M) * D * 4 * 8;
+    float* skws = sk_bytes ? a.take<float>(sk_bytes / 4) : nullptr;
     VILA_REQUIRE(a.ok(), "vit: workspace arena overflow");
 
     // a2: patch embed = im2col + ONE GEMM over all images (+bias) with the position embedding as a periodic residual operand
@@ -137,7 +143,7 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
         VILA_TRY(gemm(h, D, L.wo, D, L.bo, x, D, x, D, M, D, D, EPI_NONE, s));               // x += out_proj(attn)
         VILA_TRY(launch_layernorm(x, B(L.ln2_w), B(L.ln2_b), h, M, D, sh.ln_eps, s));
         VILA_TRY(gemm(h, D, L.fc1_w, D, L.fc1_b, nullptr, 0, f, F, M, F, D, EPI_GELU_TANH, s));
-        VILA_TRY(gemm(f, F, L.fc2_w, F, L.fc2_b, x, D, xo, D, M, D, F, EPI_NONE, s));        // x += fc2(gelu(fc1))
+        VILA_TRY(gemm(f, F, L.fc2_w, F, L.fc2_b, x, D, xo, D, M, D, F, EPI_NONE, s, nullptr, 0, skws, sk_bytes));   // x += fc2(gelu(fc1))
     }
     return 0;
 }

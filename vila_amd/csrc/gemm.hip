@@ -236,7 +236,10 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (splits >= 2) splits = cdiv(kt, cdiv(kt, splits));      // drop empty trailing slices
         if (splits < 2) splits = 0;
         // K < 8192 (o_proj at S = 769): the DMA ring below does it in one launch at 557 TF/s vs 482 incl. the reduce
-        if (kt < 128 && sel == 0) splits = 0;
+        // ... unless the slices are many and still long (ViT fc2 of one image, K = 4304: 20 tiles x 8 slices; with COLD weights — what a
+        // forward pass sees — 45.6 -> 33.7 us, tools/gemm_bench precold; the warm numbers above hide that a lone tile's K loop runs at
+        // HBM latency)
+        if (kt < 128 && sel == 0 && !(kt >= 64 && splits >= 6)) splits = 0;
         // measured at M = 769 (tools/microbench.py prefill): N=3584,K=18944 233 -> 122 us; N=3584,K=3584 51 -> 41 us;
         // N=4608 (72 tiles) only breaks even, so require at least 4 slices
         if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);

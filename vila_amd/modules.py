@@ -640,7 +640,7 @@ class HipQwen2ForCausalLM(_HipModule):
         if cache.max_ctx < S + max_new_tokens:
             raise ValueError(f"KV cache too small: {cache.max_ctx} < {S} + {max_new_tokens}")
         pos = torch.arange(S, device=dev, dtype=torch.int32)
-        last = torch.tensor([S - 1], device=dev, dtype=torch.int32)
+        last = torch.full((1,), S - 1, device=dev, dtype=torch.int32)          # (a fill kernel, not a host copy)
         r = self.prefill_packed(x.to(self.dtype), pos, None, S, cache=cache, last_rows=last)
         st = self._decode_session(cache, max_new_tokens, sampling)
         # the sampler mixes a device counter into its random number: the decode steps use the position of the token they consume

@@ -206,12 +206,42 @@ class HipLlavaLlamaModel(nn.Module):
         S = plan.S
         out = torch.zeros((B * S, H), device=dev, dtype=self.dtype)
         table = self.llm.model.embed_tokens.weight
-        ops.copy_rows(table, out, plan.txt_src.to(dev), plan.txt_dst.to(dev), int(plan.txt_src.numel()))
+        # the plan's index tensors go back in ONE pinned, non-blocking copy: the host never waits for the tower here, so the splice and the
+        # prefill are enqueued behind it without a gap (six pageable .to(dev) calls each blocked until the stream reached them: ~0.5 ms of idle
+        # GPU in the round-2 TTFT timeline)
+        mask_all = bool(plan.mask.all())
+        txt_src, txt_dst, img_src, img_dst, labels_d, mask_d = self._plan_to_device(
+            [plan.txt_src, plan.txt_dst, plan.img_src, plan.img_dst, plan.labels, plan.mask], dev)
+        ops.copy_rows(table, out, txt_src, txt_dst, int(plan.txt_src.numel()))
         blocks = [m for n in tok_ids for m in embeds.get(n, [])]
         if blocks:
             flat = (blocks[0] if len(blocks) == 1 else torch.cat(blocks, 0)).to(self.dtype)
-            ops.copy_rows(flat, out, None if plan.img_src_identity else plan.img_src.to(dev), plan.img_dst.to(dev), int(plan.img_dst.numel()))
-        return out.view(B, S, H), plan.labels.to(dev), plan.mask.to(dev)
+            ops.copy_rows(flat, out, None if plan.img_src_identity else img_src, img_dst, int(plan.img_dst.numel()))
+        mask_d._vila_all_true = mask_all               # host knowledge for generate(): no device round trip to learn that nothing is padded
+        return out.view(B, S, H), labels_d, mask_d
+
+    def _plan_to_device(self, tensors, dev):
+        """Host tensors -> device tensors of the same dtype / shape through one cached pinned staging buffer and ONE non-blocking copy."""
+        offs, n = [], 0
+        for t in tensors:
+            n = (n + 15) & ~15
+            offs.append(n)
+            n += t.numel() * t.element_size()
+        n = max((n + 15) & ~15, 16)
+        pin = getattr(self, "_plan_pin", None)
+        if pin is None or pin.numel() < n:
+            pin = self._plan_pin = torch.empty((max(n, 1 << 16),), dtype=torch.uint8, pin_memory=True)
+            self._plan_ev = None
+        if getattr(self, "_plan_ev", None) is not None:
+            self._plan_ev.synchronize()                # the previous call's copy has left the staging buffer
+        for t, o in zip(tensors, offs):
+            nb = t.numel() * t.element_size()
+            if nb:
+                pin[o:o + nb].copy_(t.contiguous().reshape(-1).view(torch.uint8))
+        d = pin[:n].to(dev, non_blocking=True)
+        self._plan_ev = torch.cuda.Event()
+        self._plan_ev.record()
+        return [d[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(tensors, offs)]
 
     def enable_autograd(self, use_c_abi: Optional[bool] = None, group=None):
         """Make the reference's own training call site work after the swap (llava/train/transformer_normalize_monkey_patch.py
@@ -251,6 +281,8 @@ class HipLlavaLlamaModel(nn.Module):
                  media_config: Optional[Dict[str, Dict[str, Any]]] = None, attention_mask: Optional[torch.Tensor] = None,
                  **generation_kwargs):
         inputs_embeds, _, attention_mask = self._embed(input_ids, media, media_config, None, attention_mask)
+        if getattr(attention_mask, "_vila_all_true", False):
+            attention_mask = None                      # nothing is padded: the LLM need not compact rows (a device round trip) before the prefill
         return self.llm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, **generation_kwargs)
 
 
