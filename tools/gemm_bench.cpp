@@ -195,12 +195,12 @@ int main(int argc, char** argv) {
         };
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
     }
-    if (!strcmp(what, "precold")) {    // the same question with COLD weights (what a forward pass sees), one and eight images, S = 1045 prefill
+    if (!strcmp(what, "precold")) {    // the same question with COLD weights (what a forward pass sees), one and eight images, S = 769 prefill
         g_cold = 1;
         std::vector<Case> pc = {
             {"ViT qkv  M=1024 cold", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res cold", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc1 cold", 1024, 4304, 1152, 0, 0, 0},
             {"ViT fc2+res cold", 1024, 1152, 4304, 0, 0, 1},
-            {"LLM qkv  S=1045 cold", 1045, 4608, 3584, 0, 0, 0}, {"LLM o+res S=1045 cold", 1045, 3584, 3584, 0, 0, 1},
+            {"LLM qkv  S=769 cold", 769, 4608, 3584, 0, 0, 0}, {"LLM o+res S=769 cold", 769, 3584, 3584, 0, 0, 1},
             {"ViT qkv  M=8192 cold", 8192, 3456, 1152, 0, 0, 0}, {"ViT fc1 M=8192 cold", 8192, 4304, 1152, 0, 0, 0}, {"ViT fc2 M=8192 cold", 8192, 1152, 4304, 0, 0, 1},
         };
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);

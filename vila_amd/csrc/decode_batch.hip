@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void bdec_pick_kernel(const float* __restrict
 
 // ---- attention of the batch: one block per (kv head, 256-key slice, sequence) -------------------------------------------------------------
 // The batch-1 kernel (gemv.hip attn_decode_head) gives every QUERY head its own block, so the 7 heads of a GQA group each pull the same
-// K/V rows through L2, and a row's whole context is one block's serial loop (19.6 us per layer at 8 x 1045 keys).  Here the K/V chunk a
+// K/V rows through L2, and a row's whole context is one block's serial loop (19.6 us per layer at 8 x ~800 keys).  Here the K/V chunk a
 // wave loads (16 keys) serves all G query heads of its kv head (scores on the matrix core: S[16 keys][16 heads] = K . Q^T in 4 MFMAs; P.V on
 // the VALU with the probabilities fetched by DPP row broadcasts, reductions by row swaps — the __shfl_xor formulation, 30 ds_bpermute per
 // head, took 69 us), a slice is one chunk per wave (no loop), and the slices are merged by a second small launch.  Merging inside the launch

@@ -483,7 +483,7 @@ class HipQwen2ForCausalLM(_HipModule):
         Bn, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
         return (not do_sample and forced_ids is None and not return_logits and cache is None and getattr(self, "_w4", None) is None and
                 2 <= Bn <= 16 and c.head_dim == 128 and c.hidden_size % 64 == 0 and c.intermediate_size % 64 == 0 and
-                c.hidden_size <= 3832 and ((S + max_new_tokens + 255) // 256) * 256 <= 2048)
+                ((S + max_new_tokens + 255) // 256) * 256 <= 2048)
 
     def _batch_session(self, n: int, max_ctx: int, max_new_tokens: int):
         key = (n, max_ctx, max_new_tokens, self.model.embed_tokens.weight.data_ptr(), _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr())
