@@ -326,12 +326,26 @@ def sft_flops_per_sample(cfg, S: int, n_targets: int = 256) -> float:
     return 3.0 * fwd
 
 
+def _sft_gemm_traffic():
+    """L2-fill bytes per GEMM of the contraction-major (wgrad) kernel on the four decoder shapes of the step, from the committed rocprofv3 --pmc
+    passes (tools/pmc_gemm_sft.sh -> profiles/r03_pmc_gemm_sft.json; cannot be collected inside this process), next to the algorithmic bytes."""
+    tj = os.path.join(ROOT, "profiles", "r03_pmc_gemm_sft.json")
+    if not os.path.exists(tj):
+        return None
+    with open(tj) as f:
+        d = json.load(f)
+    return {"kernel": "gemm256_kernel<0,0,true,true,7,256> (wgrad, operands as they lie)",
+            "per_gemm": {k: {"traffic_bytes": v.get("traffic_bytes"), "algorithmic_bytes": v.get("algorithmic_bytes"), "ratio": v.get("traffic_over_algorithmic")}
+                         for k, v in d.items()},
+            "source": "profiles/r03_pmc_gemm_sft.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per shape, FETCH x2 on gfx950; L2 fills, i.e. incl. what the infinity cache serves)"}
+
+
 def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: float, tflop_per_sample: float = SFT_TFLOP_PER_SAMPLE):
     step_s = elapsed / steps
     flops = tflop_per_sample * 1e12 * b
     return {"ms_per_step": round(step_s * 1e3, 2), "tokens_per_s": round(world * b * S / step_s, 1), "steps": steps, "micro_batch": b, "loss": round(loss, 4),
             "roofline": {"bound": "mfma", "achieved": round(flops / step_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(flops / step_s / (MFMA_PEAK_TF * 1e12), 4), "traffic": None,
+                         "frac": round(flops / step_s / (MFMA_PEAK_TF * 1e12), 4), "traffic": _sft_gemm_traffic(),
                          "note": f"whole step incl. optimizer; {tflop_per_sample:.1f} TFLOP per {S}-token sample fwd+bwd (SURVEY §8d), no activation recompute; "
                                  "max_grad_norm = None (scripts/NVILA-Lite/sft.sh sets no clipping)"}}
 
@@ -628,7 +642,7 @@ def decode_main(a, rank, world, dev, dist):
     # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
     # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic, traffic_src = None, None
-    for tj_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tj_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tj = os.path.join(ROOT, "profiles", tj_name)
         if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
             with open(tj) as f:

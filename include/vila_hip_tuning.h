@@ -22,6 +22,9 @@ void vila_gemm_force_tile(int tile);
 /* leftover rows (M = 256 k + r, 1 <= r <= 16) as an extra fragment of the last 256-row tile (gemm256_kernel.h, EX): -1 = VILA_GEMM_EX from the
  * environment (default 1), 0 = off, 1 = when it saves a round of tiles (and in every K-sliced launch), 2 = whenever the rows fit (tests) */
 void vila_gemm_force_ex(int mode);
+/* tile order of the 256-wide kernel (gemm256_kernel.h gemm256_tile_of): -1 = automatic (columns grouped by 4 when the grid has more than 16
+ * row tiles), 0 = row-tile-fastest everywhere (rounds 1-2), n > 1 = groups of n columns */
+void vila_gemm_force_group(int grp);
 #ifdef __cplusplus
 }
 #endif

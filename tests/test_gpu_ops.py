@@ -405,6 +405,45 @@ def test_gemm_whole_rounds_plus_sliced_tail_tiles(ops):
     assert rel_l2(dx, dyy.float() @ ww.float() + r2.float()) < 4e-3
 
 
+@pytest.mark.parametrize("grp", [-1, 4, 3, 2, 0])
+def test_gemm256_grouped_tile_order_is_a_bijection_on_ragged_grids(ops, grp):
+    """Round 3: tiles are walked in 8 x 4 patches per XCD (columns grouped by `grp`, gemm256_kernel.h gemm256_tile_of) instead of 32 x 1 strips.
+    Every order must still produce every output tile exactly once: ragged grids (19 row tiles x 4 column tiles with a 232-wide last column — the
+    last group is narrower than grp = 3), forward and contraction-major layouts, and the whole-rounds + K-sliced-tail launch whose reduce kernel
+    decodes tile ids with the same function (350 tiles = 256 + 94)."""
+    from vila_amd import _lib
+    lib = _lib.load()
+    M, N, K = 4616, 1000, 320
+    a, w = randn_bf16(M, K, seed=91), randn_bf16(N, K, seed=92, scale=K ** -0.5)
+    res = randn_bf16(M, N, seed=93)
+    ref = a.float() @ w.float().t() + res.float()
+    lib.vila_gemm_force_group(grp)
+    lib.vila_gemm_force_tile(4)
+    try:
+        out = ops.gemm(a, w, residual=res)
+        assert rel_l2(out, ref) < 4e-3, f"forward layout: {rel_l2(out, ref):.3e}"
+        lib.vila_gemm_force_tile(0)
+        at, wt = a.t().contiguous(), w.t().contiguous()                  # stored contraction-major
+        out = ops.gemm_t(at, wt, a_cm=True, b_cm=True, residual=res)
+        assert rel_l2(out, ref) < 4e-3, f"both operands contraction-major: {rel_l2(out, ref):.3e}"
+        out = ops.gemm_t(a, wt, b_cm=True, residual=res)
+        assert rel_l2(out, ref) < 4e-3, f"dgrad layout: {rel_l2(out, ref):.3e}"
+        # whole rounds + K-sliced tail tiles (needs a workspace): 70 x 5 = 350 tiles
+        M2, N2, K2 = 17920, 1032, 1024
+        a2, w2 = randn_bf16(M2, K2, seed=94), randn_bf16(N2, K2, seed=95, scale=K2 ** -0.5)
+        ws = torch.empty(8 * 96 * 65536, device="cuda", dtype=torch.float32)
+        ref2 = a2.float() @ w2.float().t()
+        out2 = ops.gemm_t(a2.t().contiguous(), w2.t().contiguous(), a_cm=True, b_cm=True, ws=ws)
+        assert rel_l2(out2, ref2) < 4e-3, f"rounds + sliced tail, contraction-major: {rel_l2(out2, ref2):.3e}"
+        assert float((out2.float() - ref2).abs().max()) < 0.25
+        lib.vila_gemm_force_tile(4)
+        out2 = ops.gemm(a2, w2, ws=ws)
+        assert rel_l2(out2, ref2) < 4e-3, f"rounds + sliced tail, forward layout: {rel_l2(out2, ref2):.3e}"
+    finally:
+        lib.vila_gemm_force_tile(0)
+        lib.vila_gemm_force_group(-1)
+
+
 @pytest.mark.parametrize("M", [257, 260, 272, 769, 3076])
 def test_gemm256_leftover_rows_ride_in_the_last_row_tile(ops, M):
     """M = 256 k + r, 1 <= r <= 16: the last 256-row tile carries the r rows as an extra 16-row fragment (gemm256_kernel.h, EX) in every

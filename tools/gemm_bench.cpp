@@ -58,17 +58,19 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
         // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
         // pseudo schedules 256 / 192: default kernels with that tile height forced (0 elsewhere = automatic)
         const bool tilef = sched >= 300 && sched < 320;          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
+        const bool grpf = sched >= 400 && sched < 420;            // pseudo schedules 400 + g: default kernels with vila_gemm_force_group(g) (0 = row-tile-fastest order)
+        vila_gemm_force_group(grpf ? sched - 400 : -1);
         const bool bmf = sched == 256 || sched == 192;
         vila_gemm_force_bm(bmf ? sched : 0);
-        const bool pol = sched >= 100 && !bmf && !tilef;
-        vila_gemm_force_sched((pol || bmf || tilef) ? 0 : sched);
+        const bool pol = sched >= 100 && !bmf && !tilef && !grpf;
+        vila_gemm_force_sched((pol || bmf || tilef || grpf) ? 0 : sched);
         vila_gemm_force_hybrid(pol ? sched == 101 : 1);
         auto call = [&]() {
             const uint16_t* w = Wc + (size_t)(ncall++ % copies) * wel;
             int rc = vila_gemm_bf16_t(A.d, lda, c.a_cm, w, ldw, c.b_cm, nullptr, c.residual ? R.d : nullptr, c.N, C, c.N, c.M, c.N, c.K, ws, ws_bytes, nullptr);
             if (rc != 0) { fprintf(stderr, "  %s sched %d: rc=%d %s\n", c.name, sched, rc, vila_last_error()); exit(3); }
         };
-        vila_gemm_force_tile(tilef ? sched - 300 : (!c.a_cm && !c.b_cm && !pol) ? 4 : 0);          // forward layout: pin the 256x256 kernel so the schedules are comparable
+        vila_gemm_force_tile(tilef ? sched - 300 : (!c.a_cm && !c.b_cm && !pol && !grpf) ? 4 : 0);          // forward layout: pin the 256x256 kernel so the schedules are comparable
         CK(hipMemset(C, 0xff, (size_t)c.M * c.N * 2));
         for (int i = 0; i < 3; ++i) call();
         CK(hipDeviceSynchronize());
@@ -106,6 +108,7 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
     vila_gemm_force_sched(0);
     vila_gemm_force_hybrid(1);
     vila_gemm_force_bm(0);
+    vila_gemm_force_group(-1);
     if (copies > 1) CK(hipFree(Wc));
     CK(hipFree(A.d)); CK(hipFree(W.d)); CK(hipFree(R.d)); CK(hipFree(C));
 }
@@ -205,6 +208,15 @@ int main(int argc, char** argv) {
         };
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
         g_cold = 0;
+    }
+    if (!strcmp(what, "grp")) {        // tile order: row-tile-fastest strips (400) vs columns grouped by 4 / 2 / 8 (8 x 4 patches per XCD)
+        for (int i : {5, 6, 7, 8, 9, 0, 2, 4}) run_case(bwd[i], {400, 404, 402, 408, 400, 404}, ws, ws_bytes);
+        for (int i : {2, 3, 5, 6}) run_case(fwd[i], {400, 404, 400, 404}, ws, ws_bytes);
+    }
+    if (!strcmp(what, "one")) {        // ONE backward shape, default kernels only: the unit of a --pmc pass (tools/pmc_gemm_sft.sh); 23 GEMM calls
+        const int idx = argc > 2 ? atoi(argv[2]) : 7;
+        if (idx < 0 || idx >= (int)bwd.size()) { fprintf(stderr, "one: index 0..%d\n", (int)bwd.size() - 1); return 2; }
+        run_case(bwd[idx], {0}, ws, ws_bytes);
     }
     if (!strcmp(what, "race")) {
         std::vector<Case> rc = {

@@ -69,13 +69,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 }
 
 // tail tiles behind whole rounds: out tile (tm, tn) = bf16(sum_s slab[s][t][256][256] + bias + residual); slab slot t holds tile id tile0 + t
-// of the tm-fastest order (the kernel indexes its slab by id - tile0, after its own XCD remap)
-__global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(const float* __restrict__ slab, int splits, int n_tail, int tile0, int tiles_m,
+// of the GEMM's tile order (the kernel indexes its slab by id - tile0, after its own XCD remap)
+__global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(const float* __restrict__ slab, int splits, int n_tail, int tile0, int tiles_m, int tiles_n, int grp,
                                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int64_t ldr,
                                                                  bf16_t* __restrict__ out, int64_t ldc, int M, int N, int res_mod) {
     const int t = blockIdx.x >> 4, part = blockIdx.x & 15;                   // 16 blocks of 16 rows per tile
     const int id = t + tile0;
-    const int m0 = (id % tiles_m) * 256, n0 = (id / tiles_m) * 256;
+    int tm, tn;
+    gemm256_tile_of(id, tiles_m, tiles_n, grp, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
     const int c = (threadIdx.x & 63) * 4;
     for (int r = part * 16 + (threadIdx.x >> 6); r < part * 16 + 16; r += 4) {
         const int gm = m0 + r, gc = n0 + c;
@@ -104,6 +106,8 @@ int launch_gemm256_cm(const GemmArgs& a, hipStream_t s);                       /
 int launch_gemm256_cm_splitk(const GemmArgs& a, int splits, float* slab, int per, hipStream_t s);
 int launch_gemm256_sched(const GemmArgs& a, int sched, hipStream_t s);
 int launch_gemm256_cm_range(const GemmArgs& a, int mode, int splits, int tile0, int n_tiles, int per, hipStream_t s);
+int g_gemm256_group = -1;           // tuning hook (vila_gemm_force_group): tile order, see gemm256_kernel.h
+extern "C" void vila_gemm_force_group(int grp) { g_gemm256_group = grp; }
 int g_gemm256_ex = -1;             // tuning hook (vila_gemm_force_ex): see gemm256_kernel.h
 extern "C" void vila_gemm_force_ex(int mode) { g_gemm256_ex = mode; }
 int g_gemm256_bm = 0;              // tuning hook (vila_gemm_force_bm): 0 = prefer_bm192's rule, 192 / 256 = force that tile height
@@ -136,7 +140,8 @@ static int try_hybrid(const GemmArgs& a, hipStream_t s) {
         VILA_TRY((launch256_t<0, EPI_NONE, false, false, T256_CC_SCHED>(a, s, 1, 0, full)));
         VILA_TRY((launch256_t<5, EPI_NONE, false, false, T256_CC_SCHED>(b, s, splits, full, tail, 0, per)));
     }
-    hipLaunchKernelGGL(splitk_tail_reduce_kernel, dim3(tail * 16), dim3(256), 0, s, a.ws, splits, tail, full, tiles_m, a.bias, a.residual, a.ldr,
+    hipLaunchKernelGGL(splitk_tail_reduce_kernel, dim3(tail * 16), dim3(256), 0, s, a.ws, splits, tail, full, tiles_m, cdiv(a.N, 256),
+                       gemm256_group(tiles_m, cdiv(a.N, 256), false), a.bias, a.residual, a.ldr,
                        (bf16_t*)a.C, a.ldc, a.M, a.N, a.res_mod);
     VILA_LAUNCH_CHECK();
     return 1;

@@ -52,8 +52,33 @@ static __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4];   /
 // wave spends 4 more MFMAs per K-tile on two of its four B fragments (wave row wr takes fragments wr and wr + 2, so the fused gate/up
 // pairing stays inside a wave).  The prompt of the benchmark is 3 x 256 + 1 tokens: without this, one row costs either a fourth row-tile
 // round or a second pass over the MLP weights through the decode GEMVs (round 1/2: 1.9 ms of an 18.4 ms TTFT).
+// ---- tile order (round 3) ---------------------------------------------------------------------------------------------------------------
+// A tile id is decoded either tm-fastest (id = tn * tiles_m + tm: the order of rounds 1-2) or GROUPED: columns in groups of `grp`, inside a
+// group tn fastest, then tm — so that the 32 tiles an XCD works on at one time (consecutive ids after xcd_remap) form an 8 x 4 patch
+// instead of a 32 x 1 strip.  Why: each XCD has its own 4-MB L2.  In a strip the 32 tiles share ONE B tile and stream 32 different A
+// tiles, and with tiles_m >> 32 nothing of A is still there when the next column comes by: the PMC counters of the SFT wgrad shapes
+// (profiles/r03_pmc_gemm_sft.txt) show A fetched from the fabric once per TILE — gate wgrad 1.74 GB of L2 fills for 138 MB of operands.
+// A patch shares every A tile 4 ways and every B tile 8 ways: (8 + 4) operand tiles per 32 instead of 33.  Both orders are bijections on
+// [0, tiles), so launches over an id range (whole rounds + K-sliced tail) and the tail's reduce kernel work with either.
+__host__ __device__ inline void gemm256_tile_of(int id, int tiles_m, int tiles_n, int grp, int& tm, int& tn) {
+    if (grp > 1) {
+        const int per = grp * tiles_m, g0 = (id / per) * grp, w = id % per;
+        const int gs = tiles_n - g0 < grp ? tiles_n - g0 : grp;
+        tn = g0 + w % gs; tm = w / gs;
+    } else {
+        tm = id % tiles_m; tn = id / tiles_m;
+    }
+}
+extern int g_gemm256_group;        // tuning hook (vila_gemm_force_group): -1 = the rule below, 0 = tm-fastest everywhere, n = groups of n
+// grouped order where a strip would be long (tiles_m > 16); never for the fused gate/up modes (their tail policy cuts whole columns)
+static inline int gemm256_group(int tiles_m, int tiles_n, bool gateup) {
+    if (gateup || tiles_n < 2) return 0;
+    if (g_gemm256_group >= 0) return g_gemm256_group;
+    return tiles_m > 16 ? 4 : 0;
+}
+
 template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256, bool EX = false>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0, int grp) {
     static_assert(BM == 256 || (BM == 192 && !ACM && (SCHED == 5 || SCHED == 6 || SCHED == 7) && MODE == 0), "192-row tiles: role-split schedules, forward-layout A");
     static_assert(!EX || (!ACM && SCHED == 7 && BM == 256 && MODE != 5), "the extra row fragment: forward-layout A, default schedule, 256-row tiles");
     constexpr int NA = BM / 64;                        // A fragments per quadrant (4, or 3 with 192-row tiles)
@@ -68,9 +93,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const int id = xcd_remap(blockIdx.x, gridDim.x) + tile0;
-    const int tm = id % tiles_m, tn = id / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN_OUT;
     const int M = p.M, N = p.N;
+    int tm, tn;
+    gemm256_tile_of(id, tiles_m, (N + BN_OUT - 1) / BN_OUT, grp, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN_OUT;
     const bool has9 = EX && (tm == tiles_m - 1) && (M > tiles_m * 256);        // block-uniform: this row tile carries rows m0 + 256 .. M - 1
     constexpr int A9_BASE = 2 * 4 * 128 * 64 * 2;                               // behind the two K-tile buffers: 2 x [16 rows][64 k] bf16
 
@@ -807,7 +833,7 @@ static inline bool gemm256_ex_saves_round(int M, int tiles_n) {
     return cdiv((M / 256) * tiles_n, 256) < cdiv(cdiv(M, 256) * tiles_n, 256);
 }
 
-// tile range [tile0, tile0 + n_tiles) of the tm-fastest tile order (n_tiles < 0: all); per = K-tiles per slice for the split modes
+// tile range [tile0, tile0 + n_tiles) of the tile order (gemm256_tile_of; n_tiles < 0: all); per = K-tiles per slice for the split modes
 template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256, bool EX = false>
 static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
     const int bn = (MODE == 2 || MODE == 4) ? 128 : 256;
@@ -821,7 +847,8 @@ static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int til
     }
     const int kt = cdiv(a.K, T256_BK);
     if (per <= 0) per = kt / splits;
-    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0);
+    const int grp = gemm256_group(tiles_m, tiles_n, MODE == 2 || MODE == 4);
+    hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0, grp);
     VILA_LAUNCH_CHECK();
     return 0;
 }
