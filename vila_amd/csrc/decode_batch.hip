@@ -119,6 +119,10 @@ __device__ __forceinline__ void bgemm_epilogue(const BGemmArgs& p, int item, con
 // becomes its own small launch.  Each wave owns a private ring of NS slots (one slot = one 64-wide k-block: NT x 2 KB of weights +
 // XR x 128 B of activations), refilled as soon as a slot is consumed, counted s_waitcnt vmcnt; the only block-wide event is the
 // exchange of the 8 partial sums at an item's end (raw s_barrier: __syncthreads() would drain the rings).
+// Measured and rejected: carrying the RMSNorm inside this kernel (raw slices in the rings, w * bf16(x * rstd) applied to every A fragment
+// between its ds_read and its MFMA, rstd per block in a prologue).  The fragment is re-normalised for every work item and wave, and with
+// software rounding that is ~240 VALU ops per k-block: gate/up 46.8 -> 67 us, lm_head 180 -> 414 us; with v_cvt_pk_bf16_f32 the step is
+// 3.64 ms against 3.60 with the two 5-us norm launches per layer — not worth a second code path.
 template <int MODE, int XR>
 __global__ __launch_bounds__(512) void bgemm_dma_kernel(BGemmArgs p, int n_items) {
     constexpr int NT = (MODE == 1 || MODE == 2) ? 2 : 1;
