@@ -280,7 +280,8 @@ def cpu_baseline(cfg, n_prompt: int, threads: int):
     nl, nv = cfg.llm.num_hidden_layers, cfg.vision.num_used_layers
     t_full = (t_tok - t_head) * (nl / L) + t_head
     ttft = t_vit * (nv / LV) + t_proj + t_prefill * (nl / L) + t_head
-    return {"value": round(1.0 / t_full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / t_full, 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "cores_note": "cores = torch threads actually used (calibrated: all hardware threads measured slower); host_cpus = os.cpu_count()",
             "sample": f"oracle/vila_oracle.py fp32 at NVILA-8B widths: {L} of {nl} decoder layers + full lm_head, {n_prompt}-token prefill "
                       f"({t_prefill:.2f}s, layers only) then {n_tok} decode tokens ({t_tok*1e3:.0f} ms/token measured; layer part scaled x{nl // L}); "
                       f"TTFT leg: {LV} of {nv} ViT layers ({t_vit:.2f}s, scaled x{nv / LV:g}) + projector ({t_proj:.2f}s) + prefill x{nl // L} + lm_head row",

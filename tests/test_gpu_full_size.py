@@ -68,10 +68,26 @@ def test_full_size_decode_matches_prefill_and_graph_matches_eager(full):
 
 def test_full_size_tower_is_batch_independent(full):
     cfg, model, px, ids = full
+    """Two images in one call vs one call each.  With the kernel choice pinned (every GEMM on the same tile kernel, same K order) the rows of an
+    image do not depend on what else is in the batch: <= 2e-3 (bit-identical in practice).  With the automatic choice the K-slicing of fc2 depends
+    on M (8 slices at 1024 rows, 6 at 2048: round 3, cold-weight policy), i.e. another fp32 summation order in 26 layers of bf16 rounding: the two
+    results differ like two bf16 runs of the same math do (<= 2e-2, the suite's hidden-state tolerance), and both stay within it of each other's
+    pinned result."""
+    from vila_amd import _lib
+    lib = _lib.load()
     both = model.encode_images(px)
     one = torch.cat([model.encode_images(px[:1]), model.encode_images(px[1:])], 0)
     assert both.shape == (2, 256, 3584)
-    assert rel_l2(both, one) < 2e-3, f"rel={rel_l2(both, one):.3e}"
+    assert rel_l2(both, one) < 2e-2, f"automatic kernel choice: rel={rel_l2(both, one):.3e}"
+    lib.vila_gemm_force_tile(7)                                  # the 128x64 ring kernel for every tower / projector GEMM, no K-slicing
+    try:
+        both_p = model.encode_images(px)
+        one_p = torch.cat([model.encode_images(px[:1]), model.encode_images(px[1:])], 0)
+    finally:
+        lib.vila_gemm_force_tile(0)
+    assert rel_l2(both_p, one_p) < 2e-3, f"pinned kernels: rel={rel_l2(both_p, one_p):.3e}"
+    assert rel_l2(both, both_p) < 2e-2 and rel_l2(one, one_p) < 2e-2, f"{rel_l2(both, both_p):.3e} {rel_l2(one, one_p):.3e}"
+    print(f"tower batch independence: auto {rel_l2(both, one):.2e}, pinned {rel_l2(both_p, one_p):.2e}, auto vs pinned {rel_l2(both, both_p):.2e} / {rel_l2(one, one_p):.2e}")
 
 
 def test_full_size_w4_decode_tracks_bf16_decode():

@@ -41,7 +41,18 @@ for line in open('gpurun_out/val_batch_decode.jsonl'):
     d = json.loads(line); print('batch decode', d['config']['workload'][:40], '|', d['value'], d['unit'], '| ms/step', d['ms_per_step'])
 "
 timeout 400 python bench.py --mode sft --dynamic-s2 --micro-batch 1 --steps 3 --warmup 1 2>"$O/val_sft_s2.err" | tee "$O/val_sft_s2.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft dynamic_s2 ->', d['ms_per_step'], 'ms')"
+timeout 400 python bench.py --config nvila_lite_3b --no-sft --no-sustain --no-cpu-baseline 2>"$O/val_bench_lite3b.err" | tail -1 > "$O/val_bench_lite3b.json"
+python -c "
+import json
+d = json.loads(open('gpurun_out/val_bench_lite3b.json').read().strip().splitlines()[-1]); print('lite-3b', d['value'], d['unit'], 'ttft', d.get('ttft_ms'))
+"
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 bash tools/pmc.sh val --no-sft --no-sustain --steps 8 --warmup 2 | tail -2
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  DB=$(find "$O/pmc_val_$CTR" -name "*.db" | head -1)
+  [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemv_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
+done
+find "$O" -path "*pmc_val_*" -name "*.db" -delete
 timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tail -1
 cp "$O/pmc_mfma_val_sft/summary.txt" "$O/val_pmc_mfma_sft_step.txt" 2>/dev/null
 timeout 600 bash tools/pmc_mfma.sh val_ttft --no-sft --no-sustain --steps 8 --warmup 2 | tail -1

@@ -34,13 +34,20 @@ class BasicImageEncoder(nn.Module):
     def embed_tokens(self, tokens: Optional[str]) -> Optional[torch.Tensor]:
         if tokens is None:
             return None
-        ids = self.parent.tokenizer(tokens).input_ids
-        return self.parent.llm.embed_tokens(torch.tensor(ids, device=self.parent.device))
+        # the token ids live on the device after the first call: `torch.tensor(ids, device=...)` is a pageable host copy, i.e. the host
+        # blocks until the stream has drained — behind the tower that was the largest gap of the TTFT timeline.  (The embedding itself is
+        # looked up every time: the table may have been trained in between.)
+        cache = self.__dict__.setdefault("_tok_ids_dev", {})
+        ids = cache.get(tokens)
+        if ids is None:
+            with torch.inference_mode(False):
+                ids = cache[tokens] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
+        return self.parent.llm.embed_tokens(ids)
 
     def forward(self, images: List[torch.Tensor], config: Dict[str, Any]) -> List[torch.Tensor]:
         images = torch.stack(list(images), dim=0)
+        start, end = self.embed_tokens(self.start_tokens), self.embed_tokens(self.end_tokens)      # enqueued ahead of the tower: off the critical path
         feats = self.parent.encode_images(images, block_sizes=config.get("block_sizes") if config else None)
-        start, end = self.embed_tokens(self.start_tokens), self.embed_tokens(self.end_tokens)
         out = []
         for f in feats:
             parts = ([start] if start is not None else []) + [f] + ([end] if end is not None else [])
@@ -67,8 +74,15 @@ class BasicVideoEncoder(nn.Module):
     def embed_tokens(self, tokens: Optional[str]) -> Optional[torch.Tensor]:
         if tokens is None:
             return None
-        ids = self.parent.tokenizer(tokens).input_ids
-        return self.parent.llm.embed_tokens(torch.tensor(ids, device=self.parent.device))
+        # the token ids live on the device after the first call: `torch.tensor(ids, device=...)` is a pageable host copy, i.e. the host
+        # blocks until the stream has drained — behind the tower that was the largest gap of the TTFT timeline.  (The embedding itself is
+        # looked up every time: the table may have been trained in between.)
+        cache = self.__dict__.setdefault("_tok_ids_dev", {})
+        ids = cache.get(tokens)
+        if ids is None:
+            with torch.inference_mode(False):
+                ids = cache[tokens] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
+        return self.parent.llm.embed_tokens(ids)
 
     def _process_features(self, feats: torch.Tensor, start, end, sep) -> torch.Tensor:
         """feats [nt, ns, H] of one video -> token block (tsp.py:28-52 / basic.py:30-41)."""
@@ -83,8 +97,8 @@ class BasicVideoEncoder(nn.Module):
     def forward(self, videos: List[torch.Tensor], config: Dict[str, Any]) -> List[torch.Tensor]:
         num_frames = [int(v.shape[0]) for v in videos]
         images = torch.cat(list(videos), dim=0)
-        feats = self.parent.encode_images(images)
         start, end, sep = self.embed_tokens(self.start_tokens), self.embed_tokens(self.end_tokens), self.embed_tokens(self.sep_tokens)
+        feats = self.parent.encode_images(images)
         return [self._process_features(f, start, end, sep) for f in torch.split(feats, num_frames)]
 
 
@@ -230,7 +244,8 @@ class HipLlavaLlamaModel(nn.Module):
         n = max((n + 15) & ~15, 16)
         pin = getattr(self, "_plan_pin", None)
         if pin is None or pin.numel() < n:
-            pin = self._plan_pin = torch.empty((max(n, 1 << 16),), dtype=torch.uint8, pin_memory=True)
+            with torch.inference_mode(False):          # a staging buffer born inside generate()'s inference mode could not be refilled outside it
+                pin = self._plan_pin = torch.empty((max(n, 1 << 16),), dtype=torch.uint8, pin_memory=True)
             self._plan_ev = None
         if getattr(self, "_plan_ev", None) is not None:
             self._plan_ev.synchronize()                # the previous call's copy has left the staging buffer
