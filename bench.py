@@ -508,7 +508,7 @@ def decode_main(a, rank, world, dev, dist):
         t0 = time.perf_counter()
         e, _, m = model._embed(ids, {"image": [pixels[i] for i in range(n_tiles)]}, media_cfg)
         pos = torch.arange(S, device=dev, dtype=torch.int32)
-        r = llm.prefill_packed(e[0], pos, None, S, cache=cache, last_rows=torch.tensor([S - 1], device=dev, dtype=torch.int32))
+        r = llm.prefill_packed(e[0], pos, None, S, cache=cache, last_rows=torch.full((1,), S - 1, device=dev, dtype=torch.int32))   # (a fill kernel: no host copy)
         first = int(ops.argmax(r.last_logits[0]))
         return time.perf_counter() - t0, first, e
 
@@ -529,9 +529,14 @@ def decode_main(a, rank, world, dev, dist):
     torch.cuda.synchronize()
     encode_ms = ev_a.elapsed_time(ev_b) / 3
     prefill_flops = vit_flops(cfg, n_tiles) + projector_flops(cfg, n_tiles) + llm_prefill_flops(cfg, S)
+    pre_traffic = None          # L2-fill bytes of the prefill's dominant kernel (fused gate/up GEMM) from the committed --pmc passes of THIS command
+    tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    if a.config == "nvila_8b" and not a.dynamic_s2 and os.path.exists(tj):
+        with open(tj) as f:
+            pre_traffic = json.load(f).get("prefill_gateup")
     prefill = {"ttft_ms": round(ttft * 1e3, 3), "encode_images_ms": round(encode_ms, 3), "tflop": round(prefill_flops / 1e12, 3),
                "roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": round(prefill_flops / ttft / (MFMA_PEAK_TF * 1e12), 4), "traffic": None,
+                            "frac": round(prefill_flops / ttft / (MFMA_PEAK_TF * 1e12), 4), "traffic": pre_traffic,
                             "note": "algorithmic FLOPs of ViT (26 layers) + projector + LLM prefill + last-row lm_head (SURVEY §8d) / host-observed TTFT"}}
 
     if a.w4:

@@ -51,6 +51,7 @@ timeout 600 bash tools/pmc.sh val --no-sft --no-sustain --steps 8 --warmup 2 | t
 for CTR in FETCH_SIZE WRITE_SIZE; do
   DB=$(find "$O/pmc_val_$CTR" -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemv_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
+  [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemm256_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
 done
 find "$O" -path "*pmc_val_*" -name "*.db" -delete
 timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tail -1
