@@ -42,8 +42,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + e^(-2u)): one v_exp_f32 and one v_rcp_f32 instead of the library tanhf (a branchy
+    // ~30-instruction routine that made the fc1 epilogue of the tower cost 6 us of a 31-us GEMM); relative error ~1e-6, the result is rounded to bf16
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
+    const float u2 = 2.f * k0 * (x + k1 * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.f + __expf(-u2));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
