@@ -89,27 +89,36 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     }
 }
 
-// Rows of up to 4096 columns (every norm of the tower and the decoder): ONE WAVE per row, no LDS, no barriers — x, w and b are all requested
+// Rows of up to 1536 columns (the tower's LayerNorms): ONE WAVE per row, no LDS, no barriers — x, w and b are all requested
 // before anything is reduced, the two reductions are wave shuffles.  The block-per-row kernel above spends its time in a dependent chain
 // (load x -> block reduce -> block reduce -> load w, b -> store) that costs 8 us for 2.4 MB at M = 1024 x 1152; the chain here is
 // load -> shuffle reduce (x2) -> store.  Same arithmetic per element; the fp32 sums are taken in another order.
-template <bool RMS>
+template <bool RMS, int MAXC>
 __global__ __launch_bounds__(256) void norm_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                         bf16_t* __restrict__ y, int rows, int cols, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;                                     // wave-uniform
     const bf16_t* xr = x + (int64_t)row * cols;
     bf16_t* yr = y + (int64_t)row * cols;
-    const int nch = cols >> 3;
-    constexpr int MAXC = 8;                                      // cols <= 64 * 8 * 8 = 4096
+    const int nch = cols >> 3;                                   // <= 64 * MAXC chunks of 16 B
     u32x4 v[MAXC], wv[MAXC], bv[MAXC];
+    // every load is UNCONDITIONAL (chunks beyond the row re-read its last chunk and are zeroed by a select): a branch around a load makes
+    // the compiler drain the memory queue at the join, which serialised the 14-21 loads of a 3584-wide row (18.7 us instead of 6)
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + 64 * i;
-        const bool ok = c < nch;
-        v[i] = ok ? *(const u32x4*)(xr + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-        wv[i] = ok ? *(const u32x4*)(w + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-        bv[i] = (!RMS && b != nullptr && ok) ? *(const u32x4*)(b + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+        const int c = lane + 64 * i, cc = c < nch ? c : nch - 1;
+        v[i] = *(const u32x4*)(xr + cc * 8);
+        wv[i] = *(const u32x4*)(w + cc * 8);
+        if constexpr (!RMS) bv[i] = *(const u32x4*)((b != nullptr ? b : w) + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const bool ok = lane + 64 * i < nch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[i][k] = ok ? v[i][k] : 0u;
+            if constexpr (!RMS) bv[i][k] = (ok && b != nullptr) ? bv[i][k] : 0u; else bv[i][k] = 0u;
+        }
     }
     auto wave_sum = [](float t) {
 #pragma unroll
@@ -168,8 +177,8 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const bf16_t* __restrict
 
 int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int cols, float eps, hipStream_t s) {
     VILA_REQUIRE(cols % 8 == 0 && cols <= 16384 && rows > 0, "layernorm: cols=%d must be a multiple of 8 and <= 16384", cols);
-    if (cols <= 4096) {
-        hipLaunchKernelGGL(norm_wave_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, y, rows, cols, eps);
+    if (cols <= 1536) {          // wider rows: the block-per-row kernel wins (3584 columns: 6.7 us vs 19 for one wave per 7-KB row at S = 769)
+        hipLaunchKernelGGL((norm_wave_kernel<false, 3>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, y, rows, cols, eps);
         VILA_LAUNCH_CHECK();
         return 0;
     }
@@ -179,8 +188,8 @@ int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* 
 }
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t s) {
     VILA_REQUIRE(cols % 8 == 0 && cols <= 16384 && rows > 0, "rmsnorm: cols=%d must be a multiple of 8 and <= 16384", cols);
-    if (cols <= 4096) {
-        hipLaunchKernelGGL(norm_wave_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16_t*)nullptr, y, rows, cols, eps);
+    if (cols <= 1536) {
+        hipLaunchKernelGGL((norm_wave_kernel<true, 3>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16_t*)nullptr, y, rows, cols, eps);
         VILA_LAUNCH_CHECK();
         return 0;
     }

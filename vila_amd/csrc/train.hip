@@ -53,7 +53,7 @@ int launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, int64_t ldi, i
 
 __device__ __forceinline__ float dgelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float t = tanhf(k0 * (x + k1 * x * x * x));
+    const float t = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * k0 * (x + k1 * x * x * x))) - 1.f;      // tanh(u) = 2 sigmoid(2u) - 1 (common.h gelu_tanh_f)
     return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x * x);
 }
 __device__ __forceinline__ float dgelu_erf(float x) {
