@@ -1,6 +1,7 @@
 """Timeline of one phase out of a rocprofv3 --kernel-trace database (rocpd sqlite): where does the wall-clock between two marker
 kernels go — kernels or the gaps between them?
-usage: python tools/rocpd_timeline.py trace_results.db <first-kernel-substring> <last-kernel-substring> [occurrence=-1] [out.txt]
+usage: python tools/rocpd_timeline.py trace_results.db <first-kernel-substring> <last-kernel-substring> [occurrence=-1 | median] [out.txt]
+("median": of all complete first..last windows the one with the median wall time — a host hiccup in one pass does not end up as the timeline)
 e.g.   python tools/rocpd_timeline.py gpurun_out/prof_r02/trace_results.db im2col_kernel argmax_stage2 -1 profiles/r02_ttft_timeline.txt
 The window runs from the start of the chosen occurrence of the first marker to the end of the next occurrence of the last marker;
 with "@next" as the last marker it runs to the start of the NEXT occurrence of the first marker (one period, e.g. one training step).
@@ -11,13 +12,25 @@ from collections import defaultdict
 
 db = sqlite3.connect(sys.argv[1])
 first, last = sys.argv[2], sys.argv[3]
-occ = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+occ = sys.argv[4] if len(sys.argv) > 4 else "-1"
 out = open(sys.argv[5], "w") if len(sys.argv) > 5 else sys.stdout
 rows = list(db.execute("select name, start, end, stream_id from kernels order by start"))
 starts = [i for i, r in enumerate(rows) if first in r[0]]
 if not starts:
     sys.exit(f"no kernel matching {first!r}")
-i0 = starts[occ]
+if occ == "median" and last != "@next":
+    cands = []
+    for a in starts:
+        b = next((i for i in range(a, len(rows)) if last in rows[i][0]), None)
+        nxt = next((x for x in starts if x > a), len(rows))
+        if b is not None and b < nxt:                           # a complete window with no second start marker inside
+            cands.append((rows[b][2] - rows[a][1], a))
+    if not cands:
+        sys.exit("no complete window")
+    cands.sort()
+    i0 = cands[len(cands) // 2][1]
+else:
+    i0 = starts[int(occ)]
 if last == "@next":
     k = starts.index(i0)
     if k + 1 >= len(starts):

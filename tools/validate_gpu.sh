@@ -65,7 +65,7 @@ fi
 timeout 600 bash tools/profile.sh val --no-sft --no-sustain --steps 32 --warmup 8 2>&1 | tail -1
 if [ -f "$O/prof_val/trace_results.db" ]; then
   python tools/rocpd_summary.py "$O/prof_val/trace_results.db" "$O/val_bench_kernel_stats.csv"
-  python tools/rocpd_timeline.py "$O/prof_val/trace_results.db" im2col_kernel argmax_stage2 -4 "$O/val_ttft_timeline.txt"
+  python tools/rocpd_timeline.py "$O/prof_val/trace_results.db" im2col_kernel argmax_stage2 median "$O/val_ttft_timeline.txt"
   rm -f "$O/prof_val/trace_results.db"
 fi
 find "$O" -name "*.db" -size +1M -delete
