@@ -100,3 +100,34 @@ def test_chat_completions_endpoint_on_the_hip_model(served):
     # text-only request and a second image in one request also go through the HIP path
     r = client.post("/chat/completions", json={"model": "NVILA-tiny", "max_tokens": 3, "messages": [{"role": "user", "content": "what is this ?"}]})
     assert r.status_code == 200 and isinstance(r.json()["choices"][0]["message"]["content"][0]["text"], str)
+
+
+def test_batched_serving_shares_the_weight_pass(served):
+    """`generate_content_batch` / `RequestBatcher` (server.py:171-290: concurrent requests): three greedy prompts of different lengths and image
+    counts as ONE padded batch through the batched decode step; identical prompts give identical replies, every row starts like its solo reply
+    (first token: the batch and the solo path share the prefill arithmetic), and the endpoint with a batching window answers like the plain one."""
+    pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    cfg, w, model, tok = served
+    img = _image()
+    prompts = [[img, "what is this ?"], "describe the image", [img, "what is this ?"], [img, "a red square", img, "you are helpful"]]
+    batch = serving.generate_content_batch(model, tok, prompts, max_new_tokens=5, eos_token_id=-1)
+    assert getattr(model.llm, "_bdecode", None) is not None, "the batched decode step was not taken"
+    assert len(batch) == 4 and batch[0] == batch[2]
+    for p, got in zip(prompts, batch):
+        solo = serving.generate_content(model, tok, p, max_new_tokens=5, eos_token_id=-1)
+        assert got.split()[:1] == solo.split()[:1], (got, solo)
+    # through the request batcher: submitted together -> one batch of 4
+    b = serving.RequestBatcher(model, tok, window_s=0.5, max_batch=8,
+                               run=lambda ps, n, system: serving.generate_content_batch(model, tok, ps, max_new_tokens=n, system=system, eos_token_id=-1))
+    try:
+        futs = [b.submit(p, 5) for p in prompts]
+        assert [f.result(timeout=60) for f in futs] == batch
+        assert b.batches == [4]
+    finally:
+        b.close()
+    # the endpoint with a batching window: a lone greedy request still answers (a batch of one falls back to the batch-1 path)
+    client = TestClient(serving.create_app(model, tok, model_name="NVILA-tiny", batch_window_s=0.01))
+    r = client.post("/chat/completions", json={"model": "NVILA-tiny", "max_tokens": 4, "temperature": 0.0, "messages": [{"role": "user", "content": "what is this ?"}]})
+    assert r.status_code == 200, r.text
+    assert r.json()["choices"][0]["message"]["content"][0]["text"] == serving.generate_content(model, tok, "what is this ?", max_new_tokens=4)

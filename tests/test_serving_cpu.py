@@ -121,3 +121,60 @@ def test_prompt_split_matches_extract_media():
     text, images = _split_prompt(["<image> describe", img])
     assert text == "describe<image>" and images == [img]
     assert _split_prompt("a typed <vila/video> token") == ("a typed  token", [])     # every MEDIA_TOKENS value, not only <image>
+
+
+class _BatchModel(_Model):
+    """Answers a padded batch: row b replies with the b-th canned text, then EOS, then padding."""
+    texts = ["a red square", "w1 w2", "you are helpful"]
+
+    def generate(self, input_ids, media, max_new_tokens, eos_token_id, attention_mask=None, pad_token_id=None, **kw):
+        self.calls.append((input_ids, media, max_new_tokens, eos_token_id, attention_mask, pad_token_id))
+        rows = [self.tok(self.texts[b % len(self.texts)]).input_ids + [1] for b in range(input_ids.shape[0])]
+        n = max(len(r) for r in rows) + 1
+        return torch.tensor([r + [int(pad_token_id)] * (n - len(r)) for r in rows])
+
+
+def test_generate_content_batch_pads_rows_and_consumes_images_in_row_order():
+    tok = _Tok()
+    m = _BatchModel(tok)
+    img = np.zeros((56, 56, 3), np.uint8)
+    out = serving.generate_content_batch(m, tok, [[img, "what is this ?"], "describe", [img, "a", img, "b c d e"]], max_new_tokens=9)
+    assert out == ["a red square", "w1 w2", "you are helpful"]
+    ids, media, n, eos, mask, pad = m.calls[0]
+    assert ids.shape == mask.shape and ids.shape[0] == 3 and n == 9 and eos == 1
+    assert [int((ids[b] == m.cfg.image_token_id).sum()) for b in range(3)] == [1, 0, 2] and len(media["image"]) == 3
+    lens = mask.sum(1).tolist()
+    assert lens[2] == ids.shape[1] and lens[1] < lens[0] < lens[2]                   # right padded to the longest row
+    for b in range(3):
+        assert bool(mask[b, : lens[b]].all()) and not bool(mask[b, lens[b]:].any())
+        assert (ids[b, lens[b]:] == pad).all()
+    assert serving.generate_content_batch(m, tok, []) == []
+
+
+def test_request_batcher_groups_concurrent_requests_and_splits_on_settings():
+    """Requests submitted together share a batch (<= max_batch); another max_new_tokens starts its own; a failure reaches every waiter."""
+    import threading
+    seen = []
+    gate = threading.Event()
+
+    def run(prompts, n, system):
+        gate.wait(2)
+        seen.append((list(prompts), n, system))
+        if prompts[0] == "boom":
+            raise RuntimeError("model failed")
+        return [f"{p}:{n}" for p in prompts]
+
+    b = serving.RequestBatcher(None, None, window_s=0.2, max_batch=3, run=run)
+    try:
+        futs = [b.submit(f"p{i}", 8) for i in range(5)] + [b.submit("q", 4), b.submit("boom", 2)]
+        gate.set()
+        got = [f.result(timeout=5) for f in futs[:6]]
+        assert got == ["p0:8", "p1:8", "p2:8", "p3:8", "p4:8", "q:4"]
+        with pytest.raises(RuntimeError):
+            futs[6].result(timeout=5)
+        sizes = [len(s[0]) for s in seen]
+        assert sizes[0] == 3 and sum(sizes[:2]) == 5 and all(s[1] == 8 for s in seen[:2])      # 5 requests, max_batch 3 -> 3 + 2
+        assert [s[1] for s in seen[2:]] == [4, 2]                                               # other settings never share a batch
+        assert b.batches[:2] == [3, 2]
+    finally:
+        b.close()

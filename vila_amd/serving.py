@@ -110,6 +110,103 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
     return tokenizer.decode(toks, skip_special_tokens=True).strip()
 
 
+def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequence[Any]]], max_new_tokens: int = 128, system: Optional[str] = None,
+                           eos_token_id=None, pad_token_id: Optional[int] = None, device: Optional[str] = None) -> List[str]:
+    """Several greedy requests as ONE padded batch (server.py:171-290 serves concurrent requests; here they share every pass over the
+    weights: `vila_llm_decode_step_batch`, up to 16 rows).  Each prompt is tokenised on its own, rows are right-padded, the images of all
+    prompts are encoded by one tower call and consumed in row order (`_embed`, llava_arch.py:454-466).  Returns one decoded reply per prompt."""
+    if not prompts:
+        return []
+    cfg = model.cfg
+    dev = device or str(model.device)
+    rows, images = [], []
+    for prompt in prompts:
+        text, imgs = _split_prompt(prompt)
+        rows.append(encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id))
+        images.extend(imgs)
+    eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+    stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
+    pad = pad_token_id if pad_token_id is not None else (getattr(tokenizer, "pad_token_id", None) or 0)
+    L = max(int(r.numel()) for r in rows)
+    ids = torch.full((len(rows), L), int(pad), dtype=torch.int64)
+    mask = torch.zeros((len(rows), L), dtype=torch.bool)
+    for b, r in enumerate(rows):
+        ids[b, : r.numel()] = r
+        mask[b, : r.numel()] = True
+    media = {"image": [preprocess_image(im, cfg.vision.image_size).to(device=dev, dtype=torch.bfloat16) for im in images]}
+    out = model.generate(input_ids=ids.to(dev), media=media, attention_mask=mask.to(dev), max_new_tokens=max_new_tokens, eos_token_id=eos,
+                         pad_token_id=int(pad))
+    replies = []
+    for row in out.tolist():
+        toks = row
+        for k, t in enumerate(row):
+            if t in stop:
+                toks = row[:k]
+                break
+        replies.append(tokenizer.decode(toks, skip_special_tokens=True).strip())
+    return replies
+
+
+class RequestBatcher:
+    """Groups greedy requests that arrive within `window_s` of each other (at most `max_batch` <= 16) into one `generate_content_batch` call.
+    `submit` returns a `concurrent.futures.Future` of the reply; one worker thread owns the model.  Requests with different `max_new_tokens`
+    or system prompts do not share a batch (the batch runs to the longest reply; a row that stops early is padded like HF does)."""
+
+    def __init__(self, model, tokenizer, window_s: float = 0.005, max_batch: int = 16, run=None):
+        import queue
+        import threading
+        self.model, self.tokenizer, self.window_s, self.max_batch = model, tokenizer, float(window_s), int(max(1, min(16, max_batch)))
+        self._run = run or (lambda prompts, n, system: generate_content_batch(self.model, self.tokenizer, prompts, max_new_tokens=n, system=system))
+        self._q: "queue.Queue" = queue.Queue()
+        self.batches: List[int] = []                     # sizes of the batches that ran (observability / tests)
+        self._stop = False
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def submit(self, prompt, max_new_tokens: int = 128, system: Optional[str] = None):
+        from concurrent.futures import Future
+        f: Future = Future()
+        self._q.put((prompt, int(max_new_tokens), system, f))
+        return f
+
+    def close(self):
+        self._stop = True
+        self._q.put(None)
+        self._thread.join(timeout=5)
+
+    def _loop(self):
+        import queue
+        held = None
+        while not self._stop:
+            item = held if held is not None else self._q.get()
+            held = None
+            if item is None:
+                break
+            group = [item]
+            deadline = time.time() + self.window_s
+            while len(group) < self.max_batch:
+                try:
+                    nxt = self._q.get(timeout=max(0.0, deadline - time.time()))
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    self._stop = True
+                    break
+                if nxt[1] != item[1] or nxt[2] != item[2]:           # other generation settings: it starts the next group
+                    held = nxt
+                    break
+                group.append(nxt)
+            try:
+                with torch.inference_mode():
+                    replies = self._run([g[0] for g in group], item[1], item[2])
+                self.batches.append(len(group))
+                for g, r in zip(group, replies):
+                    g[3].set_result(r)
+            except Exception as e:                                    # every waiter of the group sees the failure
+                for g in group:
+                    g[3].set_exception(e)
+
+
 _MODELS = None
 
 
@@ -126,13 +223,16 @@ def _request_models():
     return _MODELS
 
 
-def create_app(model, tokenizer, model_name: str = "NVILA-8B"):
-    """FastAPI app with the reference's POST /chat/completions (server.py:171-290).  Import-time optional: needs fastapi + pydantic."""
+def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: Optional[float] = None):
+    """FastAPI app with the reference's POST /chat/completions (server.py:171-290).  Import-time optional: needs fastapi + pydantic.
+    batch_window_s: when set, greedy requests (temperature 0) that arrive within that window share a batched decode (`RequestBatcher`)."""
     from fastapi import FastAPI
     from fastapi.responses import JSONResponse, StreamingResponse
 
     ChatMessage, ChatCompletionRequest = _request_models()
     app = FastAPI()
+    batcher = RequestBatcher(model, tokenizer, window_s=batch_window_s) if batch_window_s is not None else None
+    app.state.batcher = batcher
 
     def _prompt_of(messages):
         parts: List[Any] = []
@@ -160,10 +260,15 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B"):
             if request.model != model_name:
                 raise ValueError(f"The endpoint is configured to use the model {model_name}, but the request model is {request.model}")
             parts, system = _prompt_of(request.messages)
-            with torch.inference_mode():
-                text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
-                                        temperature=request.temperature if request.temperature is not None else 0.2,
-                                        top_p=request.top_p if request.top_p is not None else 0.9)
+            temperature = request.temperature if request.temperature is not None else 0.2
+            if batcher is not None and not temperature:
+                import asyncio
+                fut = batcher.submit(parts, request.max_tokens or 512, system)
+                text = await asyncio.get_running_loop().run_in_executor(None, fut.result)
+            else:
+                with torch.inference_mode():
+                    text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
+                                            temperature=temperature, top_p=request.top_p if request.top_p is not None else 0.9)
             if request.stream:
                 def chunks() -> Iterator[str]:
                     for i, word in enumerate(re.findall(r"\S+\s*", text)):
