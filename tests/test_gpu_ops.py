@@ -422,6 +422,10 @@ def test_gemm256_grouped_tile_order_is_a_bijection_on_ragged_grids(ops, grp):
     try:
         out = ops.gemm(a, w, residual=res)
         assert rel_l2(out, ref) < 4e-3, f"forward layout: {rel_l2(out, ref):.3e}"
+        w_up = randn_bf16(N, K, seed=96, scale=K ** -0.5)                 # fused gate/up over the whole grid (19 x 8 tiles of 128 columns)
+        want = torch.nn.functional.silu(a.float() @ w.float().t()) * (a.float() @ w_up.float().t())
+        out = ops.gemm(a, w, w2=w_up, epi=3)
+        assert rel_l2(out, want) < 6e-3, f"gate/up: {rel_l2(out, want):.3e}"
         lib.vila_gemm_force_tile(0)
         at, wt = a.t().contiguous(), w.t().contiguous()                  # stored contraction-major
         out = ops.gemm_t(at, wt, a_cm=True, b_cm=True, residual=res)

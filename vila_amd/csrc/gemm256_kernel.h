@@ -70,7 +70,7 @@ __host__ __device__ inline void gemm256_tile_of(int id, int tiles_m, int tiles_n
     }
 }
 extern int g_gemm256_group;        // tuning hook (vila_gemm_force_group): -1 = the rule below, 0 = tm-fastest everywhere, n = groups of n
-// grouped order where a strip would be long (tiles_m > 16); never for the fused gate/up modes (their tail policy cuts whole columns)
+// grouped order where a strip would be long (tiles_m > 16); `gateup` = a fused gate/up launch over part of the grid (tail policy): never
 static inline int gemm256_group(int tiles_m, int tiles_n, bool gateup) {
     if (gateup || tiles_n < 2) return 0;
     if (g_gemm256_group >= 0) return g_gemm256_group;
@@ -847,7 +847,9 @@ static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int til
     }
     const int kt = cdiv(a.K, T256_BK);
     if (per <= 0) per = kt / splits;
-    const int grp = gemm256_group(tiles_m, tiles_n, MODE == 2 || MODE == 4);
+    // fused gate/up: grouped only when this launch covers the whole grid (its whole-rounds + sliced-tail policy cuts whole tile COLUMNS)
+    const bool gu_partial = (MODE == 4) || (MODE == 2 && (tile0 != 0 || n_tiles != tiles_m * tiles_n));
+    const int grp = gemm256_group(tiles_m, tiles_n, gu_partial);
     hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0, grp);
     VILA_LAUNCH_CHECK();
     return 0;
