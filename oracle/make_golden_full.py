@@ -1,6 +1,7 @@
 """Full-depth golden for BASELINE configs[1] (NVILA-8B, 1 x 448^2 image + 512-token prompt, S = 769) — TEST INFRASTRUCTURE.
 
-ORACLE-EXECUTED (not reference-executed): runs the fp32 CPU oracle (oracle/vila_oracle.py, itself pinned against the
+ORACLE-EXECUTED (its reference-executed twin at the same depth and weights is make_golden_full_ref.py -> nvila8b_full_depth_ref.npz, and
+tests/test_oracle_golden.py holds this file to that one): runs the fp32 CPU oracle (oracle/vila_oracle.py, itself pinned against the
 reference-executed fixtures of make_golden.py at tiny depth) ONCE at the full 26 + 28 layer depth on CPU-drawn seeded weights and
 stores KB-sized fingerprints.  The synthetic lm_head has heavy-tailed (Pareto) row norms and the seed of those norms is searched so
 that at least 7 of the 8 greedy steps have a top-1 / top-2 margin well above 4x the logit error a bf16 path shows at this depth

@@ -131,3 +131,33 @@ def test_sample_distribution_matches_hf_processors_fixture():
         n += 1
     assert n >= 6
 
+
+
+def test_full_depth_oracle_fixture_equals_the_reference_executed_one(golden_dir):
+    """the full-depth fixture the GPU path is held to (nvila8b_full_depth.npz) is produced by the ORACLE.  Round 3 adds the same
+    run through the REFERENCE's own code at full depth (oracle/make_golden_full_ref.py: reference SigLIP + projector by file path, HF
+    Qwen2ForCausalLM in fp32, 26 + 28 layers, S = 769, same seeded weights) — here the two files are compared: same inputs and weights
+    (fingerprints), tower / projector / spliced-embedding rows, the top-32 logits of all 8 steps and the greedy ids."""
+    import os
+    a_path, b_path = os.path.join(golden_dir, "nvila8b_full_depth.npz"), os.path.join(golden_dir, "nvila8b_full_depth_ref.npz")
+    if not (os.path.exists(a_path) and os.path.exists(b_path)):
+        pytest.skip("full-depth fixtures not present")
+    a, b = np.load(a_path), np.load(b_path)
+    for k in [k for k in a.files if k.startswith("fp_")] + ["input_ids"]:
+        assert np.array_equal(a[k], b[k]), f"{k}: the two fixtures were not produced from the same weights / inputs"
+
+    def rel(x, y):
+        return float(np.linalg.norm(x.astype(np.float64) - y.astype(np.float64)) / max(np.linalg.norm(y.astype(np.float64)), 1e-30))
+    assert rel(a["vit_rows"], b["vit_rows"]) < 1e-4 and abs(float(a["vit_norm"]) / float(b["vit_norm"]) - 1) < 1e-5
+    assert rel(a["proj_rows"], b["proj_rows"]) < 1e-4 and abs(float(a["proj_norm"]) / float(b["proj_norm"]) - 1) < 1e-5
+    assert rel(a["embed_rows"], b["embed_rows"]) < 1e-4
+    assert np.array_equal(a["greedy_ids"], b["greedy_ids"]), (a["greedy_ids"], b["greedy_ids"])
+    assert np.array_equal(a["top_ids"][:, 0], b["top_ids"][:, 0])
+    worst = 0.0
+    for t in range(a["top_ids"].shape[0]):
+        ia = {int(i): float(v) for i, v in zip(a["top_ids"][t], a["top_vals"][t])}
+        common = [(ia[int(i)], float(v)) for i, v in zip(b["top_ids"][t], b["top_vals"][t]) if int(i) in ia]
+        assert len(common) >= 28, f"step {t}: the top-32 sets share only {len(common)} ids"
+        worst = max(worst, max(abs(x - y) for x, y in common) / float(b["logit_absmax"][t]))
+    assert worst < 2e-4, f"top-32 logits differ by {worst:.2e} of the step's largest logit"
+    assert np.allclose(a["logit_norm"], b["logit_norm"], rtol=1e-4)
