@@ -16,6 +16,9 @@ against those fixtures.  The HF-LLM leg is therefore pinned against transformers
 the reference names — same arithmetic (cf. the in-tree mirror
 `llava/model/language_model/fp8activationqwen2.py:992-1055`), but say so: the LLM boundary is
 "pinned against a newer release of the un-vendored dependency".
+Round 3: the same three pieces of reference code were also run ONCE AT FULL SIZE (26 + 28 layers at NVILA-8B widths, S = 769, fp32;
+`oracle/make_golden_full_ref.py` -> `tests/golden/nvila8b_full_depth_ref.npz`), and the oracle's own full-depth fixture equals that
+run to 2.4e-6 of the largest logit with identical greedy ids (`tests/test_oracle_golden.py`).
 
 All tensors fp32 unless noted.  `w` is a flat dict keyed by the reference's state_dict names
 (SURVEY.md Appendix C).
