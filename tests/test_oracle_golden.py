@@ -133,13 +133,15 @@ def test_sample_distribution_matches_hf_processors_fixture():
 
 
 
-def test_full_depth_oracle_fixture_equals_the_reference_executed_one(golden_dir):
+@pytest.mark.parametrize("stem", ["nvila8b_full_depth", "nvila_lite3b_full_depth"])
+def test_full_depth_oracle_fixture_equals_the_reference_executed_one(golden_dir, stem):
     """the full-depth fixture the GPU path is held to (nvila8b_full_depth.npz) is produced by the ORACLE.  Round 3 adds the same
     run through the REFERENCE's own code at full depth (oracle/make_golden_full_ref.py: reference SigLIP + projector by file path, HF
     Qwen2ForCausalLM in fp32, 26 + 28 layers, S = 769, same seeded weights) — here the two files are compared: same inputs and weights
     (fingerprints), tower / projector / spliced-embedding rows, the top-32 logits of all 8 steps and the greedy ids."""
     import os
-    a_path, b_path = os.path.join(golden_dir, "nvila8b_full_depth.npz"), os.path.join(golden_dir, "nvila8b_full_depth_ref.npz")
+    # (nvila_lite3b_*: BASELINE configs[0] at full depth — 26 + 36 layers, 3x3 projector, tied head, S = 154; oracle/make_golden_lite3b.py)
+    a_path, b_path = os.path.join(golden_dir, f"{stem}.npz"), os.path.join(golden_dir, f"{stem}_ref.npz")
     if not (os.path.exists(a_path) and os.path.exists(b_path)):
         pytest.skip("full-depth fixtures not present")
     a, b = np.load(a_path), np.load(b_path)

@@ -91,6 +91,10 @@ def _draw(name: str, shape, kind: str, cfg: VilaConfig, seed: int, device) -> to
     g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
     x = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
     if kind == "w":
+        a = float(getattr(cfg, "lm_head_tail", 0.0))
+        if a > 0 and name == "llm.model.embed_tokens.weight" and cfg.llm.tie_word_embeddings:
+            # a tied head IS the embedding table: the heavy-tailed row norms that make the full-depth fixtures' argmax decisive go here
+            return x * cfg.init_std * lm_head_row_scale(name, shape[0], cfg).to(device)[:, None]
         return x * cfg.init_std
     if kind == "h":
         x = x * cfg.lm_head_std
