@@ -163,3 +163,39 @@ def test_full_depth_oracle_fixture_equals_the_reference_executed_one(golden_dir,
         worst = max(worst, max(abs(x - y) for x, y in common) / float(b["logit_absmax"][t]))
     assert worst < 2e-4, f"top-32 logits differ by {worst:.2e} of the step's largest logit"
     assert np.allclose(a["logit_norm"], b["logit_norm"], rtol=1e-4)
+
+
+def test_oracle_autograd_equals_the_reference_executed_gradients(golden_dir):
+    """Row a13 pinned at the gradient level: tests/golden/tiny_sft_grads.npz holds the gradients torch autograd produces through the REFERENCE'S
+    own modules (reference SigLIP + projector by file path, HF Qwen2ForCausalLM, loss = sum CE / num_items; oracle/make_golden_grads.py).  Autograd
+    through the oracle's restated forward (`vlm_sft_loss`, packed branch — the reference's training path, llava_llama.py:125-134) on the same
+    weights and batch must give the same loss and, for every one of the 86 parameter tensors, the same gradient norm and leading values."""
+    import os
+    from oracle.make_golden_grads import case
+    path = os.path.join(golden_dir, "tiny_sft_grads.npz")
+    if not os.path.exists(path):
+        pytest.skip("gradient fixture not present")
+    fx = np.load(path)
+    cfg, w, px, ids, labels, mask = case()
+    assert np.array_equal(ids.numpy(), fx["input_ids"]) and np.array_equal(labels.numpy(), fx["labels"])
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss = O.vlm_sft_loss([p for p in px], ids, labels, mask, wr, cfg, num_items_in_batch=int(fx["num_items"]), packed=True)
+    assert abs(float(loss) - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"])), (float(loss), float(fx["loss"]))
+    loss.backward()
+    names = [str(n) for n in fx["names"]]
+    assert len(names) == 86
+    worst = ("", 0.0)
+    for i, name in enumerate(names):
+        g = wr[name].grad
+        g = torch.zeros_like(wr[name]) if g is None else g
+        gn, gv = float(fx[f"gn_{i}"]), torch.from_numpy(fx[f"gv_{i}"])
+        if gn < 1e-6:                                                 # no gradient on either side: the tower layer behind hidden_states[-2]; the
+            assert float(g.norm()) < 1e-6, name                       # k_proj biases (softmax is shift-invariant: exactly zero up to rounding noise)
+            continue
+        assert abs(float(g.double().norm()) / gn - 1) < 2e-4, f"{name}: |grad| {float(g.norm()):.6e} vs reference {gn:.6e}"
+        lead = g.reshape(-1)[:64]
+        err = float((lead - gv).norm() / max(float(gv.norm()), 1e-12 * gn))
+        if float(gv.norm()) > 1e-3 * gn / (g.numel() ** 0.5) * 8:       # leading values that are not numerically zero
+            assert err < 2e-3, f"{name}: leading values rel {err:.2e}"
+        worst = max(worst, (name, err), key=lambda t: t[1])
+    print(f"oracle autograd vs reference-executed gradients: worst leading-value deviation {worst[1]:.2e} ({worst[0]})")
