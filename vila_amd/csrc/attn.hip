@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_v1_kernel(AttnArgs p) {
 
 template <int HD, bool CAUSAL, int QF>
 static int launch_attn_v1_q(const AttnArgs& a, hipStream_t s) {
-    constexpr int KK = (HD + 31) / 32, HDP = KK * 32, DN = (HD + 15) / 16;
+    constexpr int KK = (HD + 31) / 32, HDP = KK * 32;
     const size_t lds = (size_t)4 * 64 * (HDP + 8) * 2;   // K and V tiles, double buffered
     static bool attr_set = false;
     if (!attr_set) {
