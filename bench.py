@@ -136,36 +136,38 @@ def selftest_main(a, rank, world):
     dist = init_dist("gloo") if world > 1 else None
     extra = {}
     step = lambda: time.sleep(0.002)
-    if a.mode == "sft":
-        # dry run of the SFT mode's data-parallel plumbing (no kernels): the trainer's flat buffers over a tiny CPU model, the global
-        # token count and every gradient bucket's exchange over the process group, in the backward order the real step announces them
-        from vila_amd import configs
-        from vila_amd.train import SFTTrainer
-        from vila_amd.vlm import HipLlavaLlamaModel
-        torch.manual_seed(0)
-        cfg = configs.tiny("mlp_downsample")
-        tr = SFTTrainer(HipLlavaLlamaModel(cfg, device="cpu"), optimizer_state=False)
-        tr.flat.grads = tr.flat.grads.float()
-        order = ["llm.lm_head.", "llm.model.norm."] + [f"llm.model.layers.{i}." for i in reversed(range(cfg.llm.num_hidden_layers))]
-        order += ["llm.model.embed_tokens.", "mm_projector."]
-        order += [f"vision_tower.vision_tower.vision_model.encoder.layers.{i}." for i in reversed(range(cfg.vision.num_used_layers))]
-        order += ["vision_tower.vision_tower.vision_model.embeddings."]
-        box = {}
+    # dry run of the SFT data-parallel plumbing (no kernels): the trainer's flat buffers over a tiny CPU model, the global token count, the
+    # media agreement and every gradient bucket's exchange over the process group, in the backward order the real step announces them.
+    # `--mode sft` times it; the default mode runs it once — the GPU default mode runs the real SFT side measurement on every rank.
+    from vila_amd import configs
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import HipLlavaLlamaModel
+    torch.manual_seed(0)
+    cfg = configs.tiny("mlp_downsample")
+    tr = SFTTrainer(HipLlavaLlamaModel(cfg, device="cpu"), optimizer_state=False)
+    tr.flat.grads = tr.flat.grads.float()
+    order = ["llm.lm_head.", "llm.model.norm."] + [f"llm.model.layers.{i}." for i in reversed(range(cfg.llm.num_hidden_layers))]
+    order += ["llm.model.embed_tokens."] + tr.media_bucket_order()
+    box = {}
 
-        def step():
-            box["n"] = tr.global_num_items(100 + rank)
-            tr.reducer.log.clear()
-            tr.flat.grads.fill_(float(rank + 1))
-            for pre in order:
-                tr._ready(pre)
-            tr.reducer.wait()
-        step()
-        covered = torch.zeros(tr.flat.numel, dtype=torch.bool)
-        for _, s0, e0 in tr.reducer.log:
-            covered[s0:e0] = True
-        want = float(sum(range(1, world + 1)))
-        extra = {"mode": "sft dry run", "global_num_items": box["n"], "buckets": len(tr.reducer.log),
-                 "exchange_ok": bool((tr.flat.grads[covered] == want).all()), "grad_exchange": tr.reducer.describe()}
+    def sft_step():
+        box["n"] = tr.global_num_items(100 + rank)
+        box["media"] = tr.agree_on_media(True)
+        tr.reducer.log.clear()
+        tr.flat.grads.fill_(float(rank + 1))
+        for pre in order:
+            tr._ready(pre)
+        tr._finish_backward()
+    sft_step()
+    covered = torch.zeros(tr.flat.numel, dtype=torch.bool)
+    for _, s0, e0 in tr.reducer.log:
+        covered[s0:e0] = True
+    want = float(sum(range(1, world + 1)))
+    dry = {"global_num_items": box["n"], "buckets": len(tr.reducer.log), "exchange_ok": bool((tr.flat.grads[covered] == want).all()),
+           **exchange_summary(tr, world)}
+    if a.mode == "sft":
+        step = sft_step
+        extra = {"mode": "sft dry run", **dry}
     for _ in range(a.warmup):
         step()
     elapsed = timed_region(dist, None, a.steps, step, lambda: None)
@@ -175,7 +177,8 @@ def selftest_main(a, rank, world):
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
                           "config": {"workload": "selftest", "parallelism": f"gloo x{world}", "group_world_size": group_world,
-                                     "requested_gpus": a.gpus, **extra}}))
+                                     "requested_gpus": a.gpus, **extra},
+                          "sft": {"dry_run": True, **dry}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -351,6 +354,52 @@ def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: floa
                                  "max_grad_norm = None (scripts/NVILA-Lite/sft.sh sets no clipping)"}}
 
 
+SFT_1GPU_FILE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vila_bench_sft_1gpu_ms.txt")
+
+
+def exchange_summary(tr, world: int) -> dict:
+    """What one step hands to the process group: the distinct gradient buckets the reducer announced (bf16 slices of the flat buffer)."""
+    spans = {pre: (s0, e0) for pre, s0, e0 in tr.reducer.log}
+    nbytes = sum(e0 - s0 for s0, e0 in spans.values()) * tr.flat.grads.element_size()
+    return {"world": world, "grad_exchange": tr.reducer.describe(),
+            "exchange_bytes": int(nbytes), "exchange_active": bool(tr.reducer.active())}
+
+
+def sft_side_measurement(model, cfg, a, rank, world, dev, dist):
+    """The `sft` block of the default bench line.  All ranks agree (one tiny all-reduce) that the trainer fits before any of them enters a
+    step, so a rank that failed to allocate cannot leave the others waiting inside a gradient all-reduce."""
+    group = dist if (dist is not None and (world > 1 or os.environ.get("VILA_BENCH_FORCE_DIST"))) else None
+    try:
+        if group is not None:
+            free = torch.cuda.mem_get_info(dev)[0]
+            ok = torch.tensor([1.0 if free > 150e9 else 0.0], device=dev)
+            group.all_reduce(ok, op=group.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                return {"error": f"skipped: a rank has < 150 GB free (this rank: {free / 1e9:.0f} GB)", "world": world}
+        el, loss, S_sft, tr = sft_measure(model, cfg, a, rank, dev, group, 2, 1)
+        blk = sft_block(el, 2, a.micro_batch, S_sft, world, loss)
+        blk.update(exchange_summary(tr, world))
+        one = os.environ.get("VILA_BENCH_SFT_1GPU_MS")
+        if world == 1 and group is None:
+            try:
+                with open(SFT_1GPU_FILE, "w") as f:
+                    f.write(str(blk["ms_per_step"]))
+            except OSError:
+                pass
+        elif one is None and os.path.exists(SFT_1GPU_FILE):
+            one = open(SFT_1GPU_FILE).read().strip()
+        if world > 1:
+            try:
+                blk["weak_scaling_eff"] = round(float(one) / blk["ms_per_step"], 4) if one else None
+            except ValueError:
+                blk["weak_scaling_eff"] = None
+            blk["weak_scaling_note"] = ("1-GPU ms/step / N-GPU ms/step at the same per-GPU micro-batch; the 1-GPU figure comes from VILA_BENCH_SFT_1GPU_MS or "
+                                        f"from the N = 1 run of this bench on the same box ({SFT_1GPU_FILE}); null when neither exists")
+        return blk
+    except Exception as ex:      # the decode line must survive a failure of the side measurement; say so loudly in the JSON
+        return {"error": f"{type(ex).__name__}: {ex}", "world": world}
+
+
 def sft_main(a, rank, world, dev, dist):
     from vila_amd import configs
     from vila_amd.vlm import build_model
@@ -370,7 +419,7 @@ def sft_main(a, rank, world, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 master/AdamW state)",
             "data": "synthetic", "loss": blk["loss"],
             "config": {"workload": f"{cfg.name} SFT step, micro-batch {a.micro_batch} x S={S} packed, all params trainable, AdamW",
-                       "parallelism": f"dp{world}", "grad_exchange": tr.reducer.describe()},
+                       "parallelism": f"dp{world}", **exchange_summary(tr, world)},
             "roofline": blk["roofline"]}))
     if dist is not None:
         dist.destroy_process_group()
@@ -663,14 +712,13 @@ def decode_main(a, rank, world, dev, dist):
                                "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                "gpu_ms_per_step_hip_events": round(ev0.elapsed_time(ev1) / a.steps, 4)}}
 
-    # ---- bounded SFT sub-measurement: 1 warm + 2 timed steps of the configs[2] per-GPU workload (needs ~150 GB of the 288 GB) ----
+    # ---- bounded SFT sub-measurement: 1 warm + 2 timed steps of the configs[2] per-GPU workload (needs ~150 GB of the 288 GB).  With
+    # world > 1 (the driver's `bench.py --gpus N`) EVERY rank runs it with the process group: the per-layer gradient buckets go through RCCL's
+    # SUM all-reduce under the backward (replaces scripts/zero3.json + transformer_normalize_monkey_patch.py:242-263), so the
+    # scaling runs exercise the 16.1 GB exchange without any extra flag. ----
     sft = None
-    if world == 1 and not a.no_sft and not a.w4 and not a.dynamic_s2 and not a.w8_vit and a.config == "nvila_8b":
-        try:
-            el, loss, S_sft, _tr = sft_measure(model, cfg, a, rank, dev, None, 2, 1)
-            sft = sft_block(el, 2, a.micro_batch, S_sft, 1, loss)
-        except Exception as ex:      # the decode line must survive a failure of the side measurement; say so loudly in the JSON
-            sft = {"error": f"{type(ex).__name__}: {ex}"}
+    if not a.no_sft and not a.w4 and not a.dynamic_s2 and not a.w8_vit and a.config == "nvila_8b":
+        sft = sft_side_measurement(model, cfg, a, rank, world, dev, dist)
 
     if rank != 0:
         if dist is not None:

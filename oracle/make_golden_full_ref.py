@@ -7,15 +7,20 @@ tiny depth.  This script runs the REFERENCE'S OWN CODE at the full 26 + 28 layer
   * projector: /root/reference/llava/model/multimodal_projector/base_projector.py (`mlp_downsample`)
   * decoder: HF `Qwen2ForCausalLM` (the class the reference instantiates, language_model/builder.py:64; transformers as installed here, see
     `hf_version` in the file — the reference pins 4.46.0), eager attention, fp32, KV cache, greedy argmax for 8 steps
-and stores the same KB-sized fingerprints as make_golden_full.py (top-32 logits per step, greedy ids, rows of the tower / projector output
-and of the spliced embeddings).  tests/test_oracle_golden.py holds the oracle-executed fixture to it on CPU.
+and stores the same KB-sized fingerprints as make_golden_full.py: the top-32 logits of 8 steps TEACHER-FORCED WITH THE RANDOM ID SEQUENCE of
+that file (`forced_ids`; round 4 — distinct argmax tokens with margins a bf16 path could lose, see make_golden_full.py), the free-running greedy
+ids, rows of the tower / projector output and of the spliced embeddings, and (round 4, BASELINE configs[2]) the forward of the SFT micro-batch
+the bench times — 4 samples of 1 image + 512 tokens through `Qwen2ForCausalLM(inputs_embeds, labels, num_items_in_batch)`: HF's own
+ForCausalLMLoss per sample, loss = sum / num_items, top-32 logits of 8 labelled rows per sample.  tests/test_oracle_golden.py holds the
+oracle-executed fixture to this one on CPU; tests/test_gpu_full_depth.py holds the HIP path to THIS file.
 
     python oracle/make_golden_full_ref.py      # ~15 min on 8 cores, ~40 GB RSS (the 7.6 B-parameter decoder in fp32); needs /root/reference
 
-The lm_head tail parameters are READ from nvila8b_full_depth.npz so both fixtures describe the same weights.
+The lm_head tail parameters and the forced ids are READ from nvila8b_full_depth.npz so both fixtures describe the same weights and inputs.
 """
 from __future__ import annotations
 
+import copy
 import gc
 import os
 import sys
@@ -28,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import make_golden as G                     # noqa: E402  (reference loaders: ref_siglip / ref_projector / build config helpers)
-from oracle.make_golden_full import LazyBf16Weights, SEED, N_NEW, TOPK, fingerprints      # noqa: E402
+from oracle.make_golden_full import (LazyBf16Weights, SEED, N_NEW, TOPK, SFT_B, fingerprints, sft_batch, sft_rows)      # noqa: E402
 from vila_amd import configs, synthetic                 # noqa: E402
 
 SRC = os.path.join(ROOT, "tests", "golden", "nvila8b_full_depth.npz")
@@ -89,10 +94,13 @@ def main():
         vis_w = {k: w[k] for k in w.specs if k.startswith("vision_tower.")}
         hs = G.run_vision(cfg, vis_w, px)
         feats = hs[cfg.vision.select_layer]                                  # hidden_states[-2]
-        del hs, vis_w
+        del hs
         proj_w = {k: w[k] for k in w.specs if k.startswith("mm_projector.")}
         proj = G.run_projector(cfg, proj_w, feats)
-        del proj_w
+        # configs[2]'s four images through the reference tower + projector now, while their weights are around
+        spx, sids, slabels = sft_batch(cfg, SEED)
+        sft_proj = [G.run_projector(cfg, proj_w, G.run_vision(cfg, vis_w, spx[i:i + 1])[cfg.vision.select_layer])[0] for i in range(SFT_B)]
+        del proj_w, vis_w
         for k in list(w.store):
             if not k.startswith("llm."):
                 w.store.pop(k)
@@ -110,20 +118,60 @@ def main():
         t2 = time.time()
         r = llm(inputs_embeds=e, use_cache=True, logits_to_keep=1)
         past, last = r.past_key_values, r.logits[0, -1].float()
+        past0 = copy.deepcopy(past)                                          # HF's cache is updated in place: the greedy run restarts from a copy
         print(f"HF prefill {time.time() - t2:.0f}s", flush=True)
-        gen, step_logits = [], []
-        for t in range(N_NEW):
+        forced = torch.from_numpy(src["forced_ids"])
+        step_logits = []
+        for t in range(N_NEW):                                               # teacher-forced with the fixture's random sequence
             step_logits.append(last.clone())
+            if t + 1 == N_NEW:
+                break
+            r = llm(input_ids=forced[t].view(1, 1), past_key_values=past, use_cache=True)
+            past, last = r.past_key_values, r.logits[0, -1].float()
+        lg = torch.stack(step_logits)
+        gen, past, last = [], past0, lg[0]
+        for t in range(N_NEW):                                               # free-running greedy
             nxt = int(last.argmax())
             gen.append(nxt)
             if t + 1 == N_NEW:
                 break
             r = llm(input_ids=torch.tensor([[nxt]]), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
-        lg = torch.stack(step_logits)
+        del past, past0
+        # ---- configs[2]: the SFT micro-batch through the reference's modules, loss by HF's own loss function ----
+        assert np.array_equal(sids.numpy(), src["sft_input_ids"]) and np.array_equal(slabels.numpy(), src["sft_labels"])
+        n_items = int(src["sft_num_items"])
+        ce_sum, r_ids, r_vals = [], [], []
+        for i in range(SFT_B):
+            t3 = time.time()
+            imgi = torch.cat([sft_proj[i], emb(torch.tensor([cfg.newline_token_id]))], 0)
+            parts, labs = [], []
+            for tok, lab in zip(sids[i].tolist(), slabels[i].tolist()):      # llava_arch.py:454-476: a media token becomes its block, labels -100 over it
+                if tok == cfg.image_token_id:
+                    parts.append(imgi)
+                    labs += [-100] * imgi.shape[0]
+                else:
+                    parts.append(emb(torch.tensor([tok])))
+                    labs.append(lab)
+            ei, li = torch.cat(parts, 0)[None], torch.tensor(labs, dtype=torch.int64)[None]
+            r = llm(inputs_embeds=ei, labels=li, num_items_in_batch=n_items, use_cache=False)
+            ce_sum.append(float(r.loss.double()) * n_items)
+            tr = r.logits[0, sft_rows(ei.shape[1])].float().topk(TOPK, -1)
+            r_ids.append(tr.indices)
+            r_vals.append(tr.values)
+            assert int((li[0, 1:] != -100).sum()) * SFT_B == n_items
+            del r
+            print(f"HF sft sample {i}: CE sum {ce_sum[-1]:.3f} ({time.time() - t3:.0f}s)", flush=True)
+        loss = sum(ce_sum) / n_items
+        print(f"configs[2] forward (HF loss): {loss:.6f} (oracle-executed fixture: {float(src['sft_loss']):.6f})", flush=True)
     top = lg.topk(TOPK, -1)
     out.update({
-        "seed": np.int64(SEED), "input_ids": ids.numpy(), "greedy_ids": np.asarray(gen, dtype=np.int64), "hf_version": np.array(ver),
+        "seed": np.int64(SEED), "input_ids": ids.numpy(), "forced_ids": forced.numpy(), "tf_argmax_ids": lg.argmax(-1).numpy().astype(np.int64),
+        "greedy_ids": np.asarray(gen, dtype=np.int64), "hf_version": np.array(ver),
+        "lm_head_tail": src["lm_head_tail"], "lm_head_tail_seed": src["lm_head_tail_seed"], "lm_head_tail_max": src["lm_head_tail_max"],
+        "sft_input_ids": sids.numpy(), "sft_labels": slabels.numpy(), "sft_fp_pixels": spx.reshape(SFT_B, -1)[:, :16].numpy().copy(),
+        "sft_loss": np.float64(loss), "sft_ce_sums": np.asarray(ce_sum, dtype=np.float64), "sft_num_items": np.int64(n_items),
+        "sft_rows": sft_rows(769).numpy(), "sft_top_ids": torch.stack(r_ids).numpy().astype(np.int32), "sft_top_vals": torch.stack(r_vals).numpy().astype(np.float32),
         "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
         "logit_absmax": lg.abs().amax(-1).numpy().astype(np.float32), "logit_norm": lg.norm(dim=-1).numpy().astype(np.float32),
         "vit_rows": feats[0, [0, 511, 1023], :256].numpy().astype(np.float32), "vit_norm": np.float32(feats.norm()),

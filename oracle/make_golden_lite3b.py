@@ -1,5 +1,5 @@
 """Full-depth fixtures for BASELINE configs[0] — NVILA-Lite-3B-shaped widths (SigLIP 26 layers -> 3x3 projector -> 36-layer Qwen2.5-3B-shaped
-decoder, tied head), 1 x 448^2 image + 32-token prompt (S = 154), 8 greedy steps — TEST INFRASTRUCTURE.
+decoder, tied head), 1 x 448^2 image + 32-token prompt (S = 154), 8 recorded steps — TEST INFRASTRUCTURE.
 
 Writes TWO files from the same seeded synthetic weights:
   * tests/golden/nvila_lite3b_full_depth_ref.npz — REFERENCE-EXECUTED: the reference's modeling_siglip.py and base_projector.py (loaded by file
@@ -7,10 +7,17 @@ Writes TWO files from the same seeded synthetic weights:
   * tests/golden/nvila_lite3b_full_depth.npz — ORACLE-EXECUTED (oracle/vila_oracle.py)
 tests/test_oracle_golden.py compares the two (CPU); tests/test_gpu_full_depth.py holds the HIP path to the reference-executed one.
 
-    python oracle/make_golden_lite3b.py        # ~6 min on 8 cores, ~25 GB RSS; needs /root/reference
+Round 4: the recorded steps are TEACHER-FORCED WITH A RANDOM ID SEQUENCE (`forced_ids`) instead of following greedy
+decoding into a fixed point, and the tail of the tied head's row norms is searched (oracle runs of the decoder; the tied head IS the embedding
+table, so unlike the 8B search every candidate needs its own decoder pass) for distinct argmax tokens with margins inside 4..20x the expected
+bf16 logit error.  The free-running greedy ids of the chosen weights are stored too.
+
+    python oracle/make_golden_lite3b.py        # ~20 min on 8 cores (the search), ~25 GB RSS; needs /root/reference
+    VILA_TAIL=2,10,0 python oracle/make_golden_lite3b.py     # skip the search: tail exponent, cap, seed
 """
 from __future__ import annotations
 
+import copy
 import gc
 import os
 import sys
@@ -24,25 +31,28 @@ sys.path.insert(0, ROOT)
 
 from oracle import make_golden as G                     # noqa: E402
 from oracle import vila_oracle as O                     # noqa: E402
-from oracle.make_golden_full import LazyBf16Weights, N_NEW, TOPK      # noqa: E402
+from oracle.make_golden_full import LazyBf16Weights, N_NEW, TOPK, forced_sequence, score_logits      # noqa: E402
 from oracle.make_golden_full_ref import build_hf_llm_streaming        # noqa: E402
 from vila_amd import configs, synthetic                 # noqa: E402
 
 SEED = 13
 N_TEXT = 32
-TAIL = (2.0, int(os.environ.get("VILA_TAIL_SEED", "0")), 10.0)
+REL_ERR = 0.016          # round-3 GPU run: top-32 logits rel-L2 2.1e-2 at this depth (36 layers, hidden 2048)
+CANDIDATES = [(a, m, s) for s in range(3) for a, m in ((3.0, 4.0), (2.0, 4.0), (4.0, 3.0), (3.0, 6.0), (6.0, 3.0), (2.0, 10.0))]
 KEYS = ("llm.model.layers.0.mlp.gate_proj.weight", "llm.model.layers.35.self_attn.q_proj.bias", "llm.model.embed_tokens.weight",
         "vision_tower.vision_tower.vision_model.encoder.layers.25.mlp.fc1.weight", "mm_projector.layers.2.weight")
 OUT = os.path.join(ROOT, "tests", "golden", "nvila_lite3b_full_depth{}.npz")
+EMB = "llm.model.embed_tokens.weight"
 
 
-def pack(w, px, ids, feats, proj, e, gen, lg, extra):
+def pack(w, cfg, px, ids, forced, feats, proj, e, gen, lg, extra):
     top = lg.topk(TOPK, -1)
     n_img = proj.shape[1]
     out = {f"fp_w{i}": w[k].reshape(-1)[:16].numpy().copy() for i, k in enumerate(KEYS)}
-    out.update({"fp_pixels": px.reshape(-1)[:16].numpy().copy(), "seed": np.int64(SEED), "input_ids": ids.numpy(),
-                "lm_head_tail": np.float32(TAIL[0]), "lm_head_tail_seed": np.int64(TAIL[1]), "lm_head_tail_max": np.float32(TAIL[2]),
-                "greedy_ids": np.asarray(gen, dtype=np.int64), "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
+    out.update({"fp_pixels": px.reshape(-1)[:16].numpy().copy(), "seed": np.int64(SEED), "input_ids": ids.numpy(), "forced_ids": forced.numpy(),
+                "lm_head_tail": np.float32(cfg.lm_head_tail), "lm_head_tail_seed": np.int64(cfg.lm_head_tail_seed), "lm_head_tail_max": np.float32(cfg.lm_head_tail_max),
+                "tf_argmax_ids": lg.argmax(-1).numpy().astype(np.int64), "greedy_ids": np.asarray(gen, dtype=np.int64),
+                "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
                 "logit_absmax": lg.abs().amax(-1).numpy().astype(np.float32), "logit_norm": lg.norm(dim=-1).numpy().astype(np.float32),
                 "vit_rows": feats[0, [0, 511, 1023], :256].numpy().astype(np.float32), "vit_norm": np.float32(feats.norm()),
                 "proj_rows": proj[0, [0, n_img // 2, n_img - 1], :256].numpy().astype(np.float32), "proj_norm": np.float32(proj.norm()),
@@ -51,22 +61,70 @@ def pack(w, px, ids, feats, proj, e, gen, lg, extra):
     return out
 
 
+def oracle_steps(cfg, w, proj, ids, forced, greedy: bool):
+    """Spliced embeds, teacher-forced logits [N_NEW, V] (and the free-running greedy ids) for the CURRENT cfg tail."""
+    lc = cfg.llm
+    end = O.embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+    e, _, _ = O.embed_splice(ids[None], [torch.cat([proj[0], end], 0)], w, cfg)
+    logits, past0 = O.qwen2_forward(e, w, lc)
+    last, past, steps = logits[0, -1], past0, []
+    for t in range(N_NEW):
+        steps.append(last.clone())
+        if t + 1 == N_NEW:
+            break
+        logits, past = O.qwen2_forward(O.embed_tokens(forced[t].view(1, 1), w), w, lc, past=past)
+        last = logits[0, -1]
+    lg = torch.stack(steps).float()
+    gen = []
+    if greedy:
+        past, last = past0, lg[0]
+        for t in range(N_NEW):
+            nxt = int(last.argmax())
+            gen.append(nxt)
+            if t + 1 == N_NEW:
+                break
+            logits, past = O.qwen2_forward(O.embed_tokens(torch.tensor([[nxt]]), w), w, lc, past=past)
+            last = logits[0, -1]
+    return e, lg, gen
+
+
 def main():
     torch.manual_seed(0)
     cfg = configs.nvila_lite_3b()
-    cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = TAIL   # heavy-tailed row norms of the (tied) head: a peaked next-token distribution
     w = LazyBf16Weights(cfg, SEED)
     px = synthetic.make_pixels(cfg, 1, SEED).to(torch.bfloat16).float()
     ids = synthetic.make_prompt(cfg, N_TEXT, 1, SEED)
+    forced = forced_sequence(cfg, N_NEW, SEED)
     t0 = time.time()
     with torch.no_grad():
         # ---- oracle ----
         feats_o = O.vision_tower_forward(px, w, cfg.vision)
         proj_o = O.projector_forward(feats_o, w, cfg.mm_projector_type)
-        e_o, _ = O.vlm_prefill_embeds([px[0]], ids, w, cfg)
-        gen_o, lg_o = O.greedy_generate(e_o, w, cfg, N_NEW, stop_at_eos=False)
-        print(f"oracle: S = {e_o.shape[1]}, ids {gen_o.tolist()} ({time.time() - t0:.0f}s)", flush=True)
-        np.savez_compressed(OUT.format(""), **pack(w, px, ids, feats_o, proj_o, e_o, gen_o.tolist(), lg_o.float(), {}))
+        print(f"oracle tower + projector {time.time() - t0:.0f}s", flush=True)
+        fixed = os.environ.get("VILA_TAIL")
+        cands = [tuple(float(x) for x in fixed.split(","))] if fixed else CANDIDATES
+        best = None
+        for a, m, s in cands:
+            t1 = time.time()
+            cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = float(a), int(s), float(m)
+            w.store.pop(EMB, None)
+            _, lg, _ = oracle_steps(cfg, w, proj_o, ids, forced, greedy=False)
+            scale = synthetic.lm_head_row_scale(EMB, cfg.llm.vocab_size, cfg)
+            # |xn| is not returned by the forward; sqrt(H) x the mean norm gain is what RMSNorm leaves (gains are 1 + 0.1 N(0,1))
+            xn_norm = torch.full((N_NEW,), float(cfg.llm.hidden_size) ** 0.5)
+            sc, am, ratio, margin, err = score_logits(cfg, lg, xn_norm, scale, row_std=cfg.init_std, rel_err=REL_ERR)
+            print(f"tail a={a} max={m} seed={s}: in-band {sc[0]}/{N_NEW}, distinct {sc[1]}, ids {am.tolist()}, margin/err {[round(float(r), 1) for r in ratio]} "
+                  f"({time.time() - t1:.0f}s)", flush=True)
+            if best is None or sc > best[0]:
+                best = (sc, a, m, s)
+            if sc[0] >= N_NEW - 1 and sc[1] >= N_NEW - 2:
+                break
+        _, a, m, s = best
+        cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = float(a), int(s), float(m)
+        w.store.pop(EMB, None)
+        e_o, lg_o, gen_o = oracle_steps(cfg, w, proj_o, ids, forced, greedy=True)
+        print(f"chosen tail a={a} max={m} seed={s}: S = {e_o.shape[1]}, teacher-forced argmax {lg_o.argmax(-1).tolist()}, greedy {gen_o} ({time.time() - t0:.0f}s)", flush=True)
+        np.savez_compressed(OUT.format(""), **pack(w, cfg, px, ids, forced, feats_o, proj_o, e_o, gen_o, lg_o, {}))
         # ---- reference ----
         t1 = time.time()
         vis_w = {k: w[k] for k in w.specs if k.startswith("vision_tower.")}
@@ -81,19 +139,26 @@ def main():
         e = torch.cat([img if t == cfg.image_token_id else emb(torch.tensor([t])) for t in ids.tolist()], 0)[None]
         r = llm(inputs_embeds=e, use_cache=True, logits_to_keep=1)
         past, last = r.past_key_values, r.logits[0, -1].float()
-        gen, steps = [], []
+        past0 = copy.deepcopy(past)
+        steps = []
         for t in range(N_NEW):
             steps.append(last.clone())
+            if t + 1 == N_NEW:
+                break
+            r = llm(input_ids=forced[t].view(1, 1), past_key_values=past, use_cache=True)
+            past, last = r.past_key_values, r.logits[0, -1].float()
+        lg = torch.stack(steps)
+        gen, past, last = [], past0, lg[0]
+        for t in range(N_NEW):
             nxt = int(last.argmax())
             gen.append(nxt)
             if t + 1 == N_NEW:
                 break
             r = llm(input_ids=torch.tensor([[nxt]]), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
-        lg = torch.stack(steps)
-        print(f"reference (HF {ver}): ids {gen} ({time.time() - t1:.0f}s)", flush=True)
+        print(f"reference (HF {ver}): teacher-forced argmax {lg.argmax(-1).tolist()}, greedy {gen} ({time.time() - t1:.0f}s)", flush=True)
         # the embedding table was popped from the lazy store while filling HF: fingerprints re-draw it
-        np.savez_compressed(OUT.format("_ref"), **pack(w, px, ids, feats, proj, e, gen, lg, {"hf_version": np.array(ver)}))
+        np.savez_compressed(OUT.format("_ref"), **pack(w, cfg, px, ids, forced, feats, proj, e, gen, lg, {"hf_version": np.array(ver)}))
     margin = lg.topk(2, -1).values
     print(f"margins {[round(float(a - b), 3) for a, b in margin]}; wrote both fixtures in {time.time() - t0:.0f}s", flush=True)
 

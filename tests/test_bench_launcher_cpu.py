@@ -26,6 +26,11 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     # 2 ranks x 5 steps of >= 2 ms each, max over ranks: the aggregate cannot beat 2 / 2 ms
     assert 0 < out["value"] <= 1000.0 + 1e-6
     assert out["scaling"] == "weak" and out["higher_is_better"] is True
+    # the command the driver runs (`bench.py --gpus N`, default mode) carries the SFT gradient exchange: on the GPU the real step with the
+    # process group on every rank (bench.py sft_side_measurement), here its dry run over gloo
+    sft = out["sft"]
+    assert sft["world"] == 2 and "world=2" in sft["grad_exchange"] and sft["exchange_active"] is True and sft["exchange_ok"] is True
+    assert sft["exchange_bytes"] > 0 and sft["buckets"] >= 8
 
 
 def test_single_rank_needs_no_launcher():

@@ -232,3 +232,69 @@ def test_dp_step_gloo_world2_global_count_loss_scaling_and_identical_masters():
     assert abs((l0 + l1) - (3.0 + 4.0) / want) < 1e-6                      # sum over ranks of (local sum / global count) = global mean CE
     assert m0 == m1, "the two ranks' masters differ (bitwise) after one data-parallel step"
     assert ok0 and ok1 and nb0 == nb1 > 0
+
+
+def _dp_mixed_media_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vila_amd import ops
+        from vila_amd.train import SFTTrainer
+        torch.manual_seed(0)
+        m = _tiny_model()
+        ops.adamw_step = _adamw_reference
+        tr = SFTTrainer(m, lr=1e-2, weight_decay=0.0)
+        tr.flat.grads = tr.flat.grads.float()
+        cfg = m.cfg
+        full = _bucket_order(cfg)[1:] if cfg.llm.tie_word_embeddings else _bucket_order(cfg)
+        media = tr.media_bucket_order()
+        assert full[-len(media):] == media                      # the helper names the buckets the real backward announces, in its order
+        llm_only = full[:-len(media)]
+        L = 10
+        ids = torch.randint(0, 900, (1, L))
+        labels = ids.clone()
+        images = [torch.zeros(3, 4, 4)] if rank == 0 else []    # rank 0: an image batch; rank 1: text only
+        if rank == 0:
+            ids[0, 0] = cfg.image_token_id
+
+        def fake_forward_backward(input_ids, imgs, lab, mask=None, num_items_in_batch=None, block_sizes=None):
+            """The real driver minus the math: what THIS rank's backward reaches is announced, then the shared tail of both drivers."""
+            tr._touched = []
+            tr.reducer.log.clear()
+            tr.flat.grads.zero_()
+            gg = torch.Generator().manual_seed(300 + rank)
+            for pre in (full if len(imgs) else llm_only):
+                a, b = tr.flat.span(pre)
+                tr.flat.grads[a:b] = torch.randn(b - a, generator=gg)
+                tr._ready(pre)
+            tr._announce_absent_media(len(imgs))
+            tr._finish_backward()
+            return torch.tensor(1.0)
+        tr.forward_backward = fake_forward_backward
+        tr.step(ids, images, labels)
+        a, b = tr.flat.span("mm_projector.")
+        import hashlib
+        digest = hashlib.sha256(tr.flat.master.numpy().tobytes()).hexdigest()
+        q.put((rank, [p for p, _, _ in tr.reducer.log], digest, dict(tr.flat.bucket_steps), float(tr.flat.grads[a:b].abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_step_gloo_world2_text_only_rank_takes_part_in_every_media_bucket():
+    """one rank's micro-batch has images, the other's is text-only.  Both must issue the same sequence of all-reduces (the
+    text-only rank announces the projector / tower buckets with zero gradients: llava_arch.py:508-514 does it with a dummy image), end with
+    bit-identical masters and the same per-bucket step counts — a rank that skipped those buckets would hang RCCL or mis-pair slices."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_mixed_media_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    (_, log0, m0, steps0, g0), (_, log1, m1, steps1, g1) = res
+    assert log0 == log1 and any(p.startswith("vision_tower.") for p in log1) and "mm_projector." in log1
+    assert m0 == m1, "masters differ after a step in which only one rank had images"
+    assert steps0 == steps1 and steps1["mm_projector."] == 1
+    assert g0 == g1 > 0                                          # the text-only rank received the other rank's projector gradient

@@ -642,13 +642,8 @@ class SFTTrainer:
                                    self._c_ws.data_ptr(), self._c_ws.numel(), cb, None, ops._stream()), "vila_sft_fwd_bwd")
         if err:
             raise err[0]
-        for st in (self.side, self.opt):
-            if st is not None:
-                torch.cuda.current_stream().wait_stream(st)
-        if not self._bucket_step:
-            self.reducer.wait()
-        else:
-            self.reducer.handles = []
+        self._announce_absent_media(n_img)
+        self._finish_backward()
         return loss[0]
 
     # ------------------------------------------------------------------ the step -------------------------------------------
@@ -759,6 +754,28 @@ class SFTTrainer:
             if s2 is not None:                                                         # adjoint of the merge: back onto the tower's tiles
                 dfeats = ops.s2_merge_bwd(dfeats, s2_tdesc, len(cfg.s2_scales), s2.splits)
             self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
+        self._announce_absent_media(n_img)
+        self._finish_backward()
+        return loss[0]
+
+    def media_bucket_order(self) -> List[str]:
+        """The buckets the projector / tower backward announces, in its order (`_proj_bwd`, `_vit_bwd`; BUCKET_PROJECTOR / BUCKET_VIT_* of the
+        C-ABI step)."""
+        pre = "vision_tower.vision_tower.vision_model."
+        return (["mm_projector."] + [f"{pre}encoder.layers.{i}." for i in reversed(range(self.cfg.vision.num_used_layers))] + [pre + "embeddings."])
+
+    def _announce_absent_media(self, n_img: int) -> None:
+        """Data-parallel ranks must issue the SAME sequence of collectives.  A rank whose micro-batch is text-only while another rank's has
+        images (`self._media_elsewhere`, agreed in `step()` / `agree_on_media`) announces the projector and tower buckets anyway — with the
+        zero gradients its backward left there — so every rank takes part in every bucket's all-reduce and applies the same update with the
+        same per-bucket step count.  The reference gets the same effect by pushing a dummy image through the encoders on ranks without media
+        (llava_arch.py:508-514); here no tower pass is needed, only the rank's seat in the exchange."""
+        if n_img or not getattr(self, "_media_elsewhere", False):
+            return
+        for prefix in self.media_bucket_order():
+            self._ready(prefix)
+
+    def _finish_backward(self) -> None:
         for st in (self.side, self.opt):
             if st is not None:
                 torch.cuda.current_stream().wait_stream(st)
@@ -766,7 +783,6 @@ class SFTTrainer:
             self.reducer.wait()
         else:
             self.reducer.handles = []               # every handle was waited for on the optimizer stream
-        return loss[0]
 
     def optimizer_step(self) -> None:
         f = self.flat
@@ -790,9 +806,23 @@ class SFTTrainer:
             return int(t.item())
         return labels_packed_valid
 
+    def agree_on_media(self, has_media: bool) -> bool:
+        """True when SOME rank of the group has media this step (one MAX all-reduce of a flag; a no-op in a world of one).  Sets
+        `_media_elsewhere` for `_announce_absent_media`.  `step()` calls it; a caller that drives `forward_backward` itself under data
+        parallelism (the autograd seam) calls it through `AutogradSeam.loss`."""
+        import torch.distributed as dist
+        any_media = bool(has_media)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            t = torch.tensor([1 if has_media else 0], device=self.model.device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            any_media = bool(int(t.item()))
+        self._media_elsewhere = any_media and not has_media
+        return any_media
+
     def step(self, input_ids, images, labels, attention_mask=None, block_sizes=None) -> float:
         n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
         n_global = self.global_num_items(n_local)
+        self.agree_on_media(len(images) > 0)
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
         try:
@@ -865,6 +895,7 @@ class AutogradSeam:
         tr = self.trainer
         fb = tr.forward_backward_c if tr.use_c_abi else tr.forward_backward
         tr._bucket_step = False
+        tr.agree_on_media(len(images) > 0)
         return _SftLossFn.apply(self.anchor, self, lambda: fb(input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes))
 
     def deposit(self, g: torch.Tensor) -> None:
