@@ -126,8 +126,30 @@ def test_batched_serving_shares_the_weight_pass(served):
         assert b.batches == [4]
     finally:
         b.close()
-    # the endpoint with a batching window: a lone greedy request still answers (a batch of one falls back to the batch-1 path)
-    client = TestClient(serving.create_app(model, tok, model_name="NVILA-tiny", batch_window_s=0.01))
-    r = client.post("/chat/completions", json={"model": "NVILA-tiny", "max_tokens": 4, "temperature": 0.0, "messages": [{"role": "user", "content": "what is this ?"}]})
+    # the endpoint with a batcher: requests go through the continuous batcher (ONE worker thread owns the model); a lone greedy request is a
+    # live row of the batched step, a sampled one runs solo on the same thread
+    app = serving.create_app(model, tok, model_name="NVILA-tiny", batch_window_s=0.01, max_batch=4)
+    cb = app.state.batcher
+    assert isinstance(cb, serving.ContinuousBatcher)
+    client = TestClient(app)
+    ask = {"model": "NVILA-tiny", "max_tokens": 4, "temperature": 0.0, "messages": [{"role": "user", "content": "what is this ?"}]}
+    r = client.post("/chat/completions", json=ask)
     assert r.status_code == 200, r.text
-    assert r.json()["choices"][0]["message"]["content"][0]["text"] == serving.generate_content(model, tok, "what is this ?", max_new_tokens=4)
+    text = r.json()["choices"][0]["message"]["content"][0]["text"]
+    assert isinstance(text, str) and text
+    assert cb.submit("what is this ?", 4, temperature=0.0).result(timeout=60) == text          # deterministic
+    r = client.post("/chat/completions", json={k: v for k, v in ask.items() if k != "temperature"})        # sampled: solo, same thread
+    assert r.status_code == 200 and any(ev[0] == "solo" for ev in cb.events)
+    # a late request joins the running batch: submit a long reply, then a short one once steps have run
+    import time as _t
+    n0 = len(cb.events)
+    fa = cb.submit([img, "describe the image"], 40)
+    while not any(ev[0] == "run" for ev in cb.events[n0:]):
+        _t.sleep(0.001)
+    fb = cb.submit("a red square", 6)
+    tb, ta = fb.result(timeout=60), fa.result(timeout=60)
+    assert isinstance(ta, str) and isinstance(tb, str)
+    admits = [ev for ev in cb.events[n0:] if ev[0] == "admit"]
+    assert len(admits) == 2 and admits[1][2] > admits[0][2]                                   # B was admitted after steps of A had run
+    assert len(cb.thread_ids) == 1
+    cb.close()

@@ -40,8 +40,9 @@ class _Model:
         self.tok = tok
         self.calls = []
 
-    def generate(self, input_ids, media, max_new_tokens, eos_token_id, **sampling):
+    def generate(self, input_ids, media, max_new_tokens, eos_token_id, media_config=None, **sampling):      # llava_arch.py:823-829
         self.calls.append((input_ids, media, max_new_tokens, eos_token_id))
+        self.media_config = media_config
         self.sampling = sampling
         reply = self.tok("a red square").input_ids + [1, 99]       # EOS then a token that must be dropped
         return torch.tensor([reply])
@@ -178,3 +179,143 @@ def test_request_batcher_groups_concurrent_requests_and_splits_on_settings():
         assert b.batches[:2] == [3, 2]
     finally:
         b.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# continuous batching (server.py:171-290): the scheduler over a stub engine — rows join and leave between steps
+# ----------------------------------------------------------------------------------------------------------------------
+class _StubEngine:
+    """What `HipBatchEngine` offers, minus the GPU: a request "name:n" replies tokens 100+i (i < n) then EOS; every slot — live or idle —
+    advances on every step, exactly like the batched kernel."""
+    eos = {1}
+
+    def __init__(self, n_slots=4, step_sleep=0.0):
+        import threading
+        self.n_slots, self.step_sleep = n_slots, step_sleep
+        self.script = {b: None for b in range(n_slots)}
+        self.n_out = [0] * n_slots
+        self.out = [[] for _ in range(n_slots)]
+        self.threads, self.max_live, self.calls = set(), 0, []
+        self._threading = threading
+
+    def _mark(self, what):
+        self.threads.add(self._threading.get_ident())
+        self.calls.append(what)
+
+    def embed(self, prompt, system):
+        self._mark("embed")
+        from types import SimpleNamespace
+        n = int(prompt.split(":")[1])
+        return SimpleNamespace(shape=(7,), script=[100 + i for i in range(n)] + [1] + [55] * 64)
+
+    def fits(self, n_prompt, max_new):
+        return max_new <= 48
+
+    def admit(self, slot, e):
+        self._mark("admit")
+        self.script[slot], self.n_out[slot], self.out[slot] = e.script, 0, []
+        return e.script[0]
+
+    def run(self, k):
+        import time as _t
+        self._mark("run")
+        self.max_live = max(self.max_live, sum(s is not None for s in self.script.values()))
+        for _ in range(k):
+            _t.sleep(self.step_sleep)
+            for b in range(self.n_slots):
+                sc = self.script[b]
+                self.out[b].append(sc[1 + self.n_out[b]] if sc is not None else 7)
+                self.n_out[b] += 1
+
+    def read(self):
+        self._mark("read")
+        top = max(max(self.n_out), 1)
+        return list(self.n_out), [r[:top] + [0] * (top - len(r)) for r in self.out]
+
+    def release(self, slots):
+        self._mark("release")
+        for b in slots:
+            self.n_out[b], self.out[b] = 0, []
+            if b not in self._live:
+                self.script[b] = None
+
+    _live = ()
+
+    def solo(self, prompt, max_new_tokens, system, **gen):
+        self._mark("solo")
+        assert all(s is None for s in self.script.values()) or not any(self.n_out), "a solo request ran beside live rows"
+        return f"solo {prompt} t={gen.get('temperature')}"
+
+    def decode(self, toks):
+        return " ".join(str(t) for t in toks)
+
+
+def _want(n, max_new=48):
+    return " ".join(str(100 + i) for i in range(min(n, max_new)))
+
+
+def test_continuous_batcher_admits_a_late_request_between_steps_and_retires_rows_at_eos():
+    import threading
+    import time as _t
+    eng = _StubEngine(n_slots=4, step_sleep=0.002)
+    b = serving.ContinuousBatcher(eng, max_batch=4, chunk=4)
+    # the engine must know which rows are live when told to re-wind the idle ones
+    real_release = eng.release
+
+    def release(slots):
+        eng._live = ()
+        real_release(slots)
+    eng.release = release
+    try:
+        fa = b.submit("A:30", 48)
+        while not any(ev[0] == "run" for ev in b.events):
+            _t.sleep(0.001)
+        fb = b.submit("B:5", 48)                                       # arrives while A is mid-reply
+        assert fb.result(timeout=30) == _want(5) and fa.result(timeout=30) == _want(30)
+        admits = [ev for ev in b.events if ev[0] == "admit"]
+        assert len(admits) == 2 and admits[1][2] > 0 and admits[1][3] == 1, admits      # B joined after steps had run, beside one live row
+        retire = [ev for ev in b.events if ev[0] == "retire"]
+        assert retire[0][1] == admits[1][1] and retire[0][2] < retire[1][2]             # B (5 tokens) left first, A went on
+        assert eng.max_live == 2
+        # max_new_tokens cuts a reply; the row is retired at that length
+        assert b.submit("C:40", 10).result(timeout=30) == _want(40, 10)
+        # more requests than rows: slots are handed on as rows retire
+        futs = [b.submit(f"R{i}:{3 + 2 * i}", 48) for i in range(9)]
+        assert [f.result(timeout=60) for f in futs] == [_want(3 + 2 * i) for i in range(9)]
+        assert eng.max_live <= 4 and len([ev for ev in b.events if ev[0] == "admit"]) == 12
+        # a sampled request and one too long for the slots run SOLO on the same worker thread, after the live rows drained, in arrival order
+        f1 = b.submit("L:20", 48)
+        f2 = b.submit("S:4", 16, temperature=0.7, top_p=0.8)
+        f3 = b.submit("T:4", 200)                                      # does not fit the slots' reply capacity
+        f4 = b.submit("U:4", 48)
+        assert f2.result(timeout=30) == "solo S:4 t=0.7" and f3.result(timeout=30).startswith("solo T:4")
+        assert f1.result(timeout=30) == _want(20) and f4.result(timeout=30) == _want(4)
+        assert eng.threads == b.thread_ids and threading.get_ident() not in eng.threads and len(eng.threads) == 1
+    finally:
+        b.close()
+
+
+def test_endpoint_routes_every_request_through_the_one_worker_thread():
+    """with a batcher configured, sampled requests (the default, temperature 0.2) used to run inline on the event-loop thread
+    beside the worker's batch.  Now every request is executed by the batcher's thread."""
+    pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    import threading
+    tok = _Tok()
+    m = _Model(tok)
+    m.llm = None                                                       # no batched step on the stub: the static-window batcher + its model lock
+    seen = []
+    orig = m.generate
+
+    def generate(*a, **k):
+        seen.append(threading.get_ident())
+        return orig(*a, **k)
+    m.generate = generate
+    app = serving.create_app(m, tok, model_name="stub", batch_window_s=0.01)
+    assert isinstance(app.state.batcher, serving.RequestBatcher)
+    client = TestClient(app)
+    body = {"model": "stub", "max_tokens": 4, "messages": [{"role": "user", "content": "what is this ?"}]}
+    assert client.post("/chat/completions", json=body).status_code == 200                              # sampled (default temperature)
+    assert app.state.batcher.model_lock.acquire(timeout=1)             # the lock the sampled request ran under is free again
+    app.state.batcher.model_lock.release()
+    app.state.batcher.close()

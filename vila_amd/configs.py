@@ -93,6 +93,7 @@ class VilaConfig:
     dynamic_s2: bool = False
     s2_scales: tuple = (448, 896, 1344)
     s2_resize_output_to_scale_idx: int = -1
+    max_tiles: int = 12              # configuration_llava.py:52 — the most tiles the last dynamic_s2 scale may use (mm_utils.py:341)
 
     @property
     def mm_hidden_size(self) -> int:

@@ -4,6 +4,9 @@
                      (llava/model/llava_arch.py:412-490, 528-555) as row maps for the gather kernels
   * `repack`       — `repack_multimodal_data`, non-SP branch (llava_arch.py:744-800) + `_get_unpad_data`
                      (llava/model/utils/packing.py:12-21): packed row, restarted positions, cu_seqlens
+  * `s2_plan`      — tile / block bookkeeping of the dynamic_s2 merge (llava_arch.py:298-390)
+  * `find_closest_aspect_ratio`, `dynamic_s2_tile_plan`, `dynamic_s2_preprocess` — the dynamic_s2 TILER (llava/mm_utils.py:283-296,
+                     341-405): which tile grid an image of a given size gets, and the resize + crop that produces the tiles
 """
 from __future__ import annotations
 
@@ -150,3 +153,58 @@ def s2_plan(block_sizes, scales, grid: int, downsample: int):
         blk += bh * bw
     return SimpleNamespace(desc=torch.tensor(desc, dtype=torch.int32), tile_desc=torch.tensor(tdesc, dtype=torch.int32), n_tiles=base,
                            n_blocks=blk, perms=perms, splits=splits)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dynamic_s2 tiler (host half): llava/mm_utils.py:283-296 (find_closest_aspect_ratio), 341-405 (dynamic_s2_preprocess)
+# ----------------------------------------------------------------------------------------------------------------------
+def find_closest_aspect_ratio(aspect_ratio: float, target_ratios, width: int, height: int, image_size: int):
+    """mm_utils.py:283-296: the (cols, rows) grid whose cols / rows is closest to the image's width / height; on an exact tie the LATER
+    candidate wins only if the image has more than half the pixels of that grid (so small images keep the smaller grid)."""
+    best_diff, best = float("inf"), (1, 1)
+    area = width * height
+    for ratio in target_ratios:
+        diff = abs(aspect_ratio - ratio[0] / ratio[1])
+        if diff < best_diff:
+            best_diff, best = diff, ratio
+        elif diff == best_diff and area > 0.5 * image_size * image_size * ratio[0] * ratio[1]:
+            best = ratio
+    return best
+
+
+def dynamic_s2_tile_plan(width: int, height: int, s2_scales=(448, 896, 1344), max_num: int = 12, image_size: int = 448):
+    """The integer half of `dynamic_s2_preprocess` (mm_utils.py:341-405) -> (resizes, block_size).
+    resizes = [((target_w, target_h), [crop boxes (l, t, r, b) in tile order])] — one entry per scale: every scale but the last resizes the
+    image to a SQUARE of (scale / scales[0])^2 tiles; the last scale picks the (cols, rows) grid with min_num <= cols * rows <= max_num,
+    min_num = (scales[-1] // scales[0])^2, closest to the image's aspect ratio.  block_size = (rows, cols) of that last grid — what
+    `merge_features_for_dynamic_s2` receives (llava_arch.py:298-364)."""
+    scales = list(s2_scales)
+    aspect = width / height
+    min_num = (scales[-1] // scales[0]) ** 2
+
+    def boxes(tw: int, th: int):
+        per_row = tw // image_size
+        n = per_row * (th // image_size)
+        return [((i % per_row) * image_size, (i // per_row) * image_size, (i % per_row + 1) * image_size, (i // per_row + 1) * image_size)
+                for i in range(n)]
+    resizes = []
+    for scale in scales[:-1]:
+        k = scale // scales[0]
+        resizes.append(((image_size * k, image_size * k), boxes(image_size * k, image_size * k)))
+    ratios = {(i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1) for j in range(1, n + 1) if min_num <= i * j <= max_num}
+    ratios = sorted(ratios, key=lambda x: x[0] * x[1])            # stable: ties keep the set's iteration order, as in the reference
+    cols, rows = find_closest_aspect_ratio(aspect, ratios, width, height, image_size)
+    resizes.append(((image_size * cols, image_size * rows), boxes(image_size * cols, image_size * rows)))
+    return resizes, (rows, cols)
+
+
+def dynamic_s2_preprocess(image, s2_scales=(448, 896, 1344), max_num: int = 12, image_size: int = 448):
+    """mm_utils.py:341-405 on a PIL image -> (tiles: list of PIL images of image_size^2, block_size (rows, cols)).  `Image.resize` with its
+    default filter (bicubic) exactly as the reference calls it, then the crops of the plan."""
+    w, h = image.size
+    resizes, block_size = dynamic_s2_tile_plan(w, h, s2_scales, max_num, image_size)
+    tiles = []
+    for size, boxes in resizes:
+        resized = image.resize(size)
+        tiles.extend(resized.crop(b) for b in boxes)
+    return tiles, block_size

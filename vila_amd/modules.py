@@ -76,21 +76,30 @@ class _HipModule(nn.Module):
         self._cstruct = None
         self._ws = None
 
-    def _invalidate(self) -> None:
-        """Parameter storage moved (.to(), refuse(), FlatParams re-pointing, W4 quantisation): every cached object that baked in
-        a weight pointer is dropped — the ctypes weight struct and, for the LLM, the decode session with its captured hipGraph."""
-        self._cstruct = None
+    def _drop_decode_session(self) -> None:
         st = getattr(self, "_decode", None)
         if st is not None:
             if getattr(st, "graph", None) is not None:
                 _lib.load().vila_graph_destroy(st.graph)
                 st.graph = None
             self._decode = None
+
+    def _drop_batch_session(self) -> None:
         bst = getattr(self, "_bdecode", None)
         if bst is not None:
             if getattr(bst, "graph", None) is not None:
                 _lib.load().vila_graph_destroy(bst.graph)
+                bst.graph = None
             self._bdecode = None
+
+    def _invalidate(self) -> None:
+        """Parameter storage moved (.to(), refuse(), FlatParams re-pointing, W4 quantisation): every cached object that baked in
+        a weight pointer is dropped — the ctypes weight struct and, for the LLM, both decode sessions with their captured hipGraphs.
+        (A batch-1 session whose cache / length / sampling key changed drops only ITSELF, `_decode_session`: the n-slot batch session
+        with its KV cache and graph survives a server that alternates batched and solo requests — ADVICE round 3.)"""
+        self._cstruct = None
+        self._drop_decode_session()
+        self._drop_batch_session()
 
     def refuse(self) -> None:
         """Re-establish the fused q/k/v storage after an op that re-allocated parameters (.to(), .half(), ...)."""
@@ -425,7 +434,11 @@ class HipQwen2ForCausalLM(_HipModule):
             if sampling is not None:
                 self._decode.seed.fill_(_as_i64(sampling[3]))
             return self._decode
-        self._invalidate()          # another cache / length / weight storage: drop the old session and its graph
+        old = self._decode
+        if old is not None and old.key[2:4] != key[2:4]:
+            self._invalidate()      # the weight storage moved: nothing that baked in a pointer survives
+        else:
+            self._drop_decode_session()          # another cache / length / sampling setting: only this session and its graph
         dev = self.device
         lib = _lib.load()
         w = self._struct()
@@ -482,8 +495,19 @@ class HipQwen2ForCausalLM(_HipModule):
         c = self.lcfg
         Bn, S = inputs_embeds.shape[0], inputs_embeds.shape[1]
         return (not do_sample and forced_ids is None and not return_logits and cache is None and getattr(self, "_w4", None) is None and
-                2 <= Bn <= 16 and c.head_dim == 128 and c.hidden_size % 64 == 0 and c.intermediate_size % 64 == 0 and
+                max_new_tokens >= 1 and self._qkv_fused() and 2 <= Bn <= 16 and c.head_dim == 128 and c.hidden_size % 64 == 0 and c.intermediate_size % 64 == 0 and
                 ((S + max_new_tokens + 255) // 256) * 256 <= 2048)
+
+    def _qkv_fused(self) -> bool:
+        """q/k/v of every layer are views of one buffer (the batched step reads them as ONE [q + 2kv, hidden] matrix); `refuse()` re-establishes
+        it after an op that re-allocated parameters — a model somebody un-fused falls back to the per-row loop instead of raising."""
+        c = self.lcfg
+        for i in range(c.num_hidden_layers):
+            a = _get(self, f"model.layers.{i}.self_attn")
+            q, k, v = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight
+            if k.data_ptr() != q.data_ptr() + q.numel() * q.element_size() or v.data_ptr() != k.data_ptr() + k.numel() * k.element_size():
+                return False
+        return True
 
     def _batch_session(self, n: int, max_ctx: int, max_new_tokens: int):
         key = (n, max_ctx, max_new_tokens, self.model.embed_tokens.weight.data_ptr(), _get(self, "model.layers.0.mlp.down_proj.weight").data_ptr())
@@ -512,9 +536,74 @@ class HipQwen2ForCausalLM(_HipModule):
         check(_lib.load().vila_llm_decode_step_batch(C.byref(self._struct()), C.byref(st.cache.c), C.byref(st.c), st.ws.data_ptr(), st.ws.numel(),
                                                      ops._stream()), "vila_llm_decode_step_batch")
 
-    def _generate_batch(self, inputs_embeds, attention_mask, max_new_tokens, eos_token_id, pad_token_id, use_graph: bool = True):
+    # ---- continuous batching (server.py:171-290 serves requests as they arrive): rows join and leave BETWEEN steps ---------
+    # `vila_llm_decode_step_batch` takes per-row positions / output counters, so admission is host work: prefill the newcomer alone into its
+    # KV slot, set the row's position and first token, replay the same captured graph.  A free row idles at positions 0..15 of its own slot
+    # (re-wound after every chunk), which costs nothing extra: the step streams the weights once whatever the number of live rows.
+    def batch_open(self, n_slots: int, max_ctx: int = 2048, max_new_tokens: int = 1024):
+        c = self.lcfg
+        if not (1 <= n_slots <= 16 and c.head_dim == 128 and max_ctx <= 2048 and getattr(self, "_w4", None) is None and self._qkv_fused()):
+            raise ValueError("batch_open: the batched decode step serves 1..16 rows of a bf16 head-dim-128 model with caches <= 2048 positions")
+        st = self._batch_session(max(n_slots, 2), max_ctx, max_new_tokens)
+        st.pos.zero_(); st.n_out.zero_(); st.token.zero_()
+        if st.graph is None:
+            lib = _lib.load()
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(st.stream):
+                self._batch_step(st)                                   # warm-up outside capture (kernel attributes)
+                st.stream.synchronize()
+                st.pos.zero_(); st.n_out.zero_(); st.token.zero_()
+                check(lib.vila_graph_begin(st.stream.cuda_stream), "graph_begin")
+                self._batch_step(st)
+                g = C.c_void_p()
+                check(lib.vila_graph_end(st.stream.cuda_stream, C.byref(g)), "graph_end")
+                st.graph = g
+                st.stream.synchronize()
+                st.pos.zero_(); st.n_out.zero_(); st.token.zero_()
+        return st
+
+    def batch_admit(self, st, slot: int, embeds: torch.Tensor) -> int:
+        """Prefill ONE sequence [S, H] into KV slot `slot` of the open batch and make the row live: position S, first token = argmax of the
+        prefill's last row (returned), output counter 0."""
+        S = int(embeds.shape[0])
+        if S + 1 > st.cache.max_ctx:
+            raise ValueError(f"KV cache too small: {st.cache.max_ctx} < {S} + 1")
+        dev = embeds.device
+        st.stream.synchronize()                                        # no step is reading the cache while the newcomer's rows are written
+        pos = torch.arange(S, device=dev, dtype=torch.int32)
+        seq = torch.full((S,), int(slot), device=dev, dtype=torch.int32)
+        cu = torch.tensor([0, S], device=dev, dtype=torch.int32)
+        last = torch.full((1,), S - 1, device=dev, dtype=torch.int32)
+        r = self.prefill_packed(embeds.to(self.dtype), pos, cu, S, cache=st.cache, seq_of_tok=seq, last_rows=last)
+        first = ops.argmax(r.last_logits[0])
+        st.pos[slot:slot + 1].fill_(S)
+        st.n_out[slot:slot + 1].zero_()
+        st.token[slot:slot + 1].copy_(first)
+        tok = int(first.item())                                        # (also orders the prefill before the next replay on st.stream)
+        return tok
+
+    def batch_run(self, st, k: int) -> None:
+        lib = _lib.load()
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(st.stream):
+            for _ in range(int(k)):
+                check(lib.vila_graph_launch(st.graph, st.stream.cuda_stream), "graph_launch")
+        st.stream.synchronize()
+
+    def batch_release(self, st, slots) -> None:
+        """Rows that finished (or never started): re-wound to position 0 of their own slot so an idle row never walks off its cache."""
+        slots = list(slots)
+        if slots:
+            idx = torch.tensor(slots, device=st.pos.device, dtype=torch.int64)
+            st.pos.index_fill_(0, idx, 0)
+            st.n_out.index_fill_(0, idx, 0)
+
+    def _generate_batch(self, inputs_embeds, attention_mask, max_new_tokens, eos_token_id, pad_token_id, use_graph: bool = True,
+                        forced_ids: Optional[torch.Tensor] = None, return_logits: bool = False):
         """The padded batch as ONE packed prefill (every row into its own KV-cache slot) + batched decode steps: the weights are streamed
-        once per step for all rows.  Returns [B, n_new] right-padded with pad_token_id behind each row's EOS, like HF."""
+        once per step for all rows.  Returns [B, n_new] right-padded with pad_token_id behind each row's EOS, like HF.
+        forced_ids [B, n_new] / return_logits: teacher forcing for the parity tests (eager launches; the ids fed after step t are
+        forced_ids[:, t]); returns (argmax ids [B, n_new], logits [n_new, B, V] fp32)."""
         ops._need(inputs_embeds, dtype=None, name="inputs_embeds")
         Bn, S, H = inputs_embeds.shape
         dev = inputs_embeds.device
@@ -539,6 +628,20 @@ class HipQwen2ForCausalLM(_HipModule):
         eos_set = set(eos) if isinstance(eos, (list, tuple)) else {eos}
         n_steps = max_new_tokens - 1
         lib = _lib.load()
+        if forced_ids is not None or return_logits:
+            step_logits, ids = [r.last_logits[:Bn].float().clone()], [first]
+            if forced_ids is not None:
+                st.token.copy_(forced_ids[:, 0].to(dev))
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(st.stream):
+                for t in range(n_steps):
+                    self._batch_step(st)
+                    step_logits.append(st.logits[:Bn].float().clone())
+                    ids.append(torch.cat([ops.argmax(st.logits[b]) for b in range(Bn)]))
+                    if forced_ids is not None and t + 1 < forced_ids.shape[1]:
+                        st.token.copy_(forced_ids[:, t + 1].to(dev))
+            st.stream.synchronize()
+            return torch.stack(ids, 1), torch.stack(step_logits, 0)
         if use_graph and st.graph is None and n_steps > 0:
             torch.cuda.current_stream().synchronize()
             with torch.cuda.stream(st.stream):

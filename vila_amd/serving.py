@@ -17,6 +17,7 @@ import json
 import re
 import time
 import uuid
+from types import SimpleNamespace
 from typing import Any, Dict, Iterator, List, Optional, Sequence, Union
 
 import numpy as np
@@ -27,20 +28,44 @@ MEDIA_TOKENS = {"image": "<image>", "video": "<vila/video>"}          # llava/co
 _DATA_URL = re.compile(r"^data:image/(png|jpe?g);base64,(.*)$", re.S)
 
 
-def preprocess_image(img, size: int) -> torch.Tensor:
-    """PIL image / HxWx3 uint8 array / 3xHxW float tensor in [0,1] -> [3, size, size] float32 in [-1, 1] (SigLIP processor semantics)."""
+def _to_pil(img):
+    """PIL image / HxWx3 uint8 array / 3xHxW (or HxWx3) tensor in [0,1] or [0,255] -> PIL RGB image."""
+    from PIL import Image
+    if hasattr(img, "convert"):
+        return img.convert("RGB")                                    # mm_utils.py:452
     if isinstance(img, torch.Tensor):
-        x = img.float()
-        if x.dim() == 3 and x.shape[0] != 3 and x.shape[-1] == 3:
-            x = x.permute(2, 0, 1)
-        if x.max() > 1.5:
-            x = x / 255.0
-    else:
-        arr = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)
-        x = torch.from_numpy(arr.copy()).float().permute(2, 0, 1) / 255.0
-    if x.shape[-2:] != (size, size):
-        x = torch.nn.functional.interpolate(x[None], size=(size, size), mode="bicubic", align_corners=False, antialias=True)[0].clamp(0, 1)
-    return (x - 0.5) / 0.5
+        x = img.detach().float().cpu()
+        if x.dim() == 3 and x.shape[0] == 3 and x.shape[-1] != 3:
+            x = x.permute(1, 2, 0)
+        if x.max() <= 1.5:
+            x = x * 255.0
+        img = x.round().clamp(0, 255).to(torch.uint8).numpy()
+    return Image.fromarray(np.ascontiguousarray(np.asarray(img, dtype=np.uint8)), "RGB")
+
+
+def preprocess_image(img, size: int) -> torch.Tensor:
+    """-> [3, size, size] float32 in [-1, 1], the pixels `SiglipImageProcessor.preprocess` hands the tower (mm_utils.py:442-541, row a1): PIL
+    bicubic resize to size x size (skipped when the image already has that size), rescale by 1/255, normalise with mean = std = 0.5.
+    PIL does the resampling — the reference's input producer is kept as it is, so the pixels ARE the reference's
+    (tests/test_s2_tiler_cpu.py holds this function to HF-processor-executed vectors)."""
+    from PIL import Image
+    pil = _to_pil(img)
+    if pil.size != (size, size):
+        pil = pil.resize((size, size), resample=Image.BICUBIC)
+    x = torch.from_numpy(np.asarray(pil, dtype=np.uint8).copy()).permute(2, 0, 1).float()
+    return (x * (1.0 / 255.0) - 0.5) / 0.5
+
+
+def preprocess_media(images, cfg):
+    """The media half of `generate_content` (llava_arch.py:857-879): one image under the dynamic_s2 recipe becomes the tiles of every scale
+    (`dynamic_s2_preprocess`, mm_utils.py:341-405 -> vila_amd.host) with media_config["image"]["block_sizes"] = [block_size]; otherwise every
+    image is resized to the tower's resolution (`process_images`).  -> (list of [3, size, size] float tensors, media_config)."""
+    from .host import dynamic_s2_preprocess
+    size = cfg.vision.image_size
+    if getattr(cfg, "dynamic_s2", False) and len(images) == 1:
+        tiles, block_size = dynamic_s2_preprocess(_to_pil(images[0]), list(cfg.s2_scales), int(getattr(cfg, "max_tiles", 12)), size)
+        return [preprocess_image(t, size) for t in tiles], {"image": {"block_sizes": [block_size]}}
+    return [preprocess_image(im, size) for im in images], {}
 
 
 def load_image(url: str):
@@ -95,12 +120,13 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
     cfg = model.cfg
     dev = device or str(model.device)
     ids = encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
-    media = {"image": [preprocess_image(im, cfg.vision.image_size).to(device=dev, dtype=torch.bfloat16) for im in images]}
+    tiles, media_config = preprocess_media(images, cfg)
+    media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
     gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
     if temperature and temperature > 0:
         gen.update(do_sample=True, temperature=float(temperature), top_p=float(top_p), top_k=int(top_k), seed=seed)
-    out = model.generate(input_ids=ids, media=media, **gen)
+    out = model.generate(input_ids=ids, media=media, media_config=media_config, **gen)
     toks = out[0].tolist()
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
     for k, t in enumerate(toks):                       # HF returns the EOS as the last token; decode(skip_special_tokens) drops it
@@ -119,11 +145,13 @@ def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequen
         return []
     cfg = model.cfg
     dev = device or str(model.device)
-    rows, images = [], []
+    rows, tiles, blocks = [], [], []
     for prompt in prompts:
         text, imgs = _split_prompt(prompt)
         rows.append(encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id))
-        images.extend(imgs)
+        t, mc = preprocess_media(imgs, cfg)                   # per request, like generate_content: one image -> the dynamic_s2 tiles
+        tiles.extend(t)
+        blocks.extend(mc.get("image", {}).get("block_sizes", [None] * len(imgs)))
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
     pad = pad_token_id if pad_token_id is not None else (getattr(tokenizer, "pad_token_id", None) or 0)
@@ -133,9 +161,10 @@ def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequen
     for b, r in enumerate(rows):
         ids[b, : r.numel()] = r
         mask[b, : r.numel()] = True
-    media = {"image": [preprocess_image(im, cfg.vision.image_size).to(device=dev, dtype=torch.bfloat16) for im in images]}
-    out = model.generate(input_ids=ids.to(dev), media=media, attention_mask=mask.to(dev), max_new_tokens=max_new_tokens, eos_token_id=eos,
-                         pad_token_id=int(pad))
+    media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
+    media_config = {"image": {"block_sizes": blocks}} if any(b is not None for b in blocks) else {}
+    out = model.generate(input_ids=ids.to(dev), media=media, media_config=media_config, attention_mask=mask.to(dev), max_new_tokens=max_new_tokens,
+                         eos_token_id=eos, pad_token_id=int(pad))
     replies = []
     for row in out.tolist():
         toks = row
@@ -159,6 +188,7 @@ class RequestBatcher:
         self._run = run or (lambda prompts, n, system: generate_content_batch(self.model, self.tokenizer, prompts, max_new_tokens=n, system=system))
         self._q: "queue.Queue" = queue.Queue()
         self.batches: List[int] = []                     # sizes of the batches that ran (observability / tests)
+        self.model_lock = threading.Lock()               # whoever drives the model outside the worker (sampled requests) holds this
         self._stop = False
         self._thread = threading.Thread(target=self._loop, daemon=True)
         self._thread.start()
@@ -197,7 +227,7 @@ class RequestBatcher:
                     break
                 group.append(nxt)
             try:
-                with torch.inference_mode():
+                with self.model_lock, torch.inference_mode():
                     replies = self._run([g[0] for g in group], item[1], item[2])
                 self.batches.append(len(group))
                 for g, r in zip(group, replies):
@@ -205,6 +235,197 @@ class RequestBatcher:
             except Exception as e:                                    # every waiter of the group sees the failure
                 for g in group:
                     g[3].set_exception(e)
+
+
+class HipBatchEngine:
+    """The model side of `ContinuousBatcher`: KV slots of ONE open batched-decode session (`HipQwen2ForCausalLM.batch_open`), driven by
+    the batcher's worker thread only."""
+
+    def __init__(self, model, tokenizer, n_slots: int = 8, max_ctx: int = 2048, max_new_tokens: int = 1024, eos_token_id=None):
+        self.model, self.tokenizer = model, tokenizer
+        self.n_slots, self.max_ctx, self.max_new_tokens = int(n_slots), int(max_ctx), int(max_new_tokens)
+        eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+        self.eos = set(eos) if isinstance(eos, (list, tuple)) else {eos}
+        self.st = None
+
+    def _session(self):
+        llm = self.model.llm
+        if self.st is None or getattr(llm, "_bdecode", None) is not self.st:       # first use, or the weights moved and the session was dropped
+            self.st = llm.batch_open(self.n_slots, self.max_ctx, self.max_new_tokens)
+        return self.st
+
+    def fits(self, n_prompt_tokens: int, max_new_tokens: int) -> bool:
+        return max_new_tokens <= self.max_new_tokens and n_prompt_tokens + max_new_tokens <= self.max_ctx
+
+    def embed(self, prompt, system):
+        """Prompt -> spliced embeddings [S, H] on the device (tower + projector + splice run here, on the worker thread)."""
+        cfg = self.model.cfg
+        dev = str(self.model.device)
+        text, images = _split_prompt(prompt)
+        ids = encode_with_images(self.tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
+        tiles, media_config = preprocess_media(images, cfg)
+        media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
+        e, _, _ = self.model._embed(ids, media, media_config)
+        return e[0]
+
+    def admit(self, slot: int, embeds) -> int:
+        return self.model.llm.batch_admit(self._session(), slot, embeds)
+
+    def run(self, k: int) -> None:
+        self.model.llm.batch_run(self._session(), k)
+
+    def read(self):
+        st = self._session()
+        n = st.n_out.tolist()
+        top = max(max(n), 1)
+        return n, st.out_ids[:, :min(top, st.out_ids.shape[1])].tolist()
+
+    def release(self, slots) -> None:
+        self.model.llm.batch_release(self._session(), slots)
+
+    def solo(self, prompt, max_new_tokens, system, **gen) -> str:
+        return generate_content(self.model, self.tokenizer, prompt, max_new_tokens=max_new_tokens, system=system, **gen)
+
+    def decode(self, toks) -> str:
+        return self.tokenizer.decode(toks, skip_special_tokens=True).strip()
+
+
+class ContinuousBatcher:
+    """Continuous batching in front of the batched decode step (the reference's server answers requests as they arrive,
+    server.py:171-290).  ONE worker thread owns the model (every request — greedy, sampled, batched or not — is executed by
+    it, so no two threads ever drive the sessions, the staging buffers or the captured graphs).  Between chunks of <= `chunk` decode steps the
+    worker admits waiting greedy requests into free rows (each newcomer is prefilled alone into its KV slot and joins the next step), retires
+    rows at EOS / max_new_tokens and hands their slot to the next request — a request that arrives one step after a batch started waits for at
+    most one chunk, not for the whole batch.  Requests the batched step cannot serve (sampling, replies or prompts beyond the slots' cache) run
+    solo on the same thread once the live rows have drained; arrival order is kept (a solo request at the head blocks later admissions)."""
+
+    def __init__(self, engine, max_batch: int = 8, chunk: int = 8):
+        import queue
+        import threading
+        self.engine = engine
+        self.max_batch = int(max(1, min(16, max_batch, getattr(engine, "n_slots", max_batch))))
+        self.chunk = int(max(1, chunk))
+        self._q: "queue.Queue" = queue.Queue()
+        self.events: List[tuple] = []                    # ("admit" | "retire" | "solo" | "run", ...) — observability / tests
+        self.thread_ids = set()
+        self._stop = False
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def submit(self, prompt, max_new_tokens: int = 128, system: Optional[str] = None, **gen):
+        """-> Future of the decoded reply.  gen: temperature / top_p / top_k / seed — a request with temperature > 0 is a solo one."""
+        from concurrent.futures import Future
+        f: Future = Future()
+        self._q.put(SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f))
+        return f
+
+    def close(self):
+        self._stop = True
+        self._q.put(None)
+        self._thread.join(timeout=10)
+
+    @staticmethod
+    def _greedy(req) -> bool:
+        t = req.gen.get("temperature")
+        return not t or t <= 0
+
+    def _finish(self, row, toks):
+        eng = self.engine
+        for k, t in enumerate(toks):                       # HF stops AFTER emitting eos; decode(skip_special_tokens) drops it
+            if t in eng.eos:
+                toks = toks[:k]
+                break
+        row.req.fut.set_result(eng.decode(toks))
+
+    def _loop(self):
+        import collections
+        import queue
+        import threading
+        self.thread_ids.add(threading.get_ident())
+        eng = self.engine
+        pending = collections.deque()
+        rows: Dict[int, Any] = {}
+        free = list(range(self.max_batch))
+        steps = 0
+        with torch.inference_mode():
+            while True:
+                # ---- take what has arrived (block only when there is nothing to do) ----
+                while True:
+                    try:
+                        item = self._q.get(block=not rows and not pending)
+                    except queue.Empty:
+                        break
+                    if item is None:
+                        self._stop = True
+                        break
+                    pending.append(item)
+                if self._stop:
+                    for r in list(rows.values()) + [SimpleNamespace(req=p) for p in pending]:
+                        if not r.req.fut.done():
+                            r.req.fut.set_exception(RuntimeError("batcher closed"))
+                    return
+                # ---- admit greedy requests at the head of the line into free rows; a solo request waits for the rows to drain ----
+                while pending and free:
+                    req = pending[0]
+                    try:
+                        if not self._greedy(req) or req.gen.get("_solo"):
+                            break
+                        e = eng.embed(req.prompt, req.system)
+                        if not eng.fits(int(e.shape[0]), req.max_new) or req.max_new < 1:
+                            req.gen = dict(req.gen, _solo=True)
+                            break
+                        pending.popleft()
+                        slot = free.pop(0)
+                        first = eng.admit(slot, e)
+                        row = SimpleNamespace(req=req, toks=[first], read=0)
+                        self.events.append(("admit", slot, steps, len(rows)))
+                        if first in eng.eos or req.max_new <= 1:
+                            self._finish(row, row.toks)
+                            eng.release([slot])
+                            free.append(slot)
+                            self.events.append(("retire", slot, steps))
+                        else:
+                            rows[slot] = row
+                    except Exception as ex:                            # the request fails, the batch goes on
+                        if pending and pending[0] is req:
+                            pending.popleft()
+                        req.fut.set_exception(ex)
+                if not rows:
+                    if pending and (not self._greedy(pending[0]) or pending[0].gen.get("_solo")):
+                        req = pending.popleft()
+                        gen = {k: v for k, v in req.gen.items() if k != "_solo" and v is not None}
+                        self.events.append(("solo", steps))
+                        try:
+                            req.fut.set_result(eng.solo(req.prompt, req.max_new, req.system, **gen))
+                        except Exception as ex:
+                            req.fut.set_exception(ex)
+                    continue
+                # ---- one chunk of batched steps: never past the row that is closest to its max_new_tokens ----
+                k = min(self.chunk, min(r.req.max_new - len(r.toks) for r in rows.values()))
+                try:
+                    eng.run(k)
+                    n_out, out = eng.read()
+                except Exception as ex:
+                    for r in rows.values():
+                        r.req.fut.set_exception(ex)
+                    free.extend(rows)
+                    rows.clear()
+                    continue
+                steps += k
+                self.events.append(("run", k, len(rows)))
+                done = []
+                for slot, row in rows.items():
+                    row.toks.extend(out[slot][row.read:n_out[slot]])
+                    row.read = n_out[slot]
+                    if any(t in eng.eos for t in row.toks) or len(row.toks) >= row.req.max_new:
+                        self._finish(row, row.toks[:row.req.max_new])
+                        done.append(slot)
+                for slot in done:
+                    del rows[slot]
+                    self.events.append(("retire", slot, steps))
+                idle = done + free                                     # idle rows took part in the steps too: re-wind them
+                eng.release(idle)
+                free.extend(done)
 
 
 _MODELS = None
@@ -223,15 +444,25 @@ def _request_models():
     return _MODELS
 
 
-def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: Optional[float] = None):
+def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: Optional[float] = None, max_batch: int = 8):
     """FastAPI app with the reference's POST /chat/completions (server.py:171-290).  Import-time optional: needs fastapi + pydantic.
-    batch_window_s: when set, greedy requests (temperature 0) that arrive within that window share a batched decode (`RequestBatcher`)."""
+    batch_window_s: when set (any value), requests go through a batcher whose ONE worker thread owns the model: `ContinuousBatcher` (greedy
+    requests join / leave the batched decode step between steps; sampled ones run solo on the same thread) where the model has the batched
+    step, else `RequestBatcher` (greedy requests that arrive within the window share a batch; the rest run under the batcher's lock)."""
     from fastapi import FastAPI
     from fastapi.responses import JSONResponse, StreamingResponse
 
     ChatMessage, ChatCompletionRequest = _request_models()
     app = FastAPI()
-    batcher = RequestBatcher(model, tokenizer, window_s=batch_window_s) if batch_window_s is not None else None
+    batcher = None
+    if batch_window_s is not None:
+        # continuous batching when the model has the batched decode step (a bf16 head-dim-128 decoder); else the static-window batcher
+        try:
+            ok = hasattr(model.llm, "batch_open") and model.llm.lcfg.head_dim == 128 and getattr(model.llm, "_w4", None) is None
+        except AttributeError:
+            ok = False
+        batcher = ContinuousBatcher(HipBatchEngine(model, tokenizer, n_slots=max_batch), max_batch=max_batch) if ok else \
+            RequestBatcher(model, tokenizer, window_s=batch_window_s)
     app.state.batcher = batcher
 
     def _prompt_of(messages):
@@ -261,14 +492,23 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: O
                 raise ValueError(f"The endpoint is configured to use the model {model_name}, but the request model is {request.model}")
             parts, system = _prompt_of(request.messages)
             temperature = request.temperature if request.temperature is not None else 0.2
-            if batcher is not None and not temperature:
+            top_p = request.top_p if request.top_p is not None else 0.9
+            if isinstance(batcher, ContinuousBatcher):
+                import asyncio
+                fut = batcher.submit(parts, request.max_tokens or 512, system, temperature=temperature, top_p=top_p)
+                text = await asyncio.get_running_loop().run_in_executor(None, fut.result)
+            elif batcher is not None and not temperature:
                 import asyncio
                 fut = batcher.submit(parts, request.max_tokens or 512, system)
                 text = await asyncio.get_running_loop().run_in_executor(None, fut.result)
+            elif batcher is not None:
+                with batcher.model_lock, torch.inference_mode():      # never beside the worker thread's batch
+                    text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
+                                            temperature=temperature, top_p=top_p)
             else:
                 with torch.inference_mode():
                     text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
-                                            temperature=temperature, top_p=request.top_p if request.top_p is not None else 0.9)
+                                            temperature=temperature, top_p=top_p)
             if request.stream:
                 def chunks() -> Iterator[str]:
                     for i, word in enumerate(re.findall(r"\S+\s*", text)):
