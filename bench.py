@@ -634,6 +634,9 @@ def decode_main(a, rank, world, dev, dist):
         elapsed = float(t.item())
     n_generated = int(st.n_out.item())
     assert n_generated == a.warmup + a.steps, (n_generated, a.warmup, a.steps)
+    chain_err = int(lib.vila_llm_decode_chain_error(st.ws.data_ptr(), stream.cuda_stream))
+    assert chain_err == 0, "chained decode step: a bounded wait gave up — the timed tokens are invalid"
+    chained = os.environ.get("VILA_DECODE_CHAIN", "1") != "0" and not a.w4 and cache.max_ctx <= 2048
     ctx_mid = S + a.warmup + a.steps // 2
     step_bytes = decode_bytes_per_token(cfg, ctx_mid, a.w4)
     step_s = elapsed / a.steps
@@ -741,7 +744,7 @@ def decode_main(a, rank, world, dev, dist):
         "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
         "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}{' + W8A8 vision tower' if a.w8_vit else ''}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
                                f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                   "decode": f"hipGraph replay of {launches} launches/token",
+                   "decode": f"hipGraph replay of {launches} launches/token" + (", kernels chained over two streams (each streams its weights under its predecessor's tail)" if chained else ""),
                    **({"parity": "unpinned against the reference (its quantised backend, TinyChat / llm-awq, is external: no reference-held vectors); "
                                  "pinned against the dequantise-then-fp32 oracle of the same quantised weights"} if (a.w4 or a.w8_vit) else {})},
         "roofline": roofline,

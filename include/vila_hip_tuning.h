@@ -1,7 +1,7 @@
 /* vila_hip_tuning.h — tuning and test switches of libvila_hip.so.  NOT part of the drop-in boundary (include/vila_hip.h):
  * these are PROCESS-GLOBAL, not thread-safe, and exist for the A/B measurements under tools/ and for the parity tests that pin one
  * kernel variant (tests/test_gpu_ops.py).  A product binding never calls them; every switch defaults to the measured-best policy.
- * Environment equivalents read once at first use: VILA_GEMM_EX, VILA_ATTN_FWD=v1, VILA_ATTN_BWD=v1, VILA_DECODE_ATTN. */
+ * Environment equivalents read once at first use: VILA_GEMM_EX, VILA_ATTN_FWD=v1, VILA_ATTN_BWD=v1, VILA_DECODE_ATTN, VILA_DECODE_CHAIN. */
 #ifndef VILA_HIP_TUNING_H
 #define VILA_HIP_TUNING_H
 #ifdef __cplusplus
@@ -15,6 +15,9 @@ void vila_gemm_force_hybrid(int on);
 /* tuning hook for the decode step's attention (caches up to 2048 positions): 2 (default) / 1 = per-head blocks over 256-key slices with the
  * merge in the o_proj GEMV's prologue (512 / 256 o_proj blocks), 0 = one block per query head over the whole context + plain o_proj */
 void vila_decode_force_attn(int mode);
+/* the batch-1 decode step's kernels chained over two streams (api.hip "chained decode step": kernel i streams its weights while kernel i-1
+ * finishes, then waits on its done counter): 1 = on (default), 0 = the plain single-stream step */
+void vila_decode_force_chain(int on);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible */

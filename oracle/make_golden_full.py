@@ -194,10 +194,12 @@ def main():
         print(f"chosen tail a={a} max={m} seed={s}: teacher-forced argmax {tf_ids.tolist()}, margins {[round(float(x), 3) for x in margin]}, "
               f"expected err {[round(float(x), 3) for x in err]}, ratio {[round(float(x), 1) for x in ratio]}", flush=True)
         # free-running greedy with the chosen head, from the prefill's cache
-        gen, past, last = [], past0, lg[0]
+        gen, gmargin, past, last = [], [], past0, lg[0]
         for t in range(N_NEW):
             nxt = int(last.argmax())
             gen.append(nxt)
+            t2v = last.topk(2).values
+            gmargin.append(float(t2v[0] - t2v[1]))
             if t + 1 == N_NEW:
                 break
             logits, past = O.qwen2_forward(O.embed_tokens(torch.tensor([[nxt]]), w), w, lc, past=past)
@@ -222,7 +224,7 @@ def main():
     top = lg.topk(TOPK, -1)
     out.update({
         "seed": np.int64(SEED), "input_ids": ids.numpy(), "forced_ids": forced.numpy(), "tf_argmax_ids": tf_ids.numpy().astype(np.int64),
-        "greedy_ids": np.asarray(gen, dtype=np.int64),
+        "greedy_ids": np.asarray(gen, dtype=np.int64), "greedy_margins": np.asarray(gmargin, dtype=np.float32),
         "lm_head_tail": np.float32(a), "lm_head_tail_seed": np.int64(s), "lm_head_tail_max": np.float32(m),
         "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
         "logit_absmax": lg.abs().amax(-1).numpy().astype(np.float32), "logit_norm": lg.norm(dim=-1).numpy().astype(np.float32),

@@ -129,10 +129,12 @@ def main():
             r = llm(input_ids=forced[t].view(1, 1), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
         lg = torch.stack(step_logits)
-        gen, past, last = [], past0, lg[0]
+        gen, gmargin, past, last = [], [], past0, lg[0]
         for t in range(N_NEW):                                               # free-running greedy
             nxt = int(last.argmax())
             gen.append(nxt)
+            t2v = last.topk(2).values
+            gmargin.append(float(t2v[0] - t2v[1]))
             if t + 1 == N_NEW:
                 break
             r = llm(input_ids=torch.tensor([[nxt]]), past_key_values=past, use_cache=True)
@@ -167,7 +169,7 @@ def main():
     top = lg.topk(TOPK, -1)
     out.update({
         "seed": np.int64(SEED), "input_ids": ids.numpy(), "forced_ids": forced.numpy(), "tf_argmax_ids": lg.argmax(-1).numpy().astype(np.int64),
-        "greedy_ids": np.asarray(gen, dtype=np.int64), "hf_version": np.array(ver),
+        "greedy_ids": np.asarray(gen, dtype=np.int64), "greedy_margins": np.asarray(gmargin, dtype=np.float32), "hf_version": np.array(ver),
         "lm_head_tail": src["lm_head_tail"], "lm_head_tail_seed": src["lm_head_tail_seed"], "lm_head_tail_max": src["lm_head_tail_max"],
         "sft_input_ids": sids.numpy(), "sft_labels": slabels.numpy(), "sft_fp_pixels": spx.reshape(SFT_B, -1)[:, :16].numpy().copy(),
         "sft_loss": np.float64(loss), "sft_ce_sums": np.asarray(ce_sum, dtype=np.float64), "sft_num_items": np.int64(n_items),

@@ -46,12 +46,13 @@ EMB = "llm.model.embed_tokens.weight"
 
 
 def pack(w, cfg, px, ids, forced, feats, proj, e, gen, lg, extra):
+    gen, gmargin = gen
     top = lg.topk(TOPK, -1)
     n_img = proj.shape[1]
     out = {f"fp_w{i}": w[k].reshape(-1)[:16].numpy().copy() for i, k in enumerate(KEYS)}
     out.update({"fp_pixels": px.reshape(-1)[:16].numpy().copy(), "seed": np.int64(SEED), "input_ids": ids.numpy(), "forced_ids": forced.numpy(),
                 "lm_head_tail": np.float32(cfg.lm_head_tail), "lm_head_tail_seed": np.int64(cfg.lm_head_tail_seed), "lm_head_tail_max": np.float32(cfg.lm_head_tail_max),
-                "tf_argmax_ids": lg.argmax(-1).numpy().astype(np.int64), "greedy_ids": np.asarray(gen, dtype=np.int64),
+                "tf_argmax_ids": lg.argmax(-1).numpy().astype(np.int64), "greedy_ids": np.asarray(gen, dtype=np.int64), "greedy_margins": np.asarray(gmargin, dtype=np.float32),
                 "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
                 "logit_absmax": lg.abs().amax(-1).numpy().astype(np.float32), "logit_norm": lg.norm(dim=-1).numpy().astype(np.float32),
                 "vit_rows": feats[0, [0, 511, 1023], :256].numpy().astype(np.float32), "vit_norm": np.float32(feats.norm()),
@@ -75,17 +76,19 @@ def oracle_steps(cfg, w, proj, ids, forced, greedy: bool):
         logits, past = O.qwen2_forward(O.embed_tokens(forced[t].view(1, 1), w), w, lc, past=past)
         last = logits[0, -1]
     lg = torch.stack(steps).float()
-    gen = []
+    gen, gmargin = [], []
     if greedy:
         past, last = past0, lg[0]
         for t in range(N_NEW):
             nxt = int(last.argmax())
             gen.append(nxt)
+            t2v = last.topk(2).values
+            gmargin.append(float(t2v[0] - t2v[1]))
             if t + 1 == N_NEW:
                 break
             logits, past = O.qwen2_forward(O.embed_tokens(torch.tensor([[nxt]]), w), w, lc, past=past)
             last = logits[0, -1]
-    return e, lg, gen
+    return e, lg, (gen, gmargin)
 
 
 def main():
@@ -123,7 +126,7 @@ def main():
         cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = float(a), int(s), float(m)
         w.store.pop(EMB, None)
         e_o, lg_o, gen_o = oracle_steps(cfg, w, proj_o, ids, forced, greedy=True)
-        print(f"chosen tail a={a} max={m} seed={s}: S = {e_o.shape[1]}, teacher-forced argmax {lg_o.argmax(-1).tolist()}, greedy {gen_o} ({time.time() - t0:.0f}s)", flush=True)
+        print(f"chosen tail a={a} max={m} seed={s}: S = {e_o.shape[1]}, teacher-forced argmax {lg_o.argmax(-1).tolist()}, greedy {gen_o[0]} ({time.time() - t0:.0f}s)", flush=True)
         np.savez_compressed(OUT.format(""), **pack(w, cfg, px, ids, forced, feats_o, proj_o, e_o, gen_o, lg_o, {}))
         # ---- reference ----
         t1 = time.time()
@@ -148,17 +151,19 @@ def main():
             r = llm(input_ids=forced[t].view(1, 1), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
         lg = torch.stack(steps)
-        gen, past, last = [], past0, lg[0]
+        gen, gmargin, past, last = [], [], past0, lg[0]
         for t in range(N_NEW):
             nxt = int(last.argmax())
             gen.append(nxt)
+            t2v = last.topk(2).values
+            gmargin.append(float(t2v[0] - t2v[1]))
             if t + 1 == N_NEW:
                 break
             r = llm(input_ids=torch.tensor([[nxt]]), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
         print(f"reference (HF {ver}): teacher-forced argmax {lg.argmax(-1).tolist()}, greedy {gen} ({time.time() - t1:.0f}s)", flush=True)
         # the embedding table was popped from the lazy store while filling HF: fingerprints re-draw it
-        np.savez_compressed(OUT.format("_ref"), **pack(w, cfg, px, ids, forced, feats, proj, e, gen, lg, {"hf_version": np.array(ver)}))
+        np.savez_compressed(OUT.format("_ref"), **pack(w, cfg, px, ids, forced, feats, proj, e, (gen, gmargin), lg, {"hf_version": np.array(ver)}))
     margin = lg.topk(2, -1).values
     print(f"margins {[round(float(a - b), 3) for a, b in margin]}; wrote both fixtures in {time.time() - t0:.0f}s", flush=True)
 

@@ -98,3 +98,43 @@ def test_live_model_projector_type_comes_from_the_projector_config():
     assert projector_type_of(NS(mm_projector_cfg={"mm_projector_type": "mlp_downsample"}), proj) == "mlp_downsample_3x3_fix"
     assert projector_type_of(NS(mm_projector_cfg={"mm_projector_type": "mlp_downsample_2x2_fix"}), None) == "mlp_downsample_2x2_fix"
     assert projector_type_of(None, None) == "mlp_downsample"
+
+
+def test_optimizer_state_without_bucket_counts_resumes_bias_correction_at_the_saved_step(tmp_path):
+    """a checkpoint written before per-bucket step counts existed has only `step`.  Loading it must not restart AdamW's bias
+    correction at 1 on warm moments: every bucket resumes at the saved step (`bucket_step_floor`), and a later save / load keeps that."""
+    import json
+    from vila_amd import checkpoint, configs
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import HipLlavaLlamaModel
+    torch.manual_seed(0)
+    tr = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    tr.flat.step_count = 37
+    tr.flat.bucket_steps = {"llm.model.norm.": 37}
+    d = str(tmp_path / "ck")
+    checkpoint.save_optimizer(tr, d)
+    meta_path = os.path.join(d, "optimizer", "optimizer.json")
+    meta = json.load(open(meta_path))
+    meta.pop("bucket_steps"); meta.pop("bucket_step_floor")            # what a pre-round-3 writer left
+    json.dump(meta, open(meta_path, "w"))
+    tr2 = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    checkpoint.load_optimizer(tr2, d)
+    assert tr2.flat.step_count == 37 and tr2.flat.bucket_steps == {} and tr2.flat.bucket_step_floor == 37
+    seen = []
+    from vila_amd import ops
+    orig = ops.adamw_step
+    ops.adamw_step = lambda *a, **k: seen.append(a[10])                 # the `step` argument of the bias correction
+    try:
+        tr2._adamw_bucket("mm_projector.", 1.0)
+    finally:
+        ops.adamw_step = orig
+    assert seen == [38] and tr2.flat.bucket_steps["mm_projector."] == 38
+    d2 = str(tmp_path / "ck2")
+    checkpoint.save_optimizer(tr2, d2)
+    tr3 = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    checkpoint.load_optimizer(tr3, d2)
+    assert tr3.flat.bucket_step_floor == 37 and tr3.flat.bucket_steps == {"mm_projector.": 38}
+    sd = tr3.flat.optimizer_state()
+    tr4 = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    tr4.flat.load_optimizer_state(sd)
+    assert tr4.flat.bucket_step_floor == 37 and tr4.flat.bucket_steps == {"mm_projector.": 38}

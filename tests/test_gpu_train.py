@@ -443,3 +443,47 @@ def test_autograd_seam_reference_training_call_site(use_c):
         out = model(**inputs)                                     # eval mode: the inference forward (no autograd)
     assert out.loss is not None and not out.loss.requires_grad
     print(f"autograd seam ({'one C-ABI call' if use_c else 'python-orchestrated'}): loss {float(loss):.5f} vs oracle {float(ref):.5f}, worst cosine {worst:.4f}")
+
+
+def test_autograd_seam_honours_frozen_components():
+    """the reference's stages freeze parts of the model (llava/train/args.py tune_language_model / tune_vision_tower /
+    tune_mm_projector; stage 1 trains the projector alone).  A frozen component's parameters keep requires_grad = False and never get a
+    `.grad`; the trainable ones get the same gradients as the all-trainable seam (the tower's backward is skipped, nothing else changes)."""
+    from vila_amd import configs, synthetic
+    from vila_amd.train import count_targets
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny("mlp_downsample")
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, 9).items()}
+    px = synthetic.make_pixels(cfg, 2, 9).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, 900, (2, 12), generator=g); ids[:, 0] = cfg.image_token_id
+    labels = torch.randint(0, 900, (2, 12), generator=g); labels[:, :5] = -100
+    n_items = count_targets(ids, labels, None, cfg.image_token_id)
+    inputs = dict(input_ids=ids, media={"image": [p.cuda() for p in px]}, labels=labels, num_items_in_batch=n_items)
+
+    def grads(**tune):
+        model = build_model(cfg, weights=w)
+        model.enable_autograd(use_c_abi=False, **tune)
+        model.train()
+        loss = model(**inputs).loss
+        loss.backward()
+        out = {}
+        for prefix, mod in (("llm.", model.llm), ("vision_tower.", model.vision_tower), ("mm_projector.", model.mm_projector)):
+            out.update({prefix + n: p for n, p in mod.named_parameters()})
+        return float(loss), out
+    loss_all, p_all = grads()
+    loss_s1, p_s1 = grads(tune_language_model=False, tune_vision_tower=False, tune_mm_projector=True)       # stage 1: align the projector
+    assert abs(loss_all - loss_s1) < 1e-6
+    for n, p in p_s1.items():
+        if n.startswith("mm_projector."):
+            assert p.requires_grad and p.grad is not None and rel_l2(p.grad, p_all[n].grad) < 1e-6, n
+        else:
+            assert not p.requires_grad and p.grad is None, n
+    loss_s2, p_s2 = grads(tune_vision_tower=False)                                                        # tower frozen, LLM + projector train
+    for n, p in p_s2.items():
+        if n.startswith("vision_tower."):
+            assert not p.requires_grad and p.grad is None, n
+        else:
+            assert p.grad is not None and rel_l2(p.grad, p_all[n].grad) < 1e-6, n
+    opt = torch.optim.SGD([p for p in p_s1.values() if p.requires_grad], lr=1e-2)                           # what an HF Trainer would build
+    opt.step()

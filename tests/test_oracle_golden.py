@@ -155,6 +155,19 @@ def test_full_depth_oracle_fixture_equals_the_reference_executed_one(golden_dir,
     assert rel(a["embed_rows"], b["embed_rows"]) < 1e-4
     assert np.array_equal(a["greedy_ids"], b["greedy_ids"]), (a["greedy_ids"], b["greedy_ids"])
     assert np.array_equal(a["top_ids"][:, 0], b["top_ids"][:, 0])
+    # round 4: the recorded steps are teacher-forced with a random id sequence (same in both files); the argmax tokens are mostly distinct
+    assert np.array_equal(a["forced_ids"], b["forced_ids"]) and np.array_equal(a["tf_argmax_ids"], b["tf_argmax_ids"])
+    assert np.array_equal(a["tf_argmax_ids"], a["top_ids"][:, 0])
+    assert len(set(b["tf_argmax_ids"].tolist())) >= 6, b["tf_argmax_ids"]
+    assert np.allclose(a["greedy_margins"], b["greedy_margins"], atol=2e-4 * float(b["logit_absmax"].max()))
+    if "sft_loss" in b.files:
+        # BASELINE configs[2] at full depth: the oracle's loss of the 4 x 769 micro-batch against HF's own ForCausalLMLoss (reference-executed)
+        assert np.array_equal(a["sft_input_ids"], b["sft_input_ids"]) and np.array_equal(a["sft_labels"], b["sft_labels"])
+        assert int(a["sft_num_items"]) == int(b["sft_num_items"]) == 4 * 256
+        assert abs(float(a["sft_loss"]) - float(b["sft_loss"])) < 2e-5 * abs(float(b["sft_loss"])), (float(a["sft_loss"]), float(b["sft_loss"]))
+        assert np.allclose(a["sft_ce_sums"], b["sft_ce_sums"], rtol=2e-5)
+        assert np.array_equal(a["sft_top_ids"][..., 0], b["sft_top_ids"][..., 0])
+        assert np.abs(a["sft_top_vals"][..., 0] - b["sft_top_vals"][..., 0]).max() < 2e-4 * np.abs(b["sft_top_vals"]).max()
     worst = 0.0
     for t in range(a["top_ids"].shape[0]):
         ia = {int(i): float(v) for i, v in zip(a["top_ids"][t], a["top_vals"][t])}

@@ -46,6 +46,10 @@ P
   bench_fast) timeout 400 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/bench_fast.json" 2> "$O/bench_fast.err"; python -c "
 import json; d=json.loads(open('$O/bench_fast.json').read().strip().splitlines()[-1]); print('value', d['value'], 'ttft', d['ttft_ms'], 'prefill frac', d['prefill']['roofline']['frac'])" ;;
   video)     for args in "--mode video" "--mode video --tsp"; do timeout 400 python bench.py $args 2>>"$O/video.err" | tail -1 | tee -a "$O/video.jsonl" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:60], d['value'], 'ms encode', d['encode_ms'], 'prefill', d['llm_prefill_ms'])"; done ;;
+  chain_tests) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_batch_decode.py tests/test_gpu_serving.py tests/test_gpu_sampling.py -m gpu -q -x 2>&1 | tail -25 > "$O/pytest_chain.log"; tail -25 "$O/pytest_chain.log" ;;
+  full_depth) timeout 1200 python -m pytest tests/test_gpu_full_depth.py -m gpu -q -s -k "${FD_K:-full_depth}" 2>&1 | grep -v "^$" | tail -40 > "$O/pytest_full_depth.log"; tail -40 "$O/pytest_full_depth.log" ;;
+  chain_ab)  for cfgv in "0 4" "1 4" "1 3" "1 2"; do set -- $cfgv; VILA_DECODE_CHAIN=$1 VILA_GEMV_BPC=$2 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 64 --warmup 8 > "$O/chain_$1_$2.json" 2> "$O/chain_$1_$2.err"; python -c "
+import json; d=json.loads(open('$O/chain_$1_$2.json').read().strip().splitlines()[-1]); print('chain=$1 bpc=$2: value', d['value'], 'ms/step', d['ms_per_step'], 'ttft', d['ttft_ms'])" || tail -5 "$O/chain_$1_$2.err"; done ;;
   smoke)     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
   *) echo "unknown step $step" ;;
 esac

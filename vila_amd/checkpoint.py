@@ -188,6 +188,7 @@ def save_optimizer(trainer, output_dir: str, max_shard_bytes: int = 4 << 30) -> 
             save_file({key: t[o:o + per].detach().to("cpu").contiguous()}, os.path.join(folder, name), metadata={"format": "pt"})
             files.append({"file": name, "key": key, "offset": o, "numel": int(min(per, f.numel - o))})
     meta = {"step": int(f.step_count), "numel": int(f.numel), "files": files, "bucket_steps": dict(getattr(f, "bucket_steps", {})),
+            "bucket_step_floor": int(getattr(f, "bucket_step_floor", 0)),
             "index": {n: [int(o), int(k), list(shape)] for n, (o, k, shape) in f.index.items()},
             "hyper": {"lr": trainer.lr, "betas": list(trainer.betas), "eps": trainer.eps, "weight_decay": trainer.wd}}
     with open(os.path.join(folder, "optimizer.json"), "w") as fh:
@@ -231,3 +232,5 @@ def load_optimizer(trainer, model_dir: str) -> None:
         f.params.copy_(f.master)
     f.bucket_steps = {str(k): int(v) for k, v in meta.get("bucket_steps", {}).items()}
     f.step_count = int(meta["step"])
+    # a checkpoint written before per-bucket counts existed: every bucket has seen `step` updates
+    f.bucket_step_floor = int(meta.get("bucket_step_floor", 0)) if "bucket_steps" in meta else f.step_count

@@ -426,6 +426,7 @@ extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max
     b += 2 * align_up(256 * 4, 256) + align_up((size_t)s->head_dim * 4, 256);
     b += align_up(QS * 2, 256);
     b += align_up(sample_workspace_bytes(), 256);
+    b += align_up((64 + 5 * (size_t)s->n_layers + 8) * 4, 256);      // chained step: error word + done counters (first in the arena)
     return b + 4096;
 }
 
@@ -456,6 +457,43 @@ extern "C" int vila_sample_f32(const float* logits, int n, const VilaSampling* s
     VILA_REQUIRE(sp != nullptr && logits != nullptr && out != nullptr && workspace != nullptr, "sample: NULL argument");
     return launch_sample(logits, n, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, counter, out, workspace, dist_out, S(stream));
 }
+// ---- chained decode step (round 4) ------------------------------------------------------------------------------------------------------
+// The token's kernels alternate between the caller's stream and a second one: kernel i is launched as soon as kernel i-2 has finished
+// (stream order), requests the weights it can (they do not depend on activations), and waits on kernel i-1's done counter before it touches
+// an activation (gemv_common.h chain_wait / chain_done).  What a plain kernel boundary costs — the predecessor's tail with the HBM pipe running
+// dry, the launch gap, the successor's first memory round trip — is spent streaming the successor's weights instead.  At most two kernels
+// are in flight; every kernel of the step fits on the chip next to its neighbour, so a waiting kernel can never keep the one it waits for
+// from being scheduled (and the wait is bounded: a give-up is reported in workspace word 0, see vila_llm_decode_chain_error).
+// VILA_DECODE_CHAIN=0 / vila_decode_force_chain(0): the plain single-stream step.
+static int g_decode_chain = -1;
+extern "C" void vila_decode_force_chain(int on) { g_decode_chain = on ? 1 : 0; }
+static int decode_chain_mode() {
+    if (g_decode_chain < 0) { const char* e = getenv("VILA_DECODE_CHAIN"); g_decode_chain = (e && e[0] == '0') ? 0 : 1; }
+    return g_decode_chain;
+}
+struct ChainStreams { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static ChainStreams& chain_streams() {
+    static thread_local ChainStreams per_dev[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ChainStreams& c = per_dev[dev & 15];
+    if (c.s2 == nullptr) {
+        if (hipStreamCreateWithFlags(&c.s2, hipStreamNonBlocking) != hipSuccess) c.s2 = nullptr;
+        (void)hipEventCreateWithFlags(&c.fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c.join, hipEventDisableTiming);
+    }
+    return c;
+}
+// word 0 of the decode workspace: 1 if a chained kernel's bounded wait gave up since the last call of this function (then results are invalid)
+extern "C" int vila_llm_decode_chain_error(void* workspace, vila_stream_t stream) {
+    hipStream_t s = S(stream);
+    uint32_t h = 0;
+    VILA_HIP(hipMemcpyAsync(&h, workspace, 4, hipMemcpyDeviceToHost, s));
+    VILA_HIP(hipStreamSynchronize(s));
+    if (h != 0) VILA_HIP(hipMemsetAsync(workspace, 0, 4, s));
+    return (int)h;
+}
+
 static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
                             const VilaSampling* sp, vila_stream_t stream) {
     const VilaLlmShape& sh = w->shape;
@@ -465,6 +503,7 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd, KS = sh.kv_heads * hd;
     const int ns = dec_splits(cache->max_ctx);
     Arena a(workspace, workspace_bytes);
+    uint32_t* chain_mem = a.take<uint32_t>(64 + 5 * (size_t)sh.n_layers + 8);      // [0] error word, [64..] done counters
     bf16_t* x = a.take<bf16_t>(H);
     bf16_t* x2 = a.take<bf16_t>(H);
     bf16_t* q = a.take<bf16_t>(QS);
@@ -478,8 +517,32 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     void* smp_ws = a.take<char>(sample_workspace_bytes());
     VILA_REQUIRE(a.ok(), "llm_decode: workspace arena overflow");
 
-    VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
+    const bool split256 = decode_attn_mode() >= 1 && cache->max_ctx <= 2048 && hd == 128;
+    ChainStreams* cs = nullptr;
+    if (decode_chain_mode() && split256) {                      // (the long-context split-KV + merge pair stays unchained)
+        cs = &chain_streams();
+        if (cs->s2 == nullptr || cs->fork == nullptr || cs->join == nullptr) cs = nullptr;
+    }
+    const bool chained = cs != nullptr;
+    uint32_t* ctr = chained ? chain_mem + 64 : nullptr;
+    const int n_chain = 5 * sh.n_layers + 2;
+    int k_idx = 0, prev_grid = 0;                               // index / grid of the chained kernel launched last
+    // the next chained kernel: its stream, and its link (waits for the previous kernel's whole grid, counts itself under its own index)
+    auto next_link = [&](ChainLink& c, hipStream_t& st_out) {
+        if (!chained) { st_out = s; return; }
+        c.ctr = ctr; c.err = chain_mem;
+        c.wait_idx = k_idx > 0 ? k_idx - 1 : -1; c.wait_target = (uint32_t)prev_grid; c.done_idx = k_idx;
+        st_out = (k_idx & 1) ? s : cs->s2;                      // kernel 0 goes to the second stream: the caller's stream just ran the prologue
+        ++k_idx;
+    };
+
+    VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s, ctr, chained ? n_chain : 0));
+    if (chained) {
+        VILA_HIP(hipEventRecord(cs->fork, s));
+        VILA_HIP(hipStreamWaitEvent(cs->s2, cs->fork, 0));
+    }
     bf16_t* cur = x; bf16_t* nxt = x2;
+    hipStream_t ks = s;
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];
         const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
@@ -491,27 +554,36 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
         qa.x = cur; qa.norm_w = B(L.ln1_w); qa.eps = sh.rms_eps; qa.Wqkv = B(L.wq); qa.bqkv = B(L.bq); qa.q_out = q;
         qa.kcache = kc; qa.vcache = vc; qa.pos_ptr = st->pos; qa.K = H; qa.nq = sh.q_heads; qa.nkv = sh.kv_heads; qa.hd = hd;
         qa.max_ctx = cache->max_ctx; qa.rope_cs = rope_cs;
-        VILA_TRY(launch_qkv_decode(qa, s));
+        next_link(qa.chain, ks);
+        VILA_TRY(launch_qkv_decode(qa, ks, &prev_grid));
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
         ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
-        const bool split256 = decode_attn_mode() >= 1 && cache->max_ctx <= 2048 && hd == 128;
         ad.split256 = split256 ? 1 : 0;
-        VILA_TRY(launch_attn_decode(ad, s));
+        next_link(ad.chain, ks);
+        VILA_TRY(launch_attn_decode(ad, ks, &prev_grid));
         GemvArgs o{};
         o.x = ao; o.W = B(L.wo); o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
         if (split256) { o.mode = 2; o.part_o = part_o; o.part_ml = part_ml; o.pos_ptr = st->pos; o.n_splits = cdiv(cache->max_ctx, 256); o.split_keys = 256; o.grid_cap = decode_attn_mode() == 2 ? 512 : 256; }
-        VILA_TRY(launch_gemv(o, s));
+        next_link(o.chain, ks);
+        VILA_TRY(launch_gemv(o, ks, &prev_grid));
         GemvArgs gu{};
         gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.W = B(L.w_gate); gu.W2 = B(L.w_up); gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
-        VILA_TRY(launch_gemv(gu, s));
+        next_link(gu.chain, ks);
+        VILA_TRY(launch_gemv(gu, ks, &prev_grid));
         GemvArgs dn{};
         dn.x = act; dn.W = B(L.w_down); dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0;
-        VILA_TRY(launch_gemv(dn, s));
+        next_link(dn.chain, ks);
+        VILA_TRY(launch_gemv(dn, ks, &prev_grid));
     }
     GemvArgs lm{};
     lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
-    VILA_TRY(launch_gemv(lm, s));
+    next_link(lm.chain, ks);
+    VILA_TRY(launch_gemv(lm, ks, &prev_grid));
+    if (chained) {                                              // the token choice runs on the caller's stream behind BOTH streams
+        VILA_HIP(hipEventRecord(cs->join, cs->s2));
+        VILA_HIP(hipStreamWaitEvent(s, cs->join, 0));
+    }
     if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
     else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
     VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));

@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     const bool has = g < n_groups;
     // issue the first weight batch before staging x only for short rows (K <= 4096: the staging latency is comparable to the
     // stream); for K = 18944 the x staging is long and queuing the weight loads in front of it measured 13 % slower
-    const bool early = has && (p.K <= 4096);
+    // (a chained kernel always prefetches: what it loads before the wait streams in under its predecessor's tail)
+    const bool early = has && (p.K <= 4096 || p.chain.ctr != nullptr);
     if (early) { rows_of(g, rows); load_batch<R, U>(rows, 0, lane, nch, b0); }
     if (has) epi_fetch(g);
+    chain_wait(p.chain);                        // everything above reads weights / operands of kernels <= i-2 only
     if constexpr (MODE == 2) {
         const int ks = p.split_keys > 0 ? p.split_keys : DEC_KS;
         const int n_active = (*p.pos_ptr + ks) / ks;             // ceil((pos+1)/ks)
@@ -190,18 +192,27 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
         wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 0);
         finish(g, acc);
     }
+    chain_done(p.chain);
 }
 
 // Grid sizing for the HBM-bound GEMVs: a multiple of the 256 CUs (the dispatcher deals blocks round-robin, so 448 blocks
 // would leave 64 CUs with half the work of the others) and at most 4 blocks (16 waves) per CU = everything resident at once;
 // waves then walk the row groups with a grid stride.
+// VILA_GEMV_BPC (1..4, default 4): blocks per CU cap — a chained kernel that leaves half of every CU's registers to its successor lets the
+// successor's blocks become resident (and prefetch) while it runs (api.hip "chained decode step").
+static int gemv_blocks_per_cu() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_GEMV_BPC"); v = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; }
+    return v;
+}
 static inline int balanced_grid(int n_groups) {
     int want = cdiv(n_groups, 4);
-    if (want > 1024) want = 1024;
+    const int cap = 256 * gemv_blocks_per_cu();
+    if (want > cap) want = cap;
     return want <= 256 ? want : cdiv(want, 256) * 256;
 }
 
-int launch_gemv(const GemvArgs& a, hipStream_t s) {
+int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
     const int n_groups = cdiv(a.N, 2);
@@ -224,6 +235,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
     }
     VILA_LAUNCH_CHECK();
+    if (grid_out != nullptr) *grid_out = grid;
     return 0;
 }
 
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     Batch<2, U> b0;
     const bool has = g < n_groups;
     if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); epi_fetch(g); }
+    chain_wait(p.chain);
     stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
         float acc[2] = {0.f, 0.f};
@@ -305,9 +318,10 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         wave_rows_dot<2, U>(rows, sx, p.K, lane, acc, 0);
         finish(g, acc);
     }
+    chain_done(p.chain);
 }
 
-int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s) {
+int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.hd % 4 == 0 && a.rope_cs != nullptr, "qkv_decode: K=%d hd=%d", a.K, a.hd);
     const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 2);
     const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
@@ -315,6 +329,7 @@ int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s) {
     if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(balanced_grid(n_groups)), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(balanced_grid(n_groups)), dim3(256), lds, s, a);
     VILA_LAUNCH_CHECK();
+    if (grid_out != nullptr) *grid_out = balanced_grid(n_groups);
     return 0;
 }
 
@@ -451,24 +466,16 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     p.q += row * p.q_row_stride; p.kcache += row * p.slot_stride; p.vcache += row * p.slot_stride;
     if (!SPLIT) p.o += row * p.o_row_stride;
     const int nkeys_all = p.pos_ptr[row] + 1;
-    if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
+    if (SPLIT && key_lo >= nkeys_all) {                          // block-uniform: slices beyond the context write nothing (the merge skips them)
+        chain_done(p.chain);                                     // (a chained launch still counts the block: its successor waits for the whole grid)
+        return;
+    }
     const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
     const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
     const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
-    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
-    __syncthreads();
     const int kq = lane >> 2, qd = lane & 3;        // scores: key within the chunk, d quarter
     const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup, d chunk
-    float qr[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
-    float m = -INFINITY, l = 0.f, o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-
     u32x4 kc[4], vc[4], kn_[4], vn_[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
     auto load_chunk = [&](int k0, u32x4 (&kk)[4], u32x4 (&vv)[4]) {
         const int key = k0 + kq;
 #pragma unroll
@@ -479,7 +486,23 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
         }
     };
     int k0 = key_lo + wave * 16;
-    if (k0 < nkeys) load_chunk(k0, kc, vc);
+    // a chained launch: chunks made of keys of EARLIER tokens only are in the cache already — they are requested before the wait; the chunk
+    // that holds this token's key / value (position nkeys_all - 1, written by the QKV kernel this one waits for) is loaded after it
+    const bool chained = p.chain.ctr != nullptr;
+    const bool old_chunk = chained && (k0 + 16 <= nkeys_all - 1);
+    if (old_chunk) load_chunk(k0, kc, vc);
+    chain_wait(p.chain);
+    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
+    __syncthreads();
+    float qr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
+    if (k0 < nkeys && !old_chunk) load_chunk(k0, kc, vc);
     for (; k0 < nkeys; k0 += 256) {
         const int kn = k0 + 256;
         if (kn < nkeys) load_chunk(kn, kn_, vn_);            // prefetch the wave's next chunk under this chunk's math
@@ -545,6 +568,7 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
             p.o[h * 128 + tid] = f2bf(acc / L);
         }
     }
+    chain_done(p.chain);
 }
 
 // batched decode: one block per (query head, sequence) over the sequence's whole context (caches up to 2048 positions)
@@ -558,7 +582,7 @@ int launch_attn_decode_rows(const AttnDecodeArgs& a0, int n_rows, int64_t q_row_
     return 0;
 }
 
-int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
+int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.hd == 128, "attn_decode: head_dim must be 128 (got %d)", a.hd);
     VILA_REQUIRE(a.nq % a.nkv == 0 && a.nq / a.nkv <= DEC_MAXG, "attn_decode: GQA group %d/%d unsupported (max %d)", a.nq, a.nkv, DEC_MAXG);
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
@@ -566,8 +590,10 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
         VILA_REQUIRE(a.max_ctx <= 2048 && a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: 256-key slices need max_ctx <= 2048");
         hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
+        if (grid_out != nullptr) *grid_out = a.nq * cdiv(a.max_ctx, 256);
         return 0;
     }
+    VILA_REQUIRE(a.chain.ctr == nullptr, "attn_decode: only the 256-key-slice kernel takes part in a kernel chain");
     if (a.o != nullptr && a.max_ctx <= 2048 && !a.force_split) {
         hipLaunchKernelGGL(attn_decode_head<false>, dim3(a.nq), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
@@ -592,7 +618,11 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
 // per-token prologue: x = embed[token]; rope table for the token's position: cs[0:hd/2] = cos, cs[hd/2:hd] = sin,
 // both rounded to bf16 (HF casts cos/sin to the activation dtype before use)
 __global__ void decode_prologue_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ tok, bf16_t* __restrict__ out, int H,
-                                       int64_t vocab, const int32_t* __restrict__ pos, float* __restrict__ rope_cs, int hd, float theta) {
+                                       int64_t vocab, const int32_t* __restrict__ pos, float* __restrict__ rope_cs, int hd, float theta,
+                                       uint32_t* __restrict__ chain_ctr, int n_chain) {
+    // chained step: this token's done counters start at zero (every chained kernel is launched behind this one)
+    if (chain_ctr != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_chain; i += blockDim.x) chain_ctr[i] = 0u;
     int64_t id = *tok;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < (H >> 3); c += gridDim.x * blockDim.x)
@@ -606,9 +636,10 @@ __global__ void decode_prologue_kernel(const bf16_t* __restrict__ table, const i
     }
 }
 int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
-                           int hd, float theta, hipStream_t s) {
+                           int hd, float theta, hipStream_t s, uint32_t* chain_ctr, int n_chain) {
     VILA_REQUIRE(hd / 2 <= 256, "decode_prologue: head_dim too large");
-    hipLaunchKernelGGL(decode_prologue_kernel, dim3(cdiv(H / 8, 256)), dim3(256), 0, s, table, tok, out, H, vocab, pos, rope_cs, hd, theta);
+    hipLaunchKernelGGL(decode_prologue_kernel, dim3(cdiv(H / 8, 256)), dim3(256), 0, s, table, tok, out, H, vocab, pos, rope_cs, hd, theta,
+                       chain_ctr, n_chain);
     VILA_LAUNCH_CHECK();
     return 0;
 }

@@ -2,6 +2,32 @@
 #pragma once
 #include "kernels.h"
 
+// ---- chained kernels (kernels.h ChainLink) -----------------------------------------------------------------------------------------------
+// chain_wait: thread 0 polls the predecessor's done counter (bounded: ~0.3 s), the block meets at a barrier, every wave then takes an
+// agent-scope acquire (the predecessor ran on other CUs / XCDs: its stores were written back by chain_done's release).
+__device__ __forceinline__ void chain_wait(const ChainLink& c) {
+    if (c.ctr == nullptr || c.wait_idx < 0) return;
+    if (threadIdx.x == 0) {
+        // once a wait has given up, the token is lost anyway: later waits return at once, so a scheduling surprise costs ~0.2 s, not a hang
+        if (__hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            uint32_t n = 0;
+            while (__hip_atomic_load(c.ctr + c.wait_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.wait_target) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++n > (1u << 18)) { __hip_atomic_store(c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// chain_done: after the block's last store.  The barrier retires every wave's stores to L2 (workgroup release), thread 0 then releases at
+// agent scope (L2 write-back) and counts the block.
+__device__ __forceinline__ void chain_done(const ChainLink& c) {
+    if (c.ctr == nullptr || c.done_idx < 0) return;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(c.ctr + c.done_idx, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- activation staging -------------------------------------------------------------------------
 // stage x (optionally RMS-normalised with gain, HF rounding order) as bf16 into LDS; all 256 threads participate.
 // Single pass for K <= 8192 (x kept in registers between the sum of squares and the scaling).

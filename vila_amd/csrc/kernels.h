@@ -77,6 +77,16 @@ struct AttnArgs {
 int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
 
 // ---- decode (gemv.hip) ----
+// Chained decode kernels (round 4): kernel i of a token is launched BEFORE kernel i-1 has finished (alternating streams: i-2 -> i is stream
+// order), issues the weight loads that do not depend on activations, then waits until kernel i-1's blocks have all counted themselves done.
+// ctr == nullptr: a plain kernel (no wait, no count).  gemv_common.h: chain_wait / chain_done.
+struct ChainLink {
+    uint32_t* ctr = nullptr;        // [n_kernels] done counters of this token (zeroed by the prologue kernel)
+    uint32_t* err = nullptr;        // set to 1 if a wait gave up (bounded spin: a hang becomes a reported error)
+    int wait_idx = -1;              // counter to wait on (-1: none)
+    uint32_t wait_target = 0;       // = grid size of that kernel
+    int done_idx = -1;              // counter this kernel's blocks increment
+};
 struct GemvArgs {
     const bf16_t* x;          // [K] activations (bf16)
     const bf16_t* norm_w;     // optional RMSNorm gain fused in front (null = none)
@@ -91,8 +101,9 @@ struct GemvArgs {
     const float* part_o; const float* part_ml; const int32_t* pos_ptr; int n_splits;   // mode 2
     int split_keys;           // mode 2: keys per partial slice (0 = the 64-key slices of attn_decode_partial)
     int grid_cap;             // mode 2: upper bound of the grid (0 = 256 blocks)
+    ChainLink chain;
 };
-int launch_gemv(const GemvArgs& a, hipStream_t s);
+int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out = nullptr);
 struct QkvDecodeArgs {
     const bf16_t* x; const bf16_t* norm_w; float eps;
     const bf16_t* Wqkv; const bf16_t* bqkv;   // fused [q+2kv][K], [q+2kv]
@@ -101,8 +112,9 @@ struct QkvDecodeArgs {
     const int32_t* pos_ptr;                    // device scalar: position of the new token (= current context length)
     const float* rope_cs;                      // [hd] cos | sin of that position (decode_prologue_kernel)
     int K, nq, nkv, hd, max_ctx;
+    ChainLink chain;
 };
-int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s);
+int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out = nullptr);
 struct AttnDecodeArgs {
     const bf16_t* q; const bf16_t* kcache; const bf16_t* vcache;
     bf16_t* o;                       // [nq*hd] merged output (second launch); null = partials only
@@ -113,8 +125,9 @@ struct AttnDecodeArgs {
     int split256;                    // 1: per-head blocks over 256-key slices, partials only (merged in the o_proj GEMV prologue)
     // batched decode (decode_batch.hip): row = blockIdx.z reads q + row * q_row_stride, cache slot row (+ row * slot_stride), pos_ptr[row]
     int64_t q_row_stride, o_row_stride, slot_stride;
+    ChainLink chain;                 // (the 256-key-slice kernel only)
 };
-int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out = nullptr);
 int launch_attn_decode_rows(const AttnDecodeArgs& a, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s);
 // batched decode step (decode_batch.hip)
 struct BDecodeArgs {
@@ -126,5 +139,5 @@ size_t bdecode_workspace_bytes(int H, int F, int QS, int hd, int n);
 int bdecode_step(const BDecodeArgs& m, const BLayer* layers, bf16_t* kcache, bf16_t* vcache, int max_ctx, int n_slots, int n, int32_t* pos, int64_t* token,
                  int64_t* out_ids, int32_t* n_out, int max_out, float* logits, void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_decode_prologue(const bf16_t* table, const int64_t* tok, bf16_t* out, int H, int64_t vocab, const int32_t* pos, float* rope_cs,
-                           int hd, float theta, hipStream_t s);
+                           int hd, float theta, hipStream_t s, uint32_t* chain_ctr = nullptr, int n_chain = 0);
 int launch_decode_advance(int32_t* pos, const int64_t* tok, int64_t* out_ids, int32_t* n_out, int max_out, hipStream_t s);

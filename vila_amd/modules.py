@@ -453,6 +453,7 @@ class HipQwen2ForCausalLM(_HipModule):
             st.n_out = torch.zeros(1, device=dev, dtype=torch.int32)
             st.logits = torch.zeros(self.lcfg.vocab_size, device=dev, dtype=torch.float32)
             st.ws = torch.empty((lib.vila_llm_decode_workspace_bytes(C.byref(w.shape), cache.max_ctx),), device=dev, dtype=torch.uint8)
+            st.ws[:256].zero_()                       # word 0: the chained step's error flag (vila_llm_decode_chain_error)
             st.seed = torch.zeros(1, device=dev, dtype=torch.int64)          # the sampler's seed (bit pattern of a uint64)
         if sampling is not None:
             st.seed.fill_(_as_i64(sampling[3]))
@@ -798,6 +799,10 @@ class HipQwen2ForCausalLM(_HipModule):
             st.stream.synchronize()
             out = torch.cat([first, st.out_ids[:done]])
         toks = out.tolist()
+        if int(st.ws[:4].view(torch.int32).item()) != 0:    # (the stream is drained: out.tolist() above)
+            st.ws[:4].zero_()
+            raise RuntimeError("chained decode step: a kernel's bounded wait for its predecessor gave up, the generated tokens are invalid "
+                               "(vila_llm_decode_chain_error; VILA_DECODE_CHAIN=0 selects the plain single-stream step)")
         if forced_ids is None:
             for i, t in enumerate(toks):                    # HF stops AFTER emitting eos
                 if t in eos_set:

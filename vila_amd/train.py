@@ -91,7 +91,8 @@ class FlatParams:
         return {"master": self.master, "exp_avg": self.m, "exp_avg_sq": self.v,
                 "step": torch.tensor([self.step_count], dtype=torch.int64), "numel": torch.tensor([self.numel], dtype=torch.int64),
                 "bucket_steps": torch.tensor([self.bucket_steps[n] for n in names], dtype=torch.int64),
-                "bucket_names": torch.tensor(list("\n".join(names).encode()), dtype=torch.uint8)}
+                "bucket_names": torch.tensor(list("\n".join(names).encode()), dtype=torch.uint8),
+                "bucket_step_floor": torch.tensor([int(getattr(self, "bucket_step_floor", 0))], dtype=torch.int64)}
 
     def load_optimizer_state(self, sd: Dict[str, torch.Tensor]) -> None:
         if int(sd["numel"][0]) != self.numel:
@@ -106,9 +107,14 @@ class FlatParams:
             self.params.copy_(self.master)               # bf16 params are the rounding of the master copy
         self.step_count = int(sd["step"][0])
         self.bucket_steps = {}
+        self.bucket_step_floor = int(sd["bucket_step_floor"][0]) if "bucket_step_floor" in sd else 0
         if "bucket_names" in sd and sd["bucket_names"].numel():
             names = bytes(sd["bucket_names"].to(torch.uint8).tolist()).decode().split("\n")
             self.bucket_steps = {n: int(c) for n, c in zip(names, sd["bucket_steps"].tolist())}
+        else:
+            # a state written before per-bucket counts existed: every bucket has seen `step` updates (bias correction must not restart at 1 on
+            # warm moments — the first updates after the resume would come out ~0.3x too small)
+            self.bucket_step_floor = self.step_count
 
     def grad(self, name: str) -> torch.Tensor:
         o, k, shape = self.index[name]
@@ -299,7 +305,7 @@ class SFTTrainer:
         never) is NOT updated — no weight decay, no moment decay — and its bias correction uses the number of updates IT has seen."""
         f = self.flat
         a, b = f.span(prefix)
-        step = f.bucket_steps.get(prefix, 0) + 1
+        step = f.bucket_steps.get(prefix, getattr(f, "bucket_step_floor", 0)) + 1
         f.bucket_steps[prefix] = step
         ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
                        self.eps, self.wd, step, grad_scale, lean=self.lean_adamw)
@@ -746,14 +752,15 @@ class SFTTrainer:
             ops.copy_rows(dx0, dnl, nl_dst, None, n_nl)
             ops.scatter_add_rows(dnl, ge, nl_src)
         self._ready("llm.model.embed_tokens.")
-        if n_img:
+        if n_img and not getattr(self, "skip_proj_bwd", False):
             full = n_feat == n_prow
             dproj = (torch.empty if full else torch.zeros)((n_prow, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
             ops.copy_rows(dx0, dproj, feat_dst, feat_src, n_feat)
             dfeats = self._proj_bwd(dproj.view(proj.shape[0], proj.shape[1], H), proj_saved)
             if s2 is not None:                                                         # adjoint of the merge: back onto the tower's tiles
                 dfeats = ops.s2_merge_bwd(dfeats, s2_tdesc, len(cfg.s2_scales), s2.splits)
-            self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
+            if not getattr(self, "skip_vit_bwd", False):
+                self._vit_bwd(dfeats.reshape(n_img * cfg.vision.num_patches, cfg.vision.hidden_size), vit_saved)
         self._announce_absent_media(n_img)
         self._finish_backward()
         return loss[0]
@@ -762,6 +769,10 @@ class SFTTrainer:
         """The buckets the projector / tower backward announces, in its order (`_proj_bwd`, `_vit_bwd`; BUCKET_PROJECTOR / BUCKET_VIT_* of the
         C-ABI step)."""
         pre = "vision_tower.vision_tower.vision_model."
+        if getattr(self, "skip_proj_bwd", False):            # frozen projector + tower (autograd seam, tune_* flags): nothing is announced
+            return []
+        if getattr(self, "skip_vit_bwd", False):
+            return ["mm_projector."]
         return (["mm_projector."] + [f"{pre}encoder.layers.{i}." for i in reversed(range(self.cfg.vision.num_used_layers))] + [pre + "embeddings."])
 
     def _announce_absent_media(self, n_img: int) -> None:
@@ -875,20 +886,34 @@ class AutogradSeam:
     `.grad` of every parameter is a view of ONE flat bf16 buffer (`accum`, same layout as the parameters): a backward is one flat
     `accum (+)= g * grads` pass (16 GB read + write at NVILA-8B) instead of 700 small tensor ops."""
 
-    def __init__(self, model, use_c_abi: Optional[bool] = None, group=None):
+    def __init__(self, model, use_c_abi: Optional[bool] = None, group=None, tune: Optional[Dict[str, bool]] = None):
         self.model = model
         self.trainer = SFTTrainer(model, optimizer_state=False, group=group)       # the optimizer is the caller's (HF Trainer's AdamW)
         if use_c_abi is not None:
             self.trainer.use_c_abi = bool(use_c_abi)
+        tune = {"llm.": True, "vision_tower.": True, "mm_projector.": True, **(tune or {})}
+        self.tune = tune
+        # frozen tower: its backward is never needed; frozen tower AND projector: nothing behind the spliced embeddings is (the explicit
+        # backward of the Python-orchestrated driver stops there; the one-call C-ABI step always runs the whole backward)
+        self.trainer.skip_vit_bwd = not tune["vision_tower."]
+        self.trainer.skip_proj_bwd = not tune["vision_tower."] and not tune["mm_projector."]
+        if self.trainer.skip_vit_bwd:
+            self.trainer.use_c_abi = False
         self.accum = torch.zeros_like(self.trainer.flat.grads)
-        self.params: List[Tuple[torch.nn.Parameter, torch.Tensor]] = []
+        self.params: List[Tuple[torch.nn.Parameter, torch.Tensor]] = []       # the TRAINABLE parameters and their slices of `accum`
+        self.spans: List[Tuple[int, int, tuple]] = []
         f = self.trainer.flat
         mods = {"llm.": model.llm, "vision_tower.": model.vision_tower, "mm_projector.": model.mm_projector}
         for name, (o, k, shape) in f.index.items():
             prefix = next(p for p in mods if name.startswith(p))
             prm = _get(mods[prefix], name[len(prefix):])
-            prm.requires_grad_(True)
-            self.params.append((prm, self.accum[o:o + k].view(shape)))
+            prm.requires_grad_(bool(tune[prefix]))
+            if tune[prefix]:
+                self.params.append((prm, self.accum[o:o + k].view(shape)))
+                self.spans.append((o, k, shape))
+        if not self.params:
+            raise ValueError("enable_autograd: every component is frozen")
+        self.all_trainable = all(tune.values())
         self.anchor = self.params[0][0]
 
     def loss(self, input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes) -> torch.Tensor:
@@ -905,13 +930,12 @@ class AutogradSeam:
         none = [p.grad is None for p, _ in self.params]
         with torch.no_grad():
             if all(none):                                   # first backward after zero_grad(set_to_none=True)
-                torch.mul(grads, scale, out=self.accum)
+                torch.mul(grads, scale, out=self.accum)     # (frozen components' slices are written too but no parameter points at them)
                 for p, v in self.params:
                     p.grad = v
             elif all(ours):                                 # gradient accumulation over micro-batches
                 self.accum.add_(grads, alpha=scale)
             else:                                           # somebody replaced some .grad tensors: per-parameter accumulation
-                f = self.trainer.flat
-                for (p, v), (o, k, shape) in zip(self.params, f.index.values()):
+                for (p, v), (o, k, shape) in zip(self.params, self.spans):
                     gv = grads[o:o + k].view(shape) * scale
                     p.grad = gv.clone() if p.grad is None else p.grad + gv

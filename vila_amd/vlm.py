@@ -38,10 +38,11 @@ class BasicImageEncoder(nn.Module):
         # blocks until the stream has drained — behind the tower that was the largest gap of the TTFT timeline.  (The embedding itself is
         # looked up every time: the table may have been trained in between.)
         cache = self.__dict__.setdefault("_tok_ids_dev", {})
-        ids = cache.get(tokens)
+        key = (tokens, str(self.parent.device))                          # (a model moved with .to() must not look up with ids on the old device)
+        ids = cache.get(key)
         if ids is None:
             with torch.inference_mode(False):
-                ids = cache[tokens] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
+                ids = cache[key] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
         return self.parent.llm.embed_tokens(ids)
 
     def forward(self, images: List[torch.Tensor], config: Dict[str, Any]) -> List[torch.Tensor]:
@@ -78,10 +79,11 @@ class BasicVideoEncoder(nn.Module):
         # blocks until the stream has drained — behind the tower that was the largest gap of the TTFT timeline.  (The embedding itself is
         # looked up every time: the table may have been trained in between.)
         cache = self.__dict__.setdefault("_tok_ids_dev", {})
-        ids = cache.get(tokens)
+        key = (tokens, str(self.parent.device))                          # (a model moved with .to() must not look up with ids on the old device)
+        ids = cache.get(key)
         if ids is None:
             with torch.inference_mode(False):
-                ids = cache[tokens] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
+                ids = cache[key] = torch.tensor(self.parent.tokenizer(tokens).input_ids, device=self.parent.device)
         return self.parent.llm.embed_tokens(ids)
 
     def _process_features(self, feats: torch.Tensor, start, end, sep) -> torch.Tensor:
@@ -258,14 +260,19 @@ class HipLlavaLlamaModel(nn.Module):
         self._plan_ev.record()
         return [d[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(tensors, offs)]
 
-    def enable_autograd(self, use_c_abi: Optional[bool] = None, group=None):
+    def enable_autograd(self, use_c_abi: Optional[bool] = None, group=None, tune_language_model: bool = True, tune_vision_tower: bool = True,
+                        tune_mm_projector: bool = True):
         """Make the reference's own training call site work after the swap (llava/train/transformer_normalize_monkey_patch.py
         :183-249: `loss = model(**inputs).loss` ... `accelerator.backward(loss)`): every parameter gets requires_grad, and in training
         mode `forward(labels=...)` returns a loss that is attached to the autograd graph — its backward deposits the gradients the HIP
         step computed into `.grad` (accumulating), so `loss.backward()`, gradient accumulation, `optimizer.step()` of any torch optimizer
-        and `zero_grad()` behave as with the reference's modules.  Parameters move into one flat buffer (vila_amd.train.FlatParams)."""
+        and `zero_grad()` behave as with the reference's modules.  Parameters move into one flat buffer (vila_amd.train.FlatParams).
+        tune_*: the reference's stage switches (llava/train/args.py tune_language_model / tune_vision_tower / tune_mm_projector; stage 1 trains the
+        projector alone): a frozen component's parameters keep requires_grad = False and never receive a `.grad`; the tower's backward is not
+        run at all when the tower is frozen, nor the projector's when projector and tower both are."""
         from .train import AutogradSeam
-        self._seam = AutogradSeam(self, use_c_abi=use_c_abi, group=group)
+        self._seam = AutogradSeam(self, use_c_abi=use_c_abi, group=group,
+                                  tune={"llm.": tune_language_model, "vision_tower.": tune_vision_tower, "mm_projector.": tune_mm_projector})
         return self._seam
 
     # llava_llama.py:94-159.  Inference / eval: loss without autograd.  Training mode with enable_autograd(): the SFT step behind autograd.
