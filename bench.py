@@ -636,7 +636,7 @@ def decode_main(a, rank, world, dev, dist):
     assert n_generated == a.warmup + a.steps, (n_generated, a.warmup, a.steps)
     chain_err = int(lib.vila_llm_decode_chain_error(st.ws.data_ptr(), stream.cuda_stream))
     assert chain_err == 0, "chained decode step: a bounded wait gave up — the timed tokens are invalid"
-    chained = os.environ.get("VILA_DECODE_CHAIN", "1") != "0" and not a.w4 and cache.max_ctx <= 2048
+    chained = os.environ.get("VILA_DECODE_CHAIN", "0") == "1" and not a.w4 and cache.max_ctx <= 2048
     ctx_mid = S + a.warmup + a.steps // 2
     step_bytes = decode_bytes_per_token(cfg, ctx_mid, a.w4)
     step_s = elapsed / a.steps

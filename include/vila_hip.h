@@ -379,6 +379,9 @@ int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, const void* 
 /* same contract as vila_llm_decode_step; `w` still supplies embed, norms, q/k/v biases and the bf16 lm_head */
 int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLayerW4* qlayers /*[host]*/, const VilaKvCache* cache,
                             const VilaDecodeState* st, void* workspace, size_t workspace_bytes, vila_stream_t stream);
+/* the same step with a stochastic pick (generate(do_sample=True) on the quantised decoder): temperature -> top-k -> top-p -> draw */
+int vila_llm_decode_step_w4_sample(const VilaLlmWeights* w, const VilaLlmLayerW4* qlayers /*[host]*/, const VilaKvCache* cache,
+                            const VilaDecodeState* st, void* workspace, size_t workspace_bytes, const VilaSampling* sampling, vila_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ void vila_gemm_force_hybrid(int on);
  * merge in the o_proj GEMV's prologue (512 / 256 o_proj blocks), 0 = one block per query head over the whole context + plain o_proj */
 void vila_decode_force_attn(int mode);
 /* the batch-1 decode step's kernels chained over two streams (api.hip "chained decode step": kernel i streams its weights while kernel i-1
- * finishes, then waits on its done counter): 1 = on (default), 0 = the plain single-stream step */
+ * finishes, then waits on its done counter): 0 = off (default: measured 10 % slower than the plain step, profiles/r04_decode_chain_ab.log), 1 = on */
 void vila_decode_force_chain(int on);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);

@@ -95,11 +95,11 @@ def sft_rows(S: int) -> torch.Tensor:
 
 
 # ---- the lm_head search --------------------------------------------------------------------------------------------------------------
-REL_ERR = 0.008         # bf16 GPU path vs fp32 at full depth: logit error std ~ 0.8 % of the row's logit sigma (round-3 GPU runs: 0.34-0.40 max-abs
-#                         on steps whose heaviest top-32 row had sigma ~ 20-30)
+REL_ERR = 0.03          # fallback error model (no calibration file): logit error std ~ 3 % of the row's logit sigma — the first round-4 GPU run measured
+#                         0.09-0.27 max-abs where a 0.8 % model (round 3's attractor-token steps) predicted 0.04-0.11
 BAND = (4.0, 20.0)      # wanted: margin / expected max-abs error
-TAILS = [(a, m) for a in (2.0, 3.0, 4.0, 6.0) for m in (2.0, 3.0, 4.0, 6.0)]
-SEEDS = range(96)
+TAILS = [(a, 4.0) for a in (2.0, 2.5, 3.0, 4.0, 5.0, 6.0, 8.0)]       # (the cap only rescales every logit: margins / errors do not see it)
+SEEDS = range(256)
 
 
 def expected_err(row_std, xn_norm, scale, top_ids, rel_err=REL_ERR):
@@ -122,13 +122,40 @@ def score_logits(cfg, lg, xn_norm, scale, row_std=None, rel_err=REL_ERR):
     return (int(inband.sum()), n_distinct, -badness), ids, ratio, margin, err
 
 
-def search_head(cfg, w, XN):
-    """XN [n, H] = final-norm hidden state of every recorded step.  Returns (tail_a, tail_max, tail_seed)."""
+def load_calibration(name: str, input_ids, forced):
+    """oracle/calib/<name>_xn_gpu.npz (tools/dump_full_depth_hidden.py, run on an MI355X): the final-norm hidden states the HIP path feeds its
+    lm_head on the same 8 steps.  They do not depend on the head, so logits_gpu(candidate) = XN_gpu @ head(candidate)^T — the search scores every
+    candidate against the path's MEASURED logit error instead of a model of it.  None when the file is absent (then REL_ERR is used)."""
+    path = os.path.join(ROOT, "oracle", "calib", f"{name}_xn_gpu.npz")
+    if not os.path.exists(path):
+        return None
+    c = np.load(path)
+    assert np.array_equal(c["input_ids"], input_ids.numpy()) and np.array_equal(c["forced_ids"], forced.numpy()), "calibration is for other inputs"
+    return torch.from_numpy(c["xn"]).float()
+
+
+def score_measured(lg, lg_gpu):
+    """Like score_logits with the error MEASURED: err_t = max |logits_gpu - logits_ref| over the step's top-32 reference entries."""
+    top = lg.topk(TOPK, -1)
+    err = (lg_gpu.gather(1, top.indices) - top.values).abs().max(-1).values
+    margin = top.values[:, 0] - top.values[:, 1]
+    ratio = margin / err.clamp_min(1e-9)
+    decisive = ratio > 1.25 * BAND[0]                    # the test's rule is > 4x; 25 % headroom
+    inband = decisive & (ratio < BAND[1])
+    ids = top.indices[:, 0]
+    n_dec, n_dist = int(decisive.sum()), len(set(ids[decisive].tolist()))
+    badness = float((ratio / (BAND[0] * BAND[1]) ** 0.5).log().abs().sum())
+    return (min(n_dec, 6) + min(n_dist, 6), int(inband.sum()), n_dec, -badness), ids, ratio, margin, err
+
+
+def search_head(cfg, w, XN, XN_gpu=None):
+    """XN [n, H] = final-norm hidden state of every recorded step (XN_gpu: the HIP path's, see load_calibration).  Returns (tail_a, tail_max, tail_seed)."""
     name = "llm.lm_head.weight"
     shape, kind = w.specs[name]
     cfg.lm_head_tail = 0.0
     base = synthetic._draw(name, shape, kind, cfg, w.seed, "cpu")                 # row directions x lm_head_std; the tail multiplies rows
     L0 = XN @ base.t()
+    L0g = XN_gpu @ base.t() if XN_gpu is not None else None
     del base
     xn_norm = XN.norm(dim=-1)
     best = None
@@ -136,10 +163,13 @@ def search_head(cfg, w, XN):
         for s in SEEDS:
             cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = a, int(s), m
             scale = synthetic.lm_head_row_scale(name, shape[0], cfg)
-            sc, ids, ratio, margin, err = score_logits(cfg, L0 * scale[None], xn_norm, scale)
+            if L0g is not None:
+                sc, ids, ratio, margin, err = score_measured(L0 * scale[None], L0g * scale[None])
+            else:
+                sc, ids, ratio, margin, err = score_logits(cfg, L0 * scale[None], xn_norm, scale)
             if best is None or sc > best[0]:
                 best = (sc, a, m, s, ids.tolist(), [round(float(r), 1) for r in ratio])
-                print(f"  tail a={a} max={m} seed={s}: in-band {sc[0]}/{len(XN)}, distinct {sc[1]}, ids {ids.tolist()}, margin/err {best[5]}", flush=True)
+                print(f"  tail a={a} max={m} seed={s}: score {sc[:3]}, ids {ids.tolist()}, margin/err {best[5]}", flush=True)
     return best[1], best[2], best[3]
 
 
@@ -185,7 +215,9 @@ def main():
             del hs
             print(f"sft sample {i}: S = {ei.shape[1]} ({time.time() - t2:.0f}s)", flush=True)
         w.store.pop("llm.lm_head.weight")
-        a, m, s = search_head(cfg, w, XN)
+        XN_gpu = load_calibration("nvila8b", ids, forced)
+        print("search scored against " + ("the HIP path's measured hidden states (oracle/calib)" if XN_gpu is not None else f"the error model REL_ERR = {REL_ERR}"), flush=True)
+        a, m, s = search_head(cfg, w, XN, XN_gpu)
         cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = a, int(s), m
         head = w["llm.lm_head.weight"]                                       # the chosen head, bf16-rounded like the GPU model's
         lg = (XN @ head.t()).float()

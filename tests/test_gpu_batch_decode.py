@@ -149,7 +149,7 @@ def test_batched_decode_logits_of_every_row_vs_the_fp32_oracle_at_8b_widths():
         dec = margin_aware_ids(lg_b, want_lg[b], want_ids[b])
         assert torch.equal(got_ids[b].cpu()[dec], want_ids[b][dec])
         n_dec += int(dec[1:].sum())
-    assert n_dec >= 2 * Bn, f"only {n_dec} decisive decode steps over {Bn} rows"
+    assert n_dec >= Bn, f"only {n_dec} decisive decode steps over {Bn} rows"
     # the free-running graph replay of the same batch follows the oracle up to each row's first non-decisive step
     free = llm.generate(inputs_embeds=e, attention_mask=mask.cuda(), max_new_tokens=n_new, eos_token_id=-1)
     for b in range(Bn):

@@ -41,7 +41,7 @@ def _same_host_stream(cfg, fx, keys, seed):
         assert np.array_equal(got, fx[f"fp_w{i}"]), f"CPU generator stream differs from the golden's host for {k}: cannot compare"
 
 
-def _teacher_forced_steps(model, e, fx, what):
+def _teacher_forced_steps(model, e, fx, what, min_distinct=5):
     """The fixture's 8 steps: prefill row + 7 decode steps fed `forced_ids`.  Returns (logits [8, V] on the host, decisive mask, per-step error)."""
     forced = torch.from_numpy(fx["forced_ids"])
     want = torch.from_numpy(fx["tf_argmax_ids"])
@@ -63,7 +63,7 @@ def _teacher_forced_steps(model, e, fx, what):
     am = lg.argmax(-1)
     assert torch.equal(am[decisive], want[decisive]), f"{what}: ids {am.tolist()} vs reference {want.tolist()} (decisive {decisive.tolist()})"
     # the id evidence is real: different tokens win the decisive steps, by margins the path could have lost
-    assert len(set(want[decisive].tolist())) >= 5, f"{what}: the decisive steps carry only {len(set(want[decisive].tolist()))} distinct tokens"
+    assert len(set(want[decisive].tolist())) >= min_distinct, f"{what}: the decisive steps carry only {len(set(want[decisive].tolist()))} distinct tokens"
     assert int((decisive & (ratio <= 20)).sum()) >= 3, f"{what}: margins far above the error on all but {int((decisive & (ratio <= 20)).sum())} steps: {ratio.tolist()}"
     return lg, decisive, err_t
 
@@ -160,6 +160,7 @@ def test_lite3b_full_depth_vs_reference_executed_golden():
     cfg = configs.nvila_lite_3b()
     seed = int(fx["seed"])
     cfg.lm_head_tail, cfg.lm_head_tail_seed, cfg.lm_head_tail_max = float(fx["lm_head_tail"]), int(fx["lm_head_tail_seed"]), float(fx["lm_head_tail_max"])
+    cfg.lm_head_tail_unit_rows = tuple(int(r) for r in fx["lm_head_tail_unit_rows"])      # rows the decoder can see: scale 1 (make_golden_lite3b.py)
     _same_host_stream(cfg, fx, KEYS_3B, seed)
     px = synthetic.make_pixels(cfg, 1, seed).to(torch.bfloat16)
     ids = torch.from_numpy(fx["input_ids"])
@@ -176,6 +177,8 @@ def test_lite3b_full_depth_vs_reference_executed_golden():
     S = e.shape[1]
     assert S == n_img + 1 + 32
     assert rel_l2(e[0, [0, n_img - 1, n_img, n_img + 1, S - 1], :256], torch.from_numpy(fx["embed_rows"])) < 2e-2
-    lg, decisive, err_t = _teacher_forced_steps(model, e, fx, "Lite-3B full depth")
+    # (>= 3 distinct winners here, not 5: the final hidden states of this 36-layer random decoder are nearly parallel from step to step, so however
+    # the tied head's tail is drawn, a few heavy rows win most steps — oracle/make_golden_lite3b.py searches 1792 tails and keeps the most diverse)
+    lg, decisive, err_t = _teacher_forced_steps(model, e, fx, "Lite-3B full depth", min_distinct=3)
     k = _free_running(model, ids, pxg, fx, float(err_t.max()), "Lite-3B full depth")
     print(f"Lite-3B full depth: decisive {int(decisive.sum())}/8, free-running greedy follows the reference for {k} steps")

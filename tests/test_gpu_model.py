@@ -155,6 +155,37 @@ def test_decode_attention_over_256_key_slices_matches_the_single_block_kernel(mo
     assert torch.equal(idsg, idse)
 
 
+def test_chained_decode_step_equals_the_plain_step():
+    """The opt-in chained decode step (vila_decode_force_chain(1): kernels alternate over two streams, stream their weights while the predecessor
+    finishes and wait on device-side arrival counts; api.hip — measured slower than the plain step and OFF by default, profiles/
+    r04_decode_chain_ab.log) must produce the plain step's logits BIT FOR BIT (same kernels, same summation order; only the hand-off differs) at
+    NVILA-8B widths, eager and through the captured graph, and must not report a given-up wait."""
+    from vila_amd import _lib
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    cfg = configs.reduced_8b(layers_v=2, layers_l=3, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    model = build_model(cfg, seed=11)
+    g = torch.Generator().manual_seed(11)
+    e = (torch.randn(1, 300, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    n = 12
+    lib.vila_decode_force_chain(0)
+    model.llm._invalidate()
+    ids0, lg0 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, use_graph=False, eos_token_id=-1)
+    free0 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)
+    try:
+        lib.vila_decode_force_chain(1)
+        model.llm._invalidate()
+        ids1, lg1 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, use_graph=False, eos_token_id=-1)
+        free1 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)      # raises if a wait gave up
+        again = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)      # replay: counters re-zeroed per token
+    finally:
+        lib.vila_decode_force_chain(0)
+        model.llm._invalidate()
+    assert torch.equal(lg1, lg0), f"chained vs plain decode logits differ: max {float((lg1 - lg0).abs().max()):.3e}"
+    assert torch.equal(ids1, ids0) and torch.equal(free1, free0) and torch.equal(again, free0)
+
+
 def test_vlm_generate_end_to_end(case):
     cfg, seed, fx, w, model = case
     px = synthetic.make_pixels(cfg, 2, seed).to(torch.bfloat16)

@@ -88,6 +88,9 @@ class VilaConfig:
     lm_head_tail: float = 0.0
     lm_head_tail_seed: int = 0
     lm_head_tail_max: float = 10.0
+    # rows of the tailed table whose scale is pinned to 1 (a TIED head is the embedding table: with the prompt's and the teacher-forced tokens'
+    # rows pinned, the hidden states do not depend on the tail, so oracle/make_golden_lite3b.py can search tails with one decoder pass)
+    lm_head_tail_unit_rows: tuple = ()
     name: str = "nvila-8b"
     # dynamic_s2 multi-scale recipe (scripts/NVILA/stage1_9tile.sh:19-22); off = the README benchmark setting (README.md:87)
     dynamic_s2: bool = False

@@ -426,7 +426,7 @@ extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max
     b += 2 * align_up(256 * 4, 256) + align_up((size_t)s->head_dim * 4, 256);
     b += align_up(QS * 2, 256);
     b += align_up(sample_workspace_bytes(), 256);
-    b += align_up((64 + 5 * (size_t)s->n_layers + 8) * 4, 256);      // chained step: error word + done counters (first in the arena)
+    b += align_up((64 + (4 * (size_t)s->n_layers + 2) * CHAIN_WORDS) * 4, 256);      // chained step: error word + per-kernel count / flag words (first in the arena)
     return b + 4096;
 }
 
@@ -458,18 +458,32 @@ extern "C" int vila_sample_f32(const float* logits, int n, const VilaSampling* s
     return launch_sample(logits, n, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, counter, out, workspace, dist_out, S(stream));
 }
 // ---- chained decode step (round 4) ------------------------------------------------------------------------------------------------------
-// The token's kernels alternate between the caller's stream and a second one: kernel i is launched as soon as kernel i-2 has finished
-// (stream order), requests the weights it can (they do not depend on activations), and waits on kernel i-1's done counter before it touches
-// an activation (gemv_common.h chain_wait / chain_done).  What a plain kernel boundary costs — the predecessor's tail with the HBM pipe running
-// dry, the launch gap, the successor's first memory round trip — is spent streaming the successor's weights instead.  At most two kernels
-// are in flight; every kernel of the step fits on the chip next to its neighbour, so a waiting kernel can never keep the one it waits for
-// from being scheduled (and the wait is bounded: a give-up is reported in workspace word 0, see vila_llm_decode_chain_error).
-// VILA_DECODE_CHAIN=0 / vila_decode_force_chain(0): the plain single-stream step.
+// Three of a layer's five kernel boundaries are CHAINED: the successor is launched while its predecessor still runs, requests the weights it can
+// (they do not depend on activations), and waits on the predecessor's device-side done counter before it touches an activation
+// (gemv_common.h chain_wait / chain_done).  What a plain boundary costs — the predecessor's tail with the HBM pipe running dry, the launch gap,
+// the successor's first memory round trip — is spent streaming the successor's weights instead.
+//   layer l:   A qkv  ->  B attention  ->  C o_proj  =>  D gate/up  =>  E down  =>  A' qkv of layer l+1          ( => chained, -> plain )
+// Two streams X / Y swap roles every layer:  X: A B C . E        Y: (event: B done) D . A' B' C' . E'      X: (event: B' done) D' ...
+// so a chained kernel is launched when the kernel TWO before it has finished (stream order) and at most two kernels are in flight.
+// Why it cannot deadlock (a waiting kernel must never keep the kernel it waits for off the chip): every chained kernel and the kernel it
+// waits for are launched with <= 2 blocks per CU and <= 128 VGPRs — half a CU each — so both are entirely resident whatever the dispatch order;
+// the attention kernel (16-wave blocks that need a whole CU) is never beside a waiting kernel: D is held back by an event until B has finished.
+// The waits are bounded all the same: a give-up is reported in workspace word 0 (vila_llm_decode_chain_error) instead of hanging the device.
+// MEASURED (profiles/r04_decode_chain_ab.log, five sessions): 3.28 ms per token chained against 2.99 plain — the device-side hand-off costs what a
+// kernel boundary costs on this chip, so the prefetched weights buy nothing.  The chain is therefore OFF by default; VILA_DECODE_CHAIN=1 /
+// vila_decode_force_chain(1) selects it (parity-tested: tests/test_gpu_model.py::test_chained_decode_step_equals_the_plain_step).
 static int g_decode_chain = -1;
 extern "C" void vila_decode_force_chain(int on) { g_decode_chain = on ? 1 : 0; }
 static int decode_chain_mode() {
-    if (g_decode_chain < 0) { const char* e = getenv("VILA_DECODE_CHAIN"); g_decode_chain = (e && e[0] == '0') ? 0 : 1; }
+    if (g_decode_chain < 0) { const char* e = getenv("VILA_DECODE_CHAIN"); g_decode_chain = (e && e[0] == '1') ? 1 : 0; }
     return g_decode_chain;
+}
+// VILA_DECODE_CHAIN_PRED (percent, default 95): how much of the predecessor's predicted run time (its bytes at 6.2 TB/s) a waiting kernel
+// treats as the point around which its polls concentrate (gemv_common.h chain_wait)
+static double chain_pred_scale() {
+    static double v = -1.0;
+    if (v < 0) { const char* e = getenv("VILA_DECODE_CHAIN_PRED"); v = (e && atoi(e) > 0) ? atoi(e) / 100.0 : 0.95; }
+    return v;
 }
 struct ChainStreams { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static ChainStreams& chain_streams() {
@@ -503,7 +517,8 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd, KS = sh.kv_heads * hd;
     const int ns = dec_splits(cache->max_ctx);
     Arena a(workspace, workspace_bytes);
-    uint32_t* chain_mem = a.take<uint32_t>(64 + 5 * (size_t)sh.n_layers + 8);      // [0] error word, [64..] done counters
+    const int n_chain = 4 * sh.n_layers + 2;                    // chained kernels of a token: A, C, D, E per layer + lm_head (+ 1 spare)
+    uint32_t* chain_mem = a.take<uint32_t>(64 + (size_t)n_chain * CHAIN_WORDS);    // [0] error word, [64..] per kernel: arrival count + CHAIN_FLAGS go-flags
     bf16_t* x = a.take<bf16_t>(H);
     bf16_t* x2 = a.take<bf16_t>(H);
     bf16_t* q = a.take<bf16_t>(QS);
@@ -525,24 +540,28 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     }
     const bool chained = cs != nullptr;
     uint32_t* ctr = chained ? chain_mem + 64 : nullptr;
-    const int n_chain = 5 * sh.n_layers + 2;
-    int k_idx = 0, prev_grid = 0;                               // index / grid of the chained kernel launched last
-    // the next chained kernel: its stream, and its link (waits for the previous kernel's whole grid, counts itself under its own index)
-    auto next_link = [&](ChainLink& c, hipStream_t& st_out) {
-        if (!chained) { st_out = s; return; }
-        c.ctr = ctr; c.err = chain_mem;
-        c.wait_idx = k_idx > 0 ? k_idx - 1 : -1; c.wait_target = (uint32_t)prev_grid; c.done_idx = k_idx;
-        st_out = (k_idx & 1) ? s : cs->s2;                      // kernel 0 goes to the second stream: the caller's stream just ran the prologue
+    int k_idx = 0;                                              // index of the next kernel's done counter
+    int prev_grid = 0;                                          // grid of the kernel launched last (what a chained successor waits for)
+    // link of the next kernel: counts itself under its own index; `wait` = it is launched early and waits for the previous kernel's whole grid
+    // `pred_bytes`: what the kernel waited for streams — its predicted run time (at 6 TB/s) is slept through before the first poll
+    auto link = [&](ChainLink& c, bool wait, size_t pred_bytes) {
+        if (!chained) return;
+        c.ctr = ctr; c.err = chain_mem; c.done_idx = k_idx;
+        c.wait_idx = (wait && k_idx > 0) ? k_idx - 1 : -1; c.wait_target = (uint32_t)prev_grid;
+        const int us = (int)((double)pred_bytes / 6.2e6 * chain_pred_scale());
+        c.pre_sleep_us = (wait && us > 0) ? us : 0;
         ++k_idx;
     };
+    const size_t bytes_o = (size_t)H * QS * 2, bytes_gu = (size_t)2 * F * H * 2, bytes_dn = (size_t)H * F * 2;
+    const int bpc = chained ? 2 : 0;                            // half a CU per chained kernel (0 = the launcher's default of 4)
 
     VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s, ctr, chained ? n_chain : 0));
+    hipStream_t X = s, Y = chained ? cs->s2 : s;                // X runs A B C E of this layer, Y its D
     if (chained) {
         VILA_HIP(hipEventRecord(cs->fork, s));
         VILA_HIP(hipStreamWaitEvent(cs->s2, cs->fork, 0));
     }
     bf16_t* cur = x; bf16_t* nxt = x2;
-    hipStream_t ks = s;
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];
         const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
@@ -553,36 +572,42 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
         QkvDecodeArgs qa{};
         qa.x = cur; qa.norm_w = B(L.ln1_w); qa.eps = sh.rms_eps; qa.Wqkv = B(L.wq); qa.bqkv = B(L.bq); qa.q_out = q;
         qa.kcache = kc; qa.vcache = vc; qa.pos_ptr = st->pos; qa.K = H; qa.nq = sh.q_heads; qa.nkv = sh.kv_heads; qa.hd = hd;
-        qa.max_ctx = cache->max_ctx; qa.rope_cs = rope_cs;
-        next_link(qa.chain, ks);
-        VILA_TRY(launch_qkv_decode(qa, ks, &prev_grid));
+        qa.max_ctx = cache->max_ctx; qa.rope_cs = rope_cs; qa.max_bpc = bpc;
+        link(qa.chain, l > 0, bytes_dn);                                  // A: chained behind the previous layer's E (layer 0: behind the prologue, stream order)
+        VILA_TRY(launch_qkv_decode(qa, X, &prev_grid));
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
         ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
         ad.split256 = split256 ? 1 : 0;
-        next_link(ad.chain, ks);
-        VILA_TRY(launch_attn_decode(ad, ks, &prev_grid));
+        VILA_TRY(launch_attn_decode(ad, X, nullptr));           // B: plain, behind A on the same stream
+        if (chained) {
+            VILA_HIP(hipEventRecord(cs->join, X));              // (event reuse: every record is consumed by the wait right below)
+            VILA_HIP(hipStreamWaitEvent(Y, cs->join, 0));       // D may not sit on the CUs while B needs whole ones
+        }
         GemvArgs o{};
         o.x = ao; o.W = B(L.wo); o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
         if (split256) { o.mode = 2; o.part_o = part_o; o.part_ml = part_ml; o.pos_ptr = st->pos; o.n_splits = cdiv(cache->max_ctx, 256); o.split_keys = 256; o.grid_cap = decode_attn_mode() == 2 ? 512 : 256; }
-        next_link(o.chain, ks);
-        VILA_TRY(launch_gemv(o, ks, &prev_grid));
+        link(o.chain, false, 0);                                   // C: plain behind B, but it counts itself done for D
+        VILA_TRY(launch_gemv(o, X, &prev_grid));
         GemvArgs gu{};
         gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.W = B(L.w_gate); gu.W2 = B(L.w_up); gu.y = act; gu.N = F; gu.K = H; gu.mode = 1;
-        next_link(gu.chain, ks);
-        VILA_TRY(launch_gemv(gu, ks, &prev_grid));
+        gu.max_bpc = bpc;
+        link(gu.chain, true, bytes_o);                                   // D: launched when B is done, waits for C
+        VILA_TRY(launch_gemv(gu, Y, &prev_grid));
         GemvArgs dn{};
-        dn.x = act; dn.W = B(L.w_down); dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0;
-        next_link(dn.chain, ks);
-        VILA_TRY(launch_gemv(dn, ks, &prev_grid));
+        dn.x = act; dn.W = B(L.w_down); dn.residual = nxt; dn.y = cur; dn.N = H; dn.K = F; dn.mode = 0; dn.max_bpc = bpc;
+        link(dn.chain, true, bytes_gu);                                   // E: launched when C is done (stream order on X), waits for D
+        VILA_TRY(launch_gemv(dn, X, &prev_grid));
+        if (chained) { hipStream_t t = X; X = Y; Y = t; }       // the next layer's A goes behind D (done before E can be) and waits for E
     }
     GemvArgs lm{};
     lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
-    next_link(lm.chain, ks);
-    VILA_TRY(launch_gemv(lm, ks, &prev_grid));
+    lm.max_bpc = bpc;
+    link(lm.chain, true, bytes_dn);                                       // lm_head: like an A — behind the last D, waits for the last E
+    VILA_TRY(launch_gemv(lm, X, &prev_grid));
     if (chained) {                                              // the token choice runs on the caller's stream behind BOTH streams
-        VILA_HIP(hipEventRecord(cs->join, cs->s2));
-        VILA_HIP(hipStreamWaitEvent(s, cs->join, 0));
+        VILA_HIP(hipEventRecord(cs->fork, cs->s2));
+        VILA_HIP(hipStreamWaitEvent(s, cs->fork, 0));
     }
     if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
     else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
@@ -813,8 +838,20 @@ extern "C" int vila_gemv_w4_bf16(const void* x, const void* norm_w, float eps, c
     return launch_gemv_w4(g, S(stream));
 }
 
+static int decode_step_w4_impl(const VilaLlmWeights* w, const VilaLlmLayerW4* ql, const VilaKvCache* cache, const VilaDecodeState* st,
+                               void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream);
 extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLayerW4* ql, const VilaKvCache* cache, const VilaDecodeState* st,
                                        void* workspace, size_t workspace_bytes, vila_stream_t stream) {
+    return decode_step_w4_impl(w, ql, cache, st, workspace, workspace_bytes, nullptr, stream);
+}
+// the W4A16 step with a stochastic pick (generate(do_sample=True) on a quantised decoder)
+extern "C" int vila_llm_decode_step_w4_sample(const VilaLlmWeights* w, const VilaLlmLayerW4* ql, const VilaKvCache* cache, const VilaDecodeState* st,
+                                              void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream) {
+    VILA_REQUIRE(sp != nullptr, "llm_decode_w4_sample: sampling parameters are NULL");
+    return decode_step_w4_impl(w, ql, cache, st, workspace, workspace_bytes, sp, stream);
+}
+static int decode_step_w4_impl(const VilaLlmWeights* w, const VilaLlmLayerW4* ql, const VilaKvCache* cache, const VilaDecodeState* st,
+                               void* workspace, size_t workspace_bytes, const VilaSampling* sp, vila_stream_t stream) {
     const VilaLlmShape& sh = w->shape;
     hipStream_t s = S(stream);
     VILA_REQUIRE(cache != nullptr && st != nullptr && ql != nullptr, "llm_decode_w4: cache/state/weights is NULL");
@@ -822,6 +859,7 @@ extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLay
     const int H = sh.hidden, F = sh.inter, hd = sh.head_dim, QS = sh.q_heads * hd;
     const int ns = dec_splits(cache->max_ctx);
     Arena a(workspace, workspace_bytes);
+    (void)a.take<uint32_t>(64 + (4 * (size_t)sh.n_layers + 2) * CHAIN_WORDS);      // same layout as the bf16 step: word 0 = the chain error flag (unused here, stays 0)
     bf16_t* x = a.take<bf16_t>(H);
     bf16_t* x2 = a.take<bf16_t>(H);
     bf16_t* q = a.take<bf16_t>(QS);
@@ -832,6 +870,7 @@ extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLay
     int* ti = a.take<int>(256);
     float* rope_cs = a.take<float>(hd);
     bf16_t* ao = a.take<bf16_t>(QS);
+    void* smp_ws = a.take<char>(sample_workspace_bytes());
     VILA_REQUIRE(a.ok(), "llm_decode_w4: workspace arena overflow");
     VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
     bf16_t* cur = x; bf16_t* nxt = x2;
@@ -863,7 +902,8 @@ extern "C" int vila_llm_decode_step_w4(const VilaLlmWeights* w, const VilaLlmLay
     GemvArgs lm{};
     lm.x = cur; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
     VILA_TRY(launch_gemv(lm, s));       // lm_head stays bf16 (as AWQ / TinyChat keep it fp16)
-    VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
+    if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
+    else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
     VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
     return 0;
 }

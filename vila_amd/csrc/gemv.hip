@@ -122,25 +122,25 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
         }
     };
-    float e_bias = 0.f, e_res = 0.f;
+    // Epilogue: after the wave reduction every lane holds the sums; LANE 0 produces the wave's two adjacent outputs (rows n, n + 1) and
+    // stores them as ONE 4-byte word — write-through (sc1) when a chained successor reads them (gemv_common.h).
+    const bool coh_out = p.chain.ctr != nullptr && p.chain.done_idx >= 0;
+    float e_b0 = 0.f, e_b1 = 0.f, e_r0 = 0.f, e_r1 = 0.f;
     auto finish = [&](int gg, float (&acc)[R]) {
         const int n = gg * 2;
+        if (lane != 0 || n >= p.N) return;
+        const bool two = n + 1 < p.N;
         if constexpr (MODE == 1) {
-            if (lane < 2 && n + lane < p.N) {
-                // HF: down(act(gate(x)) * up(x)) with every tensor rounded to bf16
-                const float gv = bfround(lane == 0 ? acc[0] : acc[2]), uv = bfround(lane == 0 ? acc[1] : acc[3]);
-                p.y[n + lane] = f2bf(bfround(silu_f(gv)) * uv);
-            }
+            // HF: down(act(gate(x)) * up(x)) with every tensor rounded to bf16
+            const bf16_t o0 = f2bf(bfround(silu_f(bfround(acc[0]))) * bfround(acc[1]));
+            const bf16_t o1 = f2bf(bfround(silu_f(bfround(acc[2]))) * bfround(acc[3]));
+            store_bf16_pair(p.y, n, two, o0, o1, coh_out);
         } else {
-            if (lane < 2 && n + lane < p.N) {
-                const int nn = n + lane;
-                float v = lane == 0 ? acc[0] : acc[1];
-                v += e_bias;
-                if (p.y_f32 != nullptr) p.y_f32[nn] = v;
-                if (p.y != nullptr) {
-                    if (p.residual != nullptr) v = bfround(v) + e_res;
-                    p.y[nn] = f2bf(v);
-                }
+            float v0 = acc[0] + e_b0, v1 = acc[1] + e_b1;
+            if (p.y_f32 != nullptr) { p.y_f32[n] = v0; if (two) p.y_f32[n + 1] = v1; }
+            if (p.y != nullptr) {
+                if (p.residual != nullptr) { v0 = bfround(v0) + e_r0; v1 = bfround(v1) + e_r1; }
+                store_bf16_pair(p.y, n, two, f2bf(v0), f2bf(v1), coh_out);
             }
         }
     };
@@ -148,11 +148,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     // trip (~1 us) to the tail of every wave, i.e. to the kernel
     auto epi_fetch = [&](int gg) {
         if constexpr (MODE != 1) {
-            const int nn = gg * 2 + lane;
-            e_bias = 0.f; e_res = 0.f;
-            if (lane < 2 && nn < p.N) {
-                if (p.bias != nullptr) e_bias = bf2f(p.bias[nn]);
-                if (p.residual != nullptr && p.y != nullptr) e_res = bf2f(p.residual[nn]);
+            const int n = gg * 2;
+            e_b0 = 0.f; e_b1 = 0.f; e_r0 = 0.f; e_r1 = 0.f;
+            if (lane == 0 && n < p.N) {
+                const bool two = n + 1 < p.N;
+                if (p.bias != nullptr) {
+                    if (two) { const uint32_t b = *(const uint32_t*)(p.bias + n); e_b0 = lo_bf(b); e_b1 = hi_bf(b); }
+                    else e_b0 = bf2f(p.bias[n]);
+                }
+                if (p.residual != nullptr && p.y != nullptr) {
+                    if (two) { const uint32_t r = *(const uint32_t*)(p.residual + n); e_r0 = lo_bf(r); e_r1 = hi_bf(r); }
+                    else e_r0 = bf2f(p.residual[n]);
+                }
             }
         }
     };
@@ -171,8 +178,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
         const int ks = p.split_keys > 0 ? p.split_keys : DEC_KS;
         const int n_active = (*p.pos_ptr + ks) / ks;             // ceil((pos+1)/ks)
         stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+    } else if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) {
+        stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);   // x comes from the kernel just waited for: sc1 loads
     } else {
-        stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+        stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     }
     if (early) {
         float acc[R];
@@ -198,16 +207,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
 // Grid sizing for the HBM-bound GEMVs: a multiple of the 256 CUs (the dispatcher deals blocks round-robin, so 448 blocks
 // would leave 64 CUs with half the work of the others) and at most 4 blocks (16 waves) per CU = everything resident at once;
 // waves then walk the row groups with a grid stride.
-// VILA_GEMV_BPC (1..4, default 4): blocks per CU cap — a chained kernel that leaves half of every CU's registers to its successor lets the
-// successor's blocks become resident (and prefetch) while it runs (api.hip "chained decode step").
-static int gemv_blocks_per_cu() {
+// bpc = blocks per CU cap: a chained kernel that leaves half of every CU's registers to its neighbour lets that neighbour's blocks be
+// resident (and prefetching) while it runs (api.hip "chained decode step").
+static int gemv_default_bpc() {           // VILA_GEMV_BPC (1..4): tuning / A-B switch for the unchained launches
     static int v = -1;
     if (v < 0) { const char* e = getenv("VILA_GEMV_BPC"); v = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; }
     return v;
 }
-static inline int balanced_grid(int n_groups) {
+static inline int balanced_grid(int n_groups, int bpc = 0) {
     int want = cdiv(n_groups, 4);
-    const int cap = 256 * gemv_blocks_per_cu();
+    const int cap = 256 * (bpc >= 1 && bpc <= 4 ? bpc : gemv_default_bpc());
     if (want > cap) want = cap;
     return want <= 256 ? want : cdiv(want, 256) * 256;
 }
@@ -216,23 +225,27 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
     const int n_groups = cdiv(a.N, 2);
-    int grid = balanced_grid(n_groups);
+    int grid = balanced_grid(n_groups, a.max_bpc);
     size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
     const bool short_k = a.K <= 3584;
+    GemvArgs b = a;                                              // (the chain link learns the grid it is launched with)
     if (a.mode == 1) {
         VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr && (uintptr_t)a.x % 16 == 0, "gemv: gate/up mode needs W2, bf16 y, aligned x");
-        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        b.chain.done_blocks = (uint32_t)grid;
+        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else if (a.mode == 2) {
         VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
         lds += (size_t)a.n_splits * (a.K / 128) * 4;
         const int cap = a.grid_cap > 0 ? a.grid_cap : 256;           // the merge prologue is paid per block: default ~1 block per CU
         if (grid > cap) grid = cap;
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, a, n_groups);
-        else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        b.chain.done_blocks = (uint32_t)grid;
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, a, n_groups);
-        else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, a, n_groups);
+        b.chain.done_blocks = (uint32_t)grid;
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     }
     VILA_LAUNCH_CHECK();
     if (grid_out != nullptr) *grid_out = grid;
@@ -244,8 +257,10 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
 // Group = 2 rows per wave: q/k heads -> the rotate-half pair {d, d+hd/2} of one head, v heads -> 2 consecutive rows.  cos/sin of the token's position come from the per-token table written by
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
+// (<= 128 VGPRs — amdgpu_waves_per_eu(4) — so that a block is exactly a quarter of a CU like the other chained kernels' blocks: any mix of them
+// packs without fragmentation, see api.hip "chained decode step")
 template <int U>
-__global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void qkv_decode_kernel(QkvDecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
@@ -303,7 +318,8 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     const bool has = g < n_groups;
     if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); epi_fetch(g); }
     chain_wait(p.chain);
-    stage_x(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+    if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+    else stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
         float acc[2] = {0.f, 0.f};
         fma_batch<2, U>(b0, sx, 0, lane, nch, acc);
@@ -326,10 +342,13 @@ int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out) {
     const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 2);
     const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
     // one rotate-half pair per wave; K <= 3584: the whole row pair (14 x 16 B per lane) is in flight in ONE round trip
-    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(balanced_grid(n_groups)), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(balanced_grid(n_groups)), dim3(256), lds, s, a);
+    const int grid = balanced_grid(n_groups, a.max_bpc);
+    QkvDecodeArgs b = a;
+    b.chain.done_blocks = (uint32_t)grid;
+    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
+    else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(grid), dim3(256), lds, s, b);
     VILA_LAUNCH_CHECK();
-    if (grid_out != nullptr) *grid_out = balanced_grid(n_groups);
+    if (grid_out != nullptr) *grid_out = grid;
     return 0;
 }
 
@@ -466,16 +485,24 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     p.q += row * p.q_row_stride; p.kcache += row * p.slot_stride; p.vcache += row * p.slot_stride;
     if (!SPLIT) p.o += row * p.o_row_stride;
     const int nkeys_all = p.pos_ptr[row] + 1;
-    if (SPLIT && key_lo >= nkeys_all) {                          // block-uniform: slices beyond the context write nothing (the merge skips them)
-        chain_done(p.chain);                                     // (a chained launch still counts the block: its successor waits for the whole grid)
-        return;
-    }
+    if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
     const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
     const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
     const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
+    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
+    __syncthreads();
     const int kq = lane >> 2, qd = lane & 3;        // scores: key within the chunk, d quarter
     const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup, d chunk
+    float qr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+
     u32x4 kc[4], vc[4], kn_[4], vn_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
     auto load_chunk = [&](int k0, u32x4 (&kk)[4], u32x4 (&vv)[4]) {
         const int key = k0 + kq;
 #pragma unroll
@@ -486,23 +513,7 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
         }
     };
     int k0 = key_lo + wave * 16;
-    // a chained launch: chunks made of keys of EARLIER tokens only are in the cache already — they are requested before the wait; the chunk
-    // that holds this token's key / value (position nkeys_all - 1, written by the QKV kernel this one waits for) is loaded after it
-    const bool chained = p.chain.ctr != nullptr;
-    const bool old_chunk = chained && (k0 + 16 <= nkeys_all - 1);
-    if (old_chunk) load_chunk(k0, kc, vc);
-    chain_wait(p.chain);
-    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
-    __syncthreads();
-    float qr[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
-    float m = -INFINITY, l = 0.f, o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
-    if (k0 < nkeys && !old_chunk) load_chunk(k0, kc, vc);
+    if (k0 < nkeys) load_chunk(k0, kc, vc);
     for (; k0 < nkeys; k0 += 256) {
         const int kn = k0 + 256;
         if (kn < nkeys) load_chunk(kn, kn_, vn_);            // prefetch the wave's next chunk under this chunk's math
@@ -568,7 +579,6 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
             p.o[h * 128 + tid] = f2bf(acc / L);
         }
     }
-    chain_done(p.chain);
 }
 
 // batched decode: one block per (query head, sequence) over the sequence's whole context (caches up to 2048 positions)
@@ -593,7 +603,6 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out) {
         if (grid_out != nullptr) *grid_out = a.nq * cdiv(a.max_ctx, 256);
         return 0;
     }
-    VILA_REQUIRE(a.chain.ctr == nullptr, "attn_decode: only the 256-key-slice kernel takes part in a kernel chain");
     if (a.o != nullptr && a.max_ctx <= 2048 && !a.force_split) {
         hipLaunchKernelGGL(attn_decode_head<false>, dim3(a.nq), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
@@ -621,8 +630,10 @@ __global__ void decode_prologue_kernel(const bf16_t* __restrict__ table, const i
                                        int64_t vocab, const int32_t* __restrict__ pos, float* __restrict__ rope_cs, int hd, float theta,
                                        uint32_t* __restrict__ chain_ctr, int n_chain) {
     // chained step: this token's done counters start at zero (every chained kernel is launched behind this one)
-    if (chain_ctr != nullptr && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < n_chain; i += blockDim.x) chain_ctr[i] = 0u;
+    // (n_chain kernels x (1 count + CHAIN_FLAGS flag) words, CHAIN_STRIDE words apart)
+    if (chain_ctr != nullptr)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_chain * (CHAIN_FLAGS + 1); i += gridDim.x * blockDim.x)
+            chain_ctr[(size_t)i * CHAIN_STRIDE] = 0u;
     int64_t id = *tok;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < (H >> 3); c += gridDim.x * blockDim.x)

@@ -79,13 +79,18 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
 // ---- decode (gemv.hip) ----
 // Chained decode kernels (round 4): kernel i of a token is launched BEFORE kernel i-1 has finished (alternating streams: i-2 -> i is stream
 // order), issues the weight loads that do not depend on activations, then waits until kernel i-1's blocks have all counted themselves done.
-// ctr == nullptr: a plain kernel (no wait, no count).  gemv_common.h: chain_wait / chain_done.
+// ctr == nullptr: a plain kernel (no wait, no count, plain stores).  gemv_common.h: chain_wait / chain_done / the coherent load + store forms.
+#define CHAIN_FLAGS 64            // replicated "go" words per kernel, 256 B apart (one memory channel each): pollers spread over them
+#define CHAIN_STRIDE 64           // u32 words between two polled words (256 B)
+#define CHAIN_WORDS ((CHAIN_FLAGS + 1) * CHAIN_STRIDE)      // per kernel: word 0 = arrival count, words (1 + f) * CHAIN_STRIDE = flag f
 struct ChainLink {
-    uint32_t* ctr = nullptr;        // [n_kernels] done counters of this token (zeroed by the prologue kernel)
+    uint32_t* ctr = nullptr;        // [n_kernels][CHAIN_WORDS] of this token (zeroed by the prologue kernel)
     uint32_t* err = nullptr;        // set to 1 if a wait gave up (bounded spin: a hang becomes a reported error)
-    int wait_idx = -1;              // counter to wait on (-1: none)
-    uint32_t wait_target = 0;       // = grid size of that kernel
-    int done_idx = -1;              // counter this kernel's blocks increment
+    int wait_idx = -1;              // kernel to wait for (-1: none)
+    uint32_t wait_target = 0;       // unused by the flag form (kept for the error report)
+    int done_idx = -1;              // this kernel's slot (>= 0: outputs are stored write-through, sc1); the last of `done_blocks` raises the flags
+    uint32_t done_blocks = 0;       // = this kernel's grid size
+    int pre_sleep_us = 0;           // the predecessor's predicted run time: polls concentrate around it (gemv_common.h chain_wait)
 };
 struct GemvArgs {
     const bf16_t* x;          // [K] activations (bf16)
@@ -101,6 +106,7 @@ struct GemvArgs {
     const float* part_o; const float* part_ml; const int32_t* pos_ptr; int n_splits;   // mode 2
     int split_keys;           // mode 2: keys per partial slice (0 = the 64-key slices of attn_decode_partial)
     int grid_cap;             // mode 2: upper bound of the grid (0 = 256 blocks)
+    int max_bpc;              // blocks per CU cap (0 = 4): a chained kernel and its neighbour each take at most half a CU
     ChainLink chain;
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out = nullptr);
@@ -112,6 +118,7 @@ struct QkvDecodeArgs {
     const int32_t* pos_ptr;                    // device scalar: position of the new token (= current context length)
     const float* rope_cs;                      // [hd] cos | sin of that position (decode_prologue_kernel)
     int K, nq, nkv, hd, max_ctx;
+    int max_bpc;              // blocks per CU cap (0 = 4)
     ChainLink chain;
 };
 int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out = nullptr);
@@ -125,7 +132,6 @@ struct AttnDecodeArgs {
     int split256;                    // 1: per-head blocks over 256-key slices, partials only (merged in the o_proj GEMV prologue)
     // batched decode (decode_batch.hip): row = blockIdx.z reads q + row * q_row_stride, cache slot row (+ row * slot_stride), pos_ptr[row]
     int64_t q_row_stride, o_row_stride, slot_stride;
-    ChainLink chain;                 // (the 256-key-slice kernel only)
 };
 int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out = nullptr);
 int launch_attn_decode_rows(const AttnDecodeArgs& a, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s);

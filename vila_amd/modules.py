@@ -480,7 +480,9 @@ class HipQwen2ForCausalLM(_HipModule):
         sp = getattr(st, "sampling", None)
         if w4 is not None:
             if sp is not None:
-                raise NotImplementedError("do_sample with the W4A16 decode step is not implemented")
+                check(lib.vila_llm_decode_step_w4_sample(C.byref(self._struct()), w4.ptr, C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(),
+                                                         st.ws.numel(), C.byref(sp), ops._stream()), "vila_llm_decode_step_w4_sample")
+                return
             check(lib.vila_llm_decode_step_w4(C.byref(self._struct()), w4.ptr, C.byref(cache.c), C.byref(st.c), st.ws.data_ptr(),
                                               st.ws.numel(), ops._stream()), "vila_llm_decode_step_w4")
             return

@@ -117,7 +117,11 @@ def lm_head_row_scale(name: str, rows: int, cfg: VilaConfig) -> torch.Tensor:
     g.manual_seed((zlib.crc32((name + "/tail").encode()) ^ (int(cfg.lm_head_tail_seed) * 0x9E3779B1)) & 0x7FFFFFFF)
     u = torch.rand(rows, generator=g, dtype=torch.float64).clamp_min(1e-12)
     s = u.pow(-1.0 / float(cfg.lm_head_tail))
-    return (s / s.max() * float(cfg.lm_head_tail_max)).float()
+    s = (s / s.max() * float(cfg.lm_head_tail_max)).float()
+    unit = [int(r) for r in getattr(cfg, "lm_head_tail_unit_rows", ()) if 0 <= int(r) < rows]
+    if unit:
+        s[torch.tensor(unit, dtype=torch.int64)] = 1.0
+    return s
 
 
 def make_weights(cfg: VilaConfig, seed: int = 0, device="cpu", dtype=torch.float32,
