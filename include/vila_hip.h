@@ -165,19 +165,21 @@ int vila_llm_decode_chain_error(void* workspace, vila_stream_t stream);
 
 /* generate(do_sample=True): what HF GenerationMixin.sample does after the forward — logits / temperature -> TopK -> TopP -> softmax ->
  * multinomial (server.py:101-102,185-187 sets temperature 0.2 / top_p 0.9; GenerationConfig's default top_k = 50 applies).  The whole
- * choice runs on the device (three short launches) so that a sampled step replays from a hipGraph; the uniform number is
- * splitmix64(seed, position of the token).  top_k must be in 1..64.  Parity with torch.multinomial is distributional, not bitwise. */
+ * choice runs on the device (three short launches for top_k in 1..64; one exact radix-selection launch for any other k) so that a sampled step
+ * replays from a hipGraph; the uniform number is splitmix64(seed, position of the token).  Parity with torch.multinomial is distributional,
+ * not bitwise. */
 typedef struct {
     float temperature;   /* > 0 */
-    int top_k;           /* 1..64 */
+    int top_k;           /* >= 0; 0 = no top-k filter (HF), k >= n = the same */
     float top_p;         /* (0, 1] */
     uint64_t seed;
     const uint64_t* seed_dev;   /* optional device scalar: when non-NULL the kernel reads the seed from it (a captured decode graph then
                                    serves every sampled request: the host updates 8 bytes instead of re-capturing) and `seed` is ignored */
 } VilaSampling;
 size_t vila_sample_workspace_bytes(void);
-/* logits [n] fp32 -> *out; counter: device scalar mixed into the RNG (nullable); dist_out (nullable): [64] probabilities actually sampled
- * from followed by [64] int32 token ids (descending probability, -1 = unused slot) */
+/* logits [n] fp32 -> *out; counter: device scalar mixed into the RNG (nullable); dist_out (nullable): the distribution actually sampled from —
+ * top_k in 1..64: [64] probabilities followed by [64] int32 token ids (descending probability, -1 = unused slot); any other top_k: [n] dense
+ * probabilities */
 int vila_sample_f32(const float* logits, int n, const VilaSampling* sp, const int32_t* counter, int64_t* out, void* workspace,
                     float* dist_out, vila_stream_t stream);
 int vila_llm_decode_step_sample(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,

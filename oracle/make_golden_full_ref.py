@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import make_golden as G                     # noqa: E402  (reference loaders: ref_siglip / ref_projector / build config helpers)
-from oracle.make_golden_full import (LazyBf16Weights, SEED, N_NEW, TOPK, SFT_B, fingerprints, sft_batch, sft_rows)      # noqa: E402
+from oracle.make_golden_full import (LazyBf16Weights, SEED, N_NEW, TOPK, SFT_B, fingerprints, sft_batch, sft_rows, untailed_head)      # noqa: E402
 from vila_amd import configs, synthetic                 # noqa: E402
 
 SRC = os.path.join(ROOT, "tests", "golden", "nvila8b_full_depth.npz")
@@ -92,11 +92,14 @@ def main():
     t0 = time.time()
     with torch.no_grad():
         vis_w = {k: w[k] for k in w.specs if k.startswith("vision_tower.")}
+        timing = {"threads": torch.get_num_threads(), "cpu_count": os.cpu_count(), "dtype": "fp32"}
+        tt = time.time()
         hs = G.run_vision(cfg, vis_w, px)
         feats = hs[cfg.vision.select_layer]                                  # hidden_states[-2]
         del hs
         proj_w = {k: w[k] for k in w.specs if k.startswith("mm_projector.")}
         proj = G.run_projector(cfg, proj_w, feats)
+        timing["tower_projector_s"] = round(time.time() - tt, 3)              # reference SigLIP (27 layers as the reference runs them, incl. building the module) + projector, 1 tile
         # configs[2]'s four images through the reference tower + projector now, while their weights are around
         spx, sids, slabels = sft_batch(cfg, SEED)
         sft_proj = [G.run_projector(cfg, proj_w, G.run_vision(cfg, vis_w, spx[i:i + 1])[cfg.vision.select_layer])[0] for i in range(SFT_B)]
@@ -118,8 +121,10 @@ def main():
         t2 = time.time()
         r = llm(inputs_embeds=e, use_cache=True, logits_to_keep=1)
         past, last = r.past_key_values, r.logits[0, -1].float()
+        timing["prefill_s"] = round(time.time() - t2, 3)
         past0 = copy.deepcopy(past)                                          # HF's cache is updated in place: the greedy run restarts from a copy
         print(f"HF prefill {time.time() - t2:.0f}s", flush=True)
+        t_dec = time.time()
         forced = torch.from_numpy(src["forced_ids"])
         step_logits = []
         for t in range(N_NEW):                                               # teacher-forced with the fixture's random sequence
@@ -129,6 +134,9 @@ def main():
             r = llm(input_ids=forced[t].view(1, 1), past_key_values=past, use_cache=True)
             past, last = r.past_key_values, r.logits[0, -1].float()
         lg = torch.stack(step_logits)
+        timing["decode_s_per_token"] = round((time.time() - t_dec) / (N_NEW - 1), 4)
+        timing["decode_tokens_per_s"] = round((N_NEW - 1) / (time.time() - t_dec), 4)
+        timing["ttft_s"] = round(timing["tower_projector_s"] + timing["prefill_s"], 3)
         gen, gmargin, past, last = [], [], past0, lg[0]
         for t in range(N_NEW):                                               # free-running greedy
             nxt = int(last.argmax())
@@ -141,6 +149,8 @@ def main():
             past, last = r.past_key_values, r.logits[0, -1].float()
         del past, past0
         # ---- configs[2]: the SFT micro-batch through the reference's modules, loss by HF's own loss function ----
+        # (the SFT pin uses the PLAIN synthetic head — see make_golden_full.py: the tailed head is swapped out of the HF model here)
+        llm.lm_head.weight.copy_(untailed_head(cfg, w))
         assert np.array_equal(sids.numpy(), src["sft_input_ids"]) and np.array_equal(slabels.numpy(), src["sft_labels"])
         n_items = int(src["sft_num_items"])
         ce_sum, r_ids, r_vals = [], [], []
@@ -172,7 +182,7 @@ def main():
         "greedy_ids": np.asarray(gen, dtype=np.int64), "greedy_margins": np.asarray(gmargin, dtype=np.float32), "hf_version": np.array(ver),
         "lm_head_tail": src["lm_head_tail"], "lm_head_tail_seed": src["lm_head_tail_seed"], "lm_head_tail_max": src["lm_head_tail_max"],
         "sft_input_ids": sids.numpy(), "sft_labels": slabels.numpy(), "sft_fp_pixels": spx.reshape(SFT_B, -1)[:, :16].numpy().copy(),
-        "sft_loss": np.float64(loss), "sft_ce_sums": np.asarray(ce_sum, dtype=np.float64), "sft_num_items": np.int64(n_items),
+        "sft_head_tail": np.float32(0.0), "sft_loss": np.float64(loss), "sft_ce_sums": np.asarray(ce_sum, dtype=np.float64), "sft_num_items": np.int64(n_items),
         "sft_rows": sft_rows(769).numpy(), "sft_top_ids": torch.stack(r_ids).numpy().astype(np.int32), "sft_top_vals": torch.stack(r_vals).numpy().astype(np.float32),
         "top_ids": top.indices.numpy().astype(np.int32), "top_vals": top.values.numpy().astype(np.float32),
         "logit_absmax": lg.abs().amax(-1).numpy().astype(np.float32), "logit_norm": lg.norm(dim=-1).numpy().astype(np.float32),
@@ -181,6 +191,12 @@ def main():
         "embed_rows": e[0, [0, 255, 256, 257, 768], :256].numpy().astype(np.float32), "embed_norm": np.float32(e.norm()),
     })
     np.savez_compressed(OUT, **out)
+    # a by-product, NOT a fixture: how long the reference's own code took here (the CPU reference timed on the same host class)
+    import json
+    timing.update({"what": "reference-executed NVILA-8B at full depth on this container's CPU: reference SigLIP + projector (1 tile) -> HF Qwen2ForCausalLM "
+                           "fp32 eager, 769-token prefill, 7 teacher-forced decode steps with KV cache", "hf_version": ver, "script": "oracle/make_golden_full_ref.py"})
+    with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_timing.json"), "w") as fh:
+        json.dump(timing, fh, indent=1)
     print(f"wrote {OUT} ({os.path.getsize(OUT)} bytes): ids {gen} (oracle-executed fixture: {src['greedy_ids'].tolist()}) in {time.time() - t0:.0f}s", flush=True)
 
 

@@ -12,7 +12,9 @@ import transformers
 from transformers import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
 
 CASES = [(1000, 1.0, 50, 1.0, 3.0), (4096, 0.2, 50, 0.9, 3.0), (4096, 0.7, 64, 0.5, 2.0), (5000, 1.5, 1, 0.9, 3.0), (300, 0.9, 40, 0.3, 3.0),
-         (2048, 0.8, 20, 0.95, 2.0)]
+         (2048, 0.8, 20, 0.95, 2.0),
+         # round 4 (any top_k): k > 64, k = 0 (HF adds no TopKLogitsWarper for 0: GenerationMixin._get_logits_processor), k >= V
+         (8192, 1.0, 100, 0.95, 2.5), (20000, 0.7, 1000, 0.9, 3.0), (6000, 1.0, 0, 0.9, 3.0), (3000, 0.5, 5000, 0.999, 2.0)]
 
 
 def main():
@@ -22,7 +24,8 @@ def main():
         logits = (torch.randn(1, V, generator=g) * scale).float()
         ids = torch.zeros((1, 1), dtype=torch.long)
         z = TemperatureLogitsWarper(temperature)(ids, logits.clone())
-        z = TopKLogitsWarper(top_k)(ids, z)
+        if top_k != 0:                                       # _get_logits_processor: `top_k is not None and top_k != 0`
+            z = TopKLogitsWarper(top_k)(ids, z)
         if top_p < 1.0:
             z = TopPLogitsWarper(top_p)(ids, z)
         out[f"c{n}_params"] = np.array([V, temperature, top_k, top_p], dtype=np.float64)

