@@ -347,15 +347,17 @@ def sft_flops_per_sample(cfg, S: int, n_targets: int = 256) -> float:
 def _sft_gemm_traffic():
     """L2-fill bytes per GEMM of the contraction-major (wgrad) kernel on the four decoder shapes of the step, from the committed rocprofv3 --pmc
     passes (tools/pmc_gemm_sft.sh -> profiles/r03_pmc_gemm_sft.json; cannot be collected inside this process), next to the algorithmic bytes."""
-    tj = os.path.join(ROOT, "profiles", "r03_pmc_gemm_sft.json")
-    if not os.path.exists(tj):
+    name = next((n_ for n_ in ("r04_pmc_gemm_sft.json", "r03_pmc_gemm_sft.json") if os.path.exists(os.path.join(ROOT, "profiles", n_))), None)
+    if name is None:
         return None
+    tj = os.path.join(ROOT, "profiles", name)
     with open(tj) as f:
         d = json.load(f)
     return {"kernel": "gemm256_kernel<0,0,true,true,7,256> (wgrad, operands as they lie)",
             "per_gemm": {k: {"traffic_bytes": v.get("traffic_bytes"), "algorithmic_bytes": v.get("algorithmic_bytes"), "ratio": v.get("traffic_over_algorithmic")}
                          for k, v in d.items()},
-            "source": "profiles/r03_pmc_gemm_sft.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per shape, FETCH x2 on gfx950; L2 fills, i.e. incl. what the infinity cache serves)"}
+            "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per shape over tools/gemm_bench with the kernels and tile order of that round's "
+                      "final build, FETCH x2 on gfx950; L2 fills, i.e. incl. what the infinity cache serves)"}
 
 
 def sft_block(elapsed: float, steps: int, b: int, S: int, world: int, loss: float, tflop_per_sample: float = SFT_TFLOP_PER_SAMPLE):
@@ -593,8 +595,8 @@ def decode_main(a, rank, world, dev, dist):
     encode_ms = ev_a.elapsed_time(ev_b) / 3
     prefill_flops = vit_flops(cfg, n_tiles) + projector_flops(cfg, n_tiles) + llm_prefill_flops(cfg, S)
     pre_traffic = None          # L2-fill bytes of the prefill's dominant kernel (fused gate/up GEMM) from the committed --pmc passes of THIS command
-    tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if a.config == "nvila_8b" and not a.dynamic_s2 and os.path.exists(tj):
+    tj = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(p_)), None)
+    if a.config == "nvila_8b" and not a.dynamic_s2 and tj is not None:
         with open(tj) as f:
             pre_traffic = json.load(f).get("prefill_gateup")
     prefill = {"ttft_ms": round(ttft * 1e3, 3), "encode_images_ms": round(encode_ms, 3), "tflop": round(prefill_flops / 1e12, 3),
@@ -714,7 +716,7 @@ def decode_main(a, rank, world, dev, dist):
     # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
     # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic, traffic_src = None, None
-    for tj_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tj_name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tj = os.path.join(ROOT, "profiles", tj_name)
         if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
             with open(tj) as f:

@@ -28,6 +28,9 @@ void vila_gemm_force_ex(int mode);
 /* tile order of the 256-wide kernel (gemm256_kernel.h gemm256_tile_of): -1 = automatic (columns grouped by 4 when the grid has more than 16
  * row tiles), 0 = row-tile-fastest everywhere (rounds 1-2), n > 1 = groups of n columns */
 void vila_gemm_force_group(int grp);
+/* the K-sliced GEMMs' reduce takes the next block's LayerNorm / RMSNorm along (prefill down_proj -> next input_layernorm, tower fc2 -> next
+ * layer_norm1): 1 = on (default), 0 = separate norm launches (A/B and the parity test of the fused kernel); environment: VILA_FUSE_NORM */
+void vila_gemm_force_fuse_norm(int on);
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,35 @@ def test_decode_attention_over_256_key_slices_matches_the_single_block_kernel(mo
     assert torch.equal(idsg, idse)
 
 
+def test_norm_fused_into_the_splitk_reduce_equals_the_separate_launches():
+    """Round 4: where a prefill GEMM is K-sliced (LLM down_proj at 512+ rows, tower fc2 at one image) its reduce kernel also writes the NEXT
+    block's normalisation (gemm256.hip splitk_reduce_norm_kernel).  LLM: same per-element arithmetic and the same summation order as
+    norm_kernel<RMS> -> all-row logits BIT-equal with the fusion on and off.  Tower: the separate path uses the one-wave-per-row LayerNorm
+    (another fp32 summation order) -> features equal to bf16 rounding."""
+    from vila_amd import _lib
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    cfg = configs.reduced_8b(layers_v=3, layers_l=3, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    model = build_model(cfg, seed=13)
+    g = torch.Generator().manual_seed(13)
+    T = 640                                                        # >= 512 rows: down_proj (K = 18944) takes the split-K path
+    e = (torch.randn(T, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    pos = torch.arange(T, dtype=torch.int32, device="cuda")
+    px = synthetic.make_pixels(cfg, 1, 13).to(torch.bfloat16).cuda()
+    out = {}
+    try:
+        for on in (0, 1):
+            lib.vila_gemm_force_fuse_norm(on)
+            r = model.llm.prefill_packed(e, pos, None, T, want_all_logits=True, want_layer_hidden=True)
+            out[on] = (r.all_logits.clone(), r.layer_hidden.clone(), model.vision_tower(px).clone())
+    finally:
+        lib.vila_gemm_force_fuse_norm(1)
+    assert torch.equal(out[0][1], out[1][1]), "decoder hidden states differ with the fused RMSNorm"
+    assert torch.equal(out[0][0], out[1][0]), "logits differ with the fused RMSNorm"
+    assert rel_l2(out[1][2], out[0][2]) < 2e-3, f"tower features fused vs separate LayerNorm rel={rel_l2(out[1][2], out[0][2]):.3e}"
+
+
 def test_chained_decode_step_equals_the_plain_step():
     """The opt-in chained decode step (vila_decode_force_chain(1): kernels alternate over two streams, stream their weights while the predecessor
     finishes and wait on device-side arrival counts; api.hip — measured slower than the plain step and OFF by default, profiles/

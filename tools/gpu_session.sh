@@ -56,6 +56,9 @@ import json; d=json.loads(open('$O/chain_$1_$2.json').read().strip().splitlines(
              rm -f "$GRAFT_REPO_ROOT/gpurun_out/prof_chain/trace_results.db" ;;
   bpc2)      VILA_DECODE_CHAIN=0 VILA_GEMV_BPC=2 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 64 --warmup 8 > "$O/bpc2.json" 2> "$O/bpc2.err"; python -c "
 import json; d=json.loads(open('$O/bpc2.json').read().strip().splitlines()[-1]); print('chain=0 bpc=2: value', d['value'], 'ms/step', d['ms_per_step'], 'gateup us', d['roofline']['avg_launch_us'])" || tail -5 "$O/bpc2.err" ;;
+  fuse_ab)   for c in 0 1 0 1; do VILA_FUSE_NORM=$c timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/fuse_$c.json" 2> "$O/fuse_$c.err"; python -c "
+import json; d=json.loads(open('$O/fuse_$c.json').read().strip().splitlines()[-1]); print('fuse_norm=$c: ttft', d['ttft_ms'], 'encode', d['prefill']['encode_images_ms'], 'value', d['value'])" || tail -5 "$O/fuse_$c.err"; done ;;
+  fuse_tests) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_full_size.py tests/test_gpu_baseline_configs.py tests/test_video_encoders.py tests/test_dynamic_s2.py -m gpu -q -x 2>&1 | tail -8 ;;
   smoke)     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
   *) echo "unknown step $step" ;;
 esac

@@ -53,7 +53,11 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemv_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemm256_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
 done
+python tools/pmc_traffic_json.py "$O/val_pmc_hbm_counters.txt" "$O/val_pmc_traffic.json" r04 | cut -c1-200
 find "$O" -path "*pmc_val_*" -name "*.db" -delete
+# HBM traffic of the contraction-major (wgrad) GEMMs with THIS build's tile order (the round-3 json predated the 8 x 4 patches)
+timeout 900 bash tools/pmc_gemm_sft.sh 2>&1 | tail -6
+cp "$O/pmc_gemm_sft/summary.txt" "$O/val_pmc_gemm_sft.txt" 2>/dev/null; cp "$O/pmc_gemm_sft/summary.json" "$O/val_pmc_gemm_sft.json" 2>/dev/null
 timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tail -1
 cp "$O/pmc_mfma_val_sft/summary.txt" "$O/val_pmc_mfma_sft_step.txt" 2>/dev/null
 timeout 600 bash tools/pmc_mfma.sh val_ttft --no-sft --no-sustain --steps 8 --warmup 2 | tail -1

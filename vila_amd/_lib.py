@@ -129,6 +129,7 @@ PROTOTYPES = {
     "vila_gemm_force_bm": (None, [c_int]),
     "vila_gemm_force_ex": (None, [c_int]),
     "vila_gemm_force_group": (None, [c_int]),
+    "vila_gemm_force_fuse_norm": (None, [c_int]),
     "vila_decode_force_attn": (None, [c_int]),
     "vila_decode_force_chain": (None, [c_int]),
     "vila_llm_decode_chain_error": (c_int, [c_void_p, c_void_p]),

@@ -61,10 +61,13 @@ namespace {
 inline const bf16_t* B(const void* p) { return (const bf16_t*)p; }
 inline bf16_t* B(void* p) { return (bf16_t*)p; }
 
+// the NEXT block's normalisation, offered to a GEMM whose split-K reduce can take it along (kernels.h GemmArgs::norm_*)
+struct NextNorm { const void* w = nullptr; const void* b = nullptr; float eps = 0.f; int rms = 0; bf16_t* out = nullptr; int* done = nullptr; };
 int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const bf16_t* res, int64_t ldr,
          void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0,
-         float* ws = nullptr, size_t ws_bytes = 0, int res_mod = 0) {
+         float* ws = nullptr, size_t ws_bytes = 0, int res_mod = 0, const NextNorm* nn = nullptr) {
     GemmArgs g;
+    if (nn != nullptr) { g.norm_w = B(nn->w); g.norm_b = B(nn->b); g.norm_eps = nn->eps; g.norm_rms = nn->rms; g.norm_out = nn->out; g.norm_done = nn->done; }
     g.ws = ws; g.ws_bytes = ws_bytes; g.res_mod = res_mod;
     g.A = A; g.lda = lda; g.W = B(W); g.ldw = ldw; g.W2 = B(W2); g.bias = B(bias); g.residual = res; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.M = M; g.N = N; g.K = K; g.epi = epi;
@@ -119,10 +122,12 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
     bf16_t* x0 = (sh.n_layers_run == 0) ? B(out) : x;
     VILA_TRY(gemm(patches, Kp, wpad, Kp, w->patch_b, B(w->pos_emb), D, x0, D, M, D, Kp, EPI_NONE, s, nullptr, 0, nullptr, 0, N));
 
+    int ln1_done = 0;                                           // the previous layer's fc2 reduce already wrote layer_norm1(x) into h
     for (int l = 0; l < sh.n_layers_run; ++l) {
         const VilaVitLayer& L = w->layers[l];
         bf16_t* xo = (l == sh.n_layers_run - 1) ? B(out) : x;   // last layer writes straight into `out`
-        VILA_TRY(launch_layernorm(x, B(L.ln1_w), B(L.ln1_b), h, M, D, sh.ln_eps, s));
+        if (!ln1_done) VILA_TRY(launch_layernorm(x, B(L.ln1_w), B(L.ln1_b), h, M, D, sh.ln_eps, s));
+        ln1_done = 0;
         const bool fused = (B(L.wk) == B(L.wq) + (size_t)D * D) && (B(L.wv) == B(L.wk) + (size_t)D * D) &&
                            (B(L.bk) == B(L.bq) + D) && (B(L.bv) == B(L.bk) + D);
         if (fused) {
@@ -143,7 +148,10 @@ extern "C" int vila_vit_forward(const VilaVitWeights* w, const void* pixels, int
         VILA_TRY(gemm(h, D, L.wo, D, L.bo, x, D, x, D, M, D, D, EPI_NONE, s));               // x += out_proj(attn)
         VILA_TRY(launch_layernorm(x, B(L.ln2_w), B(L.ln2_b), h, M, D, sh.ln_eps, s));
         VILA_TRY(gemm(h, D, L.fc1_w, D, L.fc1_b, nullptr, 0, f, F, M, F, D, EPI_GELU_TANH, s));
-        VILA_TRY(gemm(f, F, L.fc2_w, F, L.fc2_b, x, D, xo, D, M, D, F, EPI_NONE, s, nullptr, 0, skws, sk_bytes));   // x += fc2(gelu(fc1))
+        // x += fc2(gelu(fc1)); where fc2 is K-sliced its reduce takes the NEXT layer's layer_norm1 along (h is free: fc1 has consumed it)
+        NextNorm nn;
+        if (l + 1 < sh.n_layers_run) { nn.w = w->layers[l + 1].ln1_w; nn.b = w->layers[l + 1].ln1_b; nn.eps = sh.ln_eps; nn.rms = 0; nn.out = h; nn.done = &ln1_done; }
+        VILA_TRY(gemm(f, F, L.fc2_w, F, L.fc2_b, x, D, xo, D, M, D, F, EPI_NONE, s, nullptr, 0, skws, sk_bytes, 0, l + 1 < sh.n_layers_run ? &nn : nullptr));
     }
     return 0;
 }
@@ -318,9 +326,11 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     const bool ex_rows = gemm256_tiles_m_of(T) < cdiv(T, 256);
     const int tail_rows = (!ex_rows && T > 256 && T % 256 >= 1 && T % 256 <= 4 && H % 8 == 0 && F % 8 == 0) ? T % 256 : 0;
     const int Tg = T - tail_rows;     // rows of the gate/up and down GEMMs; the rest via GEMV
+    int ln1_done = 0;                                           // the previous layer's down-proj reduce already wrote input_layernorm(x) into h
     for (int l = 0; l < sh.n_layers; ++l) {
         const VilaLlmLayer& L = w->layers[l];
-        VILA_TRY(launch_rmsnorm(x, B(L.ln1_w), h, T, H, sh.rms_eps, s));
+        if (!ln1_done) VILA_TRY(launch_rmsnorm(x, B(L.ln1_w), h, T, H, sh.rms_eps, s));
+        ln1_done = 0;
         const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
                            (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
         if (fused) {
@@ -378,7 +388,12 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
             g.x = h + (size_t)r * H; g.W = B(L.w_gate); g.W2 = B(L.w_up); g.y = act + (size_t)r * F; g.N = F; g.K = H; g.mode = 1;
             VILA_TRY(launch_gemv(g, s));
         }
-        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, Tg, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes));  // x += down(...)
+        // x += down(...); where the GEMM is K-sliced (S = 769: 56 tiles cannot fill the chip) its reduce takes the NEXT layer's input_layernorm
+        // along (h is free: gate/up has consumed it).  Only when every row goes through the GEMM (no GEMV tail rows).
+        NextNorm nn;
+        const bool offer = l + 1 < sh.n_layers && Tg == T;
+        if (offer) { nn.w = w->layers[l + 1].ln1_w; nn.eps = sh.rms_eps; nn.rms = 1; nn.out = h; nn.done = &ln1_done; }
+        VILA_TRY(gemm(act, F, L.w_down, F, nullptr, x, H, x, H, Tg, H, F, EPI_NONE, s, nullptr, 0, skws, skws_bytes, 0, offer ? &nn : nullptr));  // x += down(...)
         for (int r = Tg; r < T; ++r) {
             GemvArgs g{};
             g.x = act + (size_t)r * F; g.W = B(L.w_down); g.residual = x + (size_t)r * H; g.y = x + (size_t)r * H; g.N = H; g.K = F; g.mode = 0;

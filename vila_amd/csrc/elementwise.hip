@@ -3,18 +3,6 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// block reduce helpers (256 threads); scratch lives in the caller's dynamic LDS to keep a single LDS object
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* scratch) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
-
-// ------------------------------------------------------------------------------------------------
 // LayerNorm (SigLIP layer_norm1/2 eps 1e-6, modeling_siglip.py:723-725; projector nn.LayerNorm eps 1e-5,
 // base_projector.py:147): y = bf16((x-mean)*rstd*w + b), two-pass variance in fp32.  One block per row.
 // RMSNorm (Qwen2RMSNorm): y = bf16(w * bf16(x * rsqrt(mean(x^2)+eps)))  -- the double rounding is HF's.

@@ -68,6 +68,86 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
+// The same reduce with the NEXT block's normalisation fused in (round 4): one block per output row — sum the slices (+ bias + residual), store
+// the row (the residual stream, rounded to bf16 as the separate kernel does), then normalise those ROUNDED values (what a separate norm launch would
+// read back) and store norm_out.  Saves the norm launch and its read of the row: LayerNorm (RMS = false: (x - mean) * rstd * w + b, two-pass
+// variance) or Qwen2RMSNorm (w * bf16(x * rstd)); same per-element arithmetic as elementwise.hip norm_kernel, N % 8 == 0, N <= 16384.
+template <bool RMS>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ slab, int splits, int64_t slab_stride, const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int N, int res_mod,
+                                                                 const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps, bf16_t* __restrict__ nout) {
+    __shared__ float scratch[4];
+    const int m = blockIdx.x, tid = threadIdx.x, nch = N >> 3;
+    constexpr int MAXC = 8;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) {
+            const float* p = slab + (int64_t)m * N + c * 8;
+            f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+            for (int sl = 1; sl < splits; ++sl) {
+                const f32x4 a2 = *(const f32x4*)(p + sl * slab_stride), b2 = *(const f32x4*)(p + sl * slab_stride + 4);
+                a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3]; b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
+            }
+            float e[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if (bias != nullptr) {
+                const u32x4 bv = *(const u32x4*)(bias + c * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[2 * k] += lo_bf(bv[k]); e[2 * k + 1] += hi_bf(bv[k]); }
+            }
+            if (residual != nullptr) {
+                const u32x4 rv = *(const u32x4*)(residual + (int64_t)(res_mod > 0 ? m % res_mod : m) * ldr + c * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[2 * k] += lo_bf(rv[k]); e[2 * k + 1] += hi_bf(rv[k]); }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = pack2bf(e[2 * k], e[2 * k + 1]);
+                v[i][2 * k] = lo_bf(o[k]); v[i][2 * k + 1] = hi_bf(o[k]);          // the stored (rounded) values are what gets normalised
+                s += RMS ? (v[i][2 * k] * v[i][2 * k] + v[i][2 * k + 1] * v[i][2 * k + 1]) : (v[i][2 * k] + v[i][2 * k + 1]);
+            }
+            *(u32x4*)(out + (int64_t)m * ldc + c * 8) = o;
+        }
+    }
+    s = block_sum_256(s, scratch);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / N + eps);
+    } else {
+        mean = s / N;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (tid + 256 * i < nch) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+            }
+        q = block_sum_256(q, scratch);
+        rstd = rsqrtf(q / N + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) {
+            const u32x4 wv = *(const u32x4*)(nw + c * 8);
+            u32x4 bv = (u32x4){0u, 0u, 0u, 0u};
+            if (!RMS && nb != nullptr) bv = *(const u32x4*)(nb + c * 8);
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = v[i][2 * k], bb = v[i][2 * k + 1];
+                if (RMS) { a = lo_bf(wv[k]) * bfround(a * rstd); bb = hi_bf(wv[k]) * bfround(bb * rstd); }
+                else { a = (a - mean) * rstd * lo_bf(wv[k]) + lo_bf(bv[k]); bb = (bb - mean) * rstd * hi_bf(wv[k]) + hi_bf(bv[k]); }
+                o[k] = pack2bf(a, bb);
+            }
+            *(u32x4*)(nout + (int64_t)m * N + c * 8) = o;
+        }
+    }
+}
+
 // tail tiles behind whole rounds: out tile (tm, tn) = bf16(sum_s slab[s][t][256][256] + bias + residual); slab slot t holds tile id tile0 + t
 // of the GEMM's tile order (the kernel indexes its slab by id - tile0, after its own XCD remap)
 __global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(const float* __restrict__ slab, int splits, int n_tail, int tile0, int tiles_m, int tiles_n, int grp,
@@ -209,6 +289,13 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s) {
     VILA_FAIL(-1, "gemm256: unsupported epilogue %d", a.epi);
 }
 
+// VILA_FUSE_NORM=0: the reduce never takes the next block's normalisation along (A/B switch)
+static int g_fuse_norm = -1;
+extern "C" void vila_gemm_force_fuse_norm(int on) { g_fuse_norm = on ? 1 : 0; }
+static bool fused_norm_enabled() {
+    if (g_fuse_norm < 0) { const char* e = getenv("VILA_FUSE_NORM"); g_fuse_norm = (e && e[0] == '0') ? 0 : 1; }
+    return g_fuse_norm != 0;
+}
 // split-K: C = sum over `splits` K-slices; `slab` = splits * M * N fp32 workspace owned by the caller
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s) {
     const int kt = cdiv(a.K, T256_BK), per = cdiv(kt, splits);
@@ -218,6 +305,16 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
     if (a.a_cm || a.b_cm) VILA_TRY(launch_gemm256_cm_splitk(b, splits, slab, per, s));
     else VILA_TRY((launch256_fwd<3, EPI_NONE>(b, s, gemm256_ex_rows(a.M) != 0, splits, 0, -1, 0, per)));      // the last slice takes the remainder
+    if (a.norm_out != nullptr && a.norm_w != nullptr && a.N % 8 == 0 && a.N <= 16384 && fused_norm_enabled()) {
+        // the reduce holds whole rows: the next block's LayerNorm / RMSNorm rides along (one launch and one read of the row less)
+        if (a.norm_rms) hipLaunchKernelGGL(splitk_reduce_norm_kernel<true>, dim3(a.M), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
+                                           (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
+        else hipLaunchKernelGGL(splitk_reduce_norm_kernel<false>, dim3(a.M), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
+                                (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
+        VILA_LAUNCH_CHECK();
+        if (a.norm_done != nullptr) *a.norm_done = 1;
+        return 0;
+    }
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,

@@ -22,6 +22,10 @@ struct GemmArgs {
     // operand storage (gemm256_kernel.h): 0 = contraction-contiguous X[rows][K] (forward layout), 1 = contraction-major X[K][rows]
     // (dgrad reads W[N,K] with b_cm; wgrad reads dY[T,N] and X[T,K] with a_cm and b_cm); lda / ldw are the STORED leading dimensions
     int a_cm = 0, b_cm = 0;
+    // optional fused follow-up normalisation of the OUTPUT rows (the next block's LayerNorm / RMSNorm): honoured only where the launcher takes
+    // the split-K path (its reduce kernel holds whole rows) — then *norm_done = 1 and norm_out[M][N] = norm(C) with C as it was just stored
+    const bf16_t* norm_w = nullptr; const bf16_t* norm_b = nullptr; float norm_eps = 0.f; int norm_rms = 0;
+    bf16_t* norm_out = nullptr; int* norm_done = nullptr;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
