@@ -3,13 +3,20 @@
 # kernel traces and the TTFT timeline.  Run on the GPU box from the repo root (gpurun -- bash tools/validate_gpu.sh); results under gpurun_out/.
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p "$O"
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > "$O/val_pytest.log"
+timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -25 > "$O/val_pytest.log"
 tail -3 "$O/val_pytest.log"
 for i in 1 2; do
   timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_$i.err" | tee "$O/val_sft_$i.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
 done
 VILA_SFT_C_ABI=1 timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_c.err" | tee "$O/val_sft_c.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft c-abi ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
 VILA_BENCH_FORCE_DIST=1 timeout 300 python bench.py --mode sft --steps 3 --warmup 1 2>"$O/val_sft_forcedist.err" | tee "$O/val_sft_forcedist.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[0]); print('sft force-dist (nccl, world 1) ->', d['ms_per_step'], 'ms')"
+# the default line with the process group forced up in a world of one: the SFT side measurement takes the RCCL path the driver's --gpus N takes
+VILA_BENCH_FORCE_DIST=1 timeout 400 python bench.py --no-sustain --no-cpu-baseline --steps 16 --warmup 4 2>"$O/val_bench_forcedist.err" | tail -1 > "$O/val_bench_forcedist.json"
+python -c "
+import json
+d = json.loads(open('gpurun_out/val_bench_forcedist.json').read()); s = d.get('sft') or {}
+print('bench (forced nccl group, world 1): value', d['value'], '| sft', s.get('ms_per_step'), 'ms, exchange_active', s.get('exchange_active'), 'bytes', s.get('exchange_bytes'), s.get('error'))
+"
 timeout 600 python bench.py > "$O/val_bench.json" 2> "$O/val_bench.err"
 python - <<'P'
 import json
