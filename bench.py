@@ -85,6 +85,30 @@ def self_launch(a, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """fd 1 -> stderr for the duration, INCLUDING what C code wrote with stdio: RCCL prints its banner with printf; with stdout a pipe the text sits
+    in libc's buffer and would be flushed at process exit — behind the JSON line, on the restored fd 1 (seen on hardware in round 4: five banner
+    lines after the line).  So libc's buffers are flushed before fd 1 is restored."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_dist(backend: str, dev=None):
     """Process group from the torchrun environment.  RCCL prints a version banner on STDOUT when the communicator is created;
     stdout must carry the one JSON line only, so fd 1 points at stderr while the group and its first collective come up."""
@@ -93,10 +117,7 @@ def init_dist(backend: str, dev=None):
         os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with stdout_to_stderr():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -104,10 +125,6 @@ def init_dist(backend: str, dev=None):
         dist.barrier()
         if backend == "nccl":
             torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
     return dist
 
 

@@ -62,3 +62,15 @@ def test_sft_mode_dry_run_on_two_ranks():
     assert out["n_gpus"] == 2 and c["group_world_size"] == 2 and c["mode"] == "sft dry run"
     assert c["global_num_items"] == 100 + 101 and c["exchange_ok"] is True and c["buckets"] >= 8
     assert "world=2" in c["grad_exchange"]
+
+
+def test_stdout_redirect_also_catches_c_stdio_writes():
+    """RCCL's version banner is written with C stdio while the communicator comes up; buffered, it used to surface at process exit BEHIND the JSON
+    line (round 4, on hardware).  bench.stdout_to_stderr must flush libc's buffers before it restores fd 1: stdout then carries the line only."""
+    code = ("import sys, ctypes; sys.path.insert(0, %r); import bench\n"
+            "with bench.stdout_to_stderr():\n"
+            "    ctypes.CDLL(None).printf(b'BANNER via C stdio\\n')\n"
+            "print('{\"ok\": 1}')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip() == '{"ok": 1}' and "BANNER via C stdio" in r.stderr
