@@ -481,7 +481,7 @@ extern "C" int vila_sample_f32(const float* logits, int n, const VilaSampling* s
 // Two streams X / Y swap roles every layer:  X: A B C . E        Y: (event: B done) D . A' B' C' . E'      X: (event: B' done) D' ...
 // so a chained kernel is launched when the kernel TWO before it has finished (stream order) and at most two kernels are in flight.
 // Why it cannot deadlock (a waiting kernel must never keep the kernel it waits for off the chip): every chained kernel and the kernel it
-// waits for are launched with <= 2 blocks per CU and <= 128 VGPRs — half a CU each — so both are entirely resident whatever the dispatch order;
+// waits for are launched with <= 2 blocks per CU and <= 136 VGPRs — about half a CU each — so both are entirely resident whatever the dispatch order;
 // the attention kernel (16-wave blocks that need a whole CU) is never beside a waiting kernel: D is held back by an event until B has finished.
 // The waits are bounded all the same: a give-up is reported in workspace word 0 (vila_llm_decode_chain_error) instead of hanging the device.
 // MEASURED (profiles/r04_decode_chain_ab.log, five sessions): 3.28 ms per token chained against 2.99 plain — the device-side hand-off costs what a

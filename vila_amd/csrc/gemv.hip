@@ -122,44 +122,42 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
         }
     };
-    // Epilogue: after the wave reduction every lane holds the sums; LANE 0 produces the wave's two adjacent outputs (rows n, n + 1) and
-    // stores them as ONE 4-byte word — write-through (sc1) when a chained successor reads them (gemv_common.h).
+    // Epilogue: after the wave reduction every lane holds the sums; lanes 0 and 1 each produce one of the wave's two adjacent outputs (rows n, n + 1).
+    // Plain launch: each stores its own bf16.  Chained launch (a successor reads the output while this kernel's neighbours still run): lane 0
+    // stores both as ONE write-through 4-byte word (gemv_common.h store_bf16_pair).
     const bool coh_out = p.chain.ctr != nullptr && p.chain.done_idx >= 0;
-    float e_b0 = 0.f, e_b1 = 0.f, e_r0 = 0.f, e_r1 = 0.f;
+    float e_bias = 0.f, e_res = 0.f;
     auto finish = [&](int gg, float (&acc)[R]) {
         const int n = gg * 2;
-        if (lane != 0 || n >= p.N) return;
-        const bool two = n + 1 < p.N;
+        bf16_t o = 0;
         if constexpr (MODE == 1) {
             // HF: down(act(gate(x)) * up(x)) with every tensor rounded to bf16
-            const bf16_t o0 = f2bf(bfround(silu_f(bfround(acc[0]))) * bfround(acc[1]));
-            const bf16_t o1 = f2bf(bfround(silu_f(bfround(acc[2]))) * bfround(acc[3]));
-            store_bf16_pair(p.y, n, two, o0, o1, coh_out);
+            const float gv = bfround(lane == 0 ? acc[0] : acc[2]), uv = bfround(lane == 0 ? acc[1] : acc[3]);
+            o = f2bf(bfround(silu_f(gv)) * uv);
         } else {
-            float v0 = acc[0] + e_b0, v1 = acc[1] + e_b1;
-            if (p.y_f32 != nullptr) { p.y_f32[n] = v0; if (two) p.y_f32[n + 1] = v1; }
-            if (p.y != nullptr) {
-                if (p.residual != nullptr) { v0 = bfround(v0) + e_r0; v1 = bfround(v1) + e_r1; }
-                store_bf16_pair(p.y, n, two, f2bf(v0), f2bf(v1), coh_out);
-            }
+            float v = lane == 0 ? acc[0] : acc[1];
+            v += e_bias;
+            if (lane < 2 && n + lane < p.N && p.y_f32 != nullptr) p.y_f32[n + lane] = v;
+            if (p.residual != nullptr) v = bfround(v) + e_res;
+            o = f2bf(v);
+        }
+        if (p.y == nullptr) return;
+        if (coh_out) {
+            const bf16_t o1 = (bf16_t)__shfl((int)o, 1, 64);
+            if (lane == 0 && n < p.N) store_bf16_pair(p.y, n, n + 1 < p.N, o, o1, true);
+        } else if (lane < 2 && n + lane < p.N) {
+            p.y[n + lane] = o;
         }
     };
     // the epilogue's operands are requested BEFORE the dot product: fetched after the reduction they add a dependent memory round
     // trip (~1 us) to the tail of every wave, i.e. to the kernel
     auto epi_fetch = [&](int gg) {
         if constexpr (MODE != 1) {
-            const int n = gg * 2;
-            e_b0 = 0.f; e_b1 = 0.f; e_r0 = 0.f; e_r1 = 0.f;
-            if (lane == 0 && n < p.N) {
-                const bool two = n + 1 < p.N;
-                if (p.bias != nullptr) {
-                    if (two) { const uint32_t b = *(const uint32_t*)(p.bias + n); e_b0 = lo_bf(b); e_b1 = hi_bf(b); }
-                    else e_b0 = bf2f(p.bias[n]);
-                }
-                if (p.residual != nullptr && p.y != nullptr) {
-                    if (two) { const uint32_t r = *(const uint32_t*)(p.residual + n); e_r0 = lo_bf(r); e_r1 = hi_bf(r); }
-                    else e_r0 = bf2f(p.residual[n]);
-                }
+            const int nn = gg * 2 + lane;
+            e_bias = 0.f; e_res = 0.f;
+            if (lane < 2 && nn < p.N) {
+                if (p.bias != nullptr) e_bias = bf2f(p.bias[nn]);
+                if (p.residual != nullptr && p.y != nullptr) e_res = bf2f(p.residual[nn]);
             }
         }
     };
@@ -257,10 +255,8 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
 // Group = 2 rows per wave: q/k heads -> the rotate-half pair {d, d+hd/2} of one head, v heads -> 2 consecutive rows.  cos/sin of the token's position come from the per-token table written by
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
-// (<= 128 VGPRs — amdgpu_waves_per_eu(4) — so that a block is exactly a quarter of a CU like the other chained kernels' blocks: any mix of them
-// packs without fragmentation, see api.hip "chained decode step")
 template <int U>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void qkv_decode_kernel(QkvDecodeArgs p) {
+__global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));

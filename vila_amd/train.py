@@ -830,10 +830,22 @@ class SFTTrainer:
         self._media_elsewhere = any_media and not has_media
         return any_media
 
+    def _global_counts(self, n_local: int, has_media: bool) -> int:
+        """`global_num_items` and `agree_on_media` as ONE all-reduce (SUM of [targets, has-media flag]): a step pays one tiny collective and one
+        host sync for both agreements."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            t = torch.tensor([n_local, 1 if has_media else 0], device=self.model.device, dtype=torch.int64)
+            dist.all_reduce(t, group=self.group)
+            n_global, any_media = int(t[0].item()), bool(int(t[1].item()))
+        else:
+            n_global, any_media = n_local, bool(has_media)
+        self._media_elsewhere = any_media and not has_media
+        return n_global
+
     def step(self, input_ids, images, labels, attention_mask=None, block_sizes=None) -> float:
         n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
-        n_global = self.global_num_items(n_local)
-        self.agree_on_media(len(images) > 0)
+        n_global = self._global_counts(n_local, len(images) > 0)
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
         try:
