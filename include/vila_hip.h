@@ -158,9 +158,10 @@ size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx);
 int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx);
 int vila_llm_decode_step(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st,
                          void* workspace, size_t workspace_bytes, vila_stream_t stream);
-/* The step's kernels are chained (each starts streaming its weights while its predecessor finishes and waits on a device counter before it
- * reads an activation).  The waits are bounded; word 0 of the workspace is set if one gave up — the caller zeroes the first 256 bytes of a new
- * workspace once, and may ask here (synchronises `stream`, returns the word and clears it): 0 = every token so far is valid. */
+/* Word 0 of the decode workspace is an error flag: the caller zeroes the first 256 bytes of a new workspace once.  Only the opt-in CHAINED
+ * step writes it (vila_hip_tuning.h vila_decode_force_chain / VILA_DECODE_CHAIN=1: each kernel starts streaming its weights while its predecessor
+ * finishes and waits on a device-side arrival count before it reads an activation; the waits are bounded and a give-up sets the word — measured
+ * slower than the plain step and off by default).  This call synchronises `stream`, returns the word and clears it: 0 = every token so far is valid. */
 int vila_llm_decode_chain_error(void* workspace, vila_stream_t stream);
 
 /* generate(do_sample=True): what HF GenerationMixin.sample does after the forward — logits / temperature -> TopK -> TopP -> softmax ->

@@ -68,7 +68,8 @@ def weight_checksum(w):
     return acc
 
 
-def run_vision(cfg, w, pixels):
+def run_vision(cfg, w, pixels, timing=None):
+    """timing (optional dict): receives `forward_s`, the seconds of the reference module's forward alone (not its construction / weight load)."""
     ms = ref_siglip()
     v = cfg.vision
     hf_cfg = ms.SiglipVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
@@ -82,8 +83,12 @@ def run_vision(cfg, w, pixels):
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all(m.startswith("vision_model.head.") for m in missing), missing  # pooling head unused by VILA
+    import time
+    t0 = time.time()
     with torch.no_grad():
         out = model(pixels, output_hidden_states=True)
+    if timing is not None:
+        timing["forward_s"] = time.time() - t0
     return [h.clone() for h in out.hidden_states]
 
 
