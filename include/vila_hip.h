@@ -337,7 +337,9 @@ int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, 
  * dynamic_s2 multi-scale path — replaces merge_features_for_dynamic_s2 + split_chessboard +
  * rearrange of LlavaMetaModel.encode_images (llava/model/llava_arch.py:298-379):
  *   feats [n_tiles, g*g, C] (tower output for every tile of every image, scales in ascending order per image)
- *   desc  device [n_blocks][6] = {first tile of the image, bh, bw, block row i, block col j, single (block_sizes None)}
+ *   desc  device [n_blocks][6] = {first tile of the image, bh | obh << 16, bw | obw << 16, block row i, block col j, single (block_sizes None)}
+ *         bh x bw = tiles of the image's last scale; obh x obw = its OUTPUT blocks: 0 in the high halves = the same grid
+ *         (s2_resize_output_to_scale_idx = -1, every shipped recipe); s x s for an earlier scale of s x s tiles (llava_arch.py:340-358)
  *   out   [n_blocks, g*g, n_scales*C] = the projector input.  splits[k] = scales[k] / scales[0] for k < n_scales-1 [host].
  * ------------------------------------------------------------------------------------------------------------ */
 int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,
@@ -345,7 +347,7 @@ int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_
 /* Backward of the above for the SFT step of the dynamic_s2 recipe (autograd through llava_arch.py:298-379: F.interpolate(mode="area")
  * backward = dy / |window| broadcast into each scale's chessboard, merge / split_chessboard adjoints), as one gather:
  *   dy [n_blocks, g*g, n_scales*C] -> dx [n_tiles, g*g, C] (every element written, no accumulation)
- *   tile_desc device [n_tiles][8] = {first output block of the tile's image, bh, bw, scale index, tile row, tile col, single, 0} */
+ *   tile_desc device [n_tiles][8] = {first output block of the tile's image, bh | obh << 16, bw | obw << 16, scale index, tile row, tile col, single, 0} */
 int vila_s2_merge_bwd_bf16(const void* dy, void* dx, const int32_t* tile_desc, int n_tiles, int grid, int channels, int n_scales,
                            const int32_t* splits, vila_stream_t stream);
 

@@ -82,6 +82,18 @@ def main():
     pin, _, _ = ref_encode_s2(ns, t, [(3, 3), None], (8, 16, 24), -1, lambda x: x[:, :1])
     fx["int_tiles"] = t.numpy()
     fx["int_proj_in"] = pin.numpy()
+    # round 4: s2_resize_output_to_scale_idx other than the last scale (llava_arch.py:340-358: every scale is area-interpolated to THAT scale's
+    # grid and the image's blocks become s x s): the same integer tiles with the output at scale 0 (1 x 1 block) and scale 1 (2 x 2 blocks)
+    for r in (0, 1):
+        pin_r, _, nbs_r = ref_encode_s2(ns, t, [(3, 3), None], (8, 16, 24), r, lambda x: x[:, :1])
+        fx[f"int_proj_in_r{r}"] = pin_r.numpy()
+        fx[f"int_new_block_sizes_r{r}"] = np.array(nbs_r)
+    # and a non-square last scale (2 x 3 tiles) pooled DOWN to the middle scale's 2 x 2 blocks
+    t2 = (torch.arange(12 * g * g * 2, dtype=torch.float32).reshape(12, g * g, 2) % 53) - 26
+    pin_m, _, nbs_m = ref_encode_s2(ns, t2, [(2, 3), None], (8, 16, 24), 1, lambda x: x[:, :1])
+    fx["int_tiles_23"] = t2.numpy()
+    fx["int_proj_in_23_r1"] = pin_m.numpy()
+    fx["int_new_block_sizes_23_r1"] = np.array(nbs_m)
     path = os.path.join(ROOT, "tests", "golden", "dynamic_s2.npz")
     np.savez_compressed(path, **fx)
     print("wrote", path, {k: v.shape for k, v in fx.items() if hasattr(v, "shape")})

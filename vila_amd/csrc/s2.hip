@@ -1,7 +1,9 @@
 // dynamic_s2 feature merge: everything the reference does between the vision tower and the projector
 // in the dynamic_s2 branch of encode_images (llava/model/llava_arch.py:298-379) as ONE gather kernel:
-//   merge_chessboard per scale  ->  F.interpolate(mode="area", fp32) to the last scale's grid  ->  channel concat  ->
-//   split_chessboard into the image's bh x bw blocks  ->  "b c h w -> b (h w) c"
+//   merge_chessboard per scale  ->  F.interpolate(mode="area", fp32) to the grid of scale `resize_output_to_scale_idx` (the last scale's in
+//   every shipped recipe; any scale since round 4)  ->  channel concat  ->  split_chessboard into the image's obh x obw OUTPUT blocks
+//   (= bh x bw when the output grid is the last scale's, s x s for an earlier scale of s x s tiles)  ->  "b c h w -> b (h w) c"
+// Descriptor words 1 / 2 carry bh | obh << 16 and bw | obw << 16 (obh = 0: the output grid is the last scale's — what rounds 1-3 wrote).
 // For output block (i, j), position (y, x), scale k the value is the fp32 mean over the adaptive-average-pool window
 //   rows [floor(Y*Hk/H), ceil((Y+1)*Hk/H)),  cols [floor(X*Wk/W), ceil((X+1)*Wk/W)),   Y = i*g + y, X = j*g + x
 // of the scale-k chessboard, whose pixel (yy, xx) is token (yy%g)*g + xx%g of tile (yy/g)*splits + xx/g.  HBM-bound gather.
@@ -25,7 +27,8 @@ __global__ void s2_merge_kernel(S2Args p) {
         const int pos = (int)(r % N); r /= N;
         const int b = (int)r;
         const int32_t* d = p.desc + b * 6;
-        const int base = d[0], bh = d[1], bw = d[2], bi = d[3], bj = d[4], single = d[5];
+        const int base = d[0], bh = d[1] & 0xffff, bw = d[2] & 0xffff, bi = d[3], bj = d[4], single = d[5];
+        const int obh = (d[1] >> 16) ? (d[1] >> 16) : bh, obw = (d[2] >> 16) ? (d[2] >> 16) : bw;
         const int y = pos / g, x = pos % g;
         float acc[8];
 #pragma unroll
@@ -37,7 +40,7 @@ __global__ void s2_merge_kernel(S2Args p) {
             int tile0 = base, sh, sw;
             for (int m = 0; m < k; ++m) tile0 += p.splits[m] * p.splits[m];
             if (k < ns - 1) { sh = sw = p.splits[k]; } else { sh = bh; sw = bw; }
-            const int Hout = g * bh, Wout = g * bw, Hk = g * sh, Wk = g * sw;
+            const int Hout = g * obh, Wout = g * obw, Hk = g * sh, Wk = g * sw;
             const int Y = bi * g + y, X = bj * g + x;
             const int ys = (Y * Hk) / Hout, ye = ((Y + 1) * Hk + Hout - 1) / Hout;
             const int xs = (X * Wk) / Wout, xe = ((X + 1) * Wk + Wout - 1) / Wout;
@@ -95,7 +98,8 @@ __global__ void s2_merge_bwd_kernel(S2BwdArgs p) {
         const int tok = (int)(r % N); r /= N;
         const int tile = (int)r;
         const int32_t* d = p.tdesc + tile * 8;
-        const int blk0 = d[0], bh = d[1], bw = d[2], k = d[3], ti = d[4], tj = d[5], single = d[6];
+        const int blk0 = d[0], bh = d[1] & 0xffff, bw = d[2] & 0xffff, k = d[3], ti = d[4], tj = d[5], single = d[6];
+        const int obh = (d[1] >> 16) ? (d[1] >> 16) : bh, obw = (d[2] >> 16) ? (d[2] >> 16) : bw;      // output block grid of the image
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -108,7 +112,7 @@ __global__ void s2_merge_bwd_kernel(S2BwdArgs p) {
         } else {
             int sh, sw;
             if (k < ns - 1) { sh = sw = p.splits[k]; } else { sh = bh; sw = bw; }
-            const int Hout = g * bh, Wout = g * bw, Hk = g * sh, Wk = g * sw;
+            const int Hout = g * obh, Wout = g * obw, Hk = g * sh, Wk = g * sw;
             const int yy = ti * g + tok / g, xx = tj * g + tok % g;
             const int Y0 = (yy * Hout) / Hk, Y1 = ((yy + 1) * Hout + Hk - 1) / Hk - 1;
             const int X0 = (xx * Wout) / Wk, X1 = ((xx + 1) * Wout + Wk - 1) / Wk - 1;
@@ -117,7 +121,7 @@ __global__ void s2_merge_bwd_kernel(S2BwdArgs p) {
                 for (int X = X0; X <= X1; ++X) {
                     const int xs = (X * Wk) / Wout, xe = ((X + 1) * Wk + Wout - 1) / Wout;
                     const float wgt = 1.f / (float)((ye - ys) * (xe - xs));
-                    const int b = blk0 + (Y / g) * bw + (X / g);
+                    const int b = blk0 + (Y / g) * obw + (X / g);
                     const int pos = (Y % g) * g + (X % g);
                     const u32x4 v = *(const u32x4*)(p.dy + ((int64_t)b * N + pos) * ostr + (int64_t)k * p.C + ch * 8);
 #pragma unroll

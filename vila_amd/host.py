@@ -111,48 +111,58 @@ def repack(attention_mask: torch.Tensor, labels: torch.Tensor) -> SimpleNamespac
                            max_seqlen=int(seqlens.max()) if B else 0, seq_of_tok=seq_id.to(torch.int32))
 
 
-def s2_plan(block_sizes, scales, grid: int, downsample: int):
-    """Host plan of the dynamic_s2 branch of encode_images (llava/model/llava_arch.py:298-390) for
-    s2_resize_output_to_scale_idx = -1 (the NVILA recipe, scripts/NVILA/stage1_9tile.sh:22):
-      desc      [n_blocks, 6] i32  {first tile of the image, bh, bw, block row, block col, single}  for vila_s2_merge_bf16
+def s2_plan(block_sizes, scales, grid: int, downsample: int, resize_idx: int = -1):
+    """Host plan of the dynamic_s2 branch of encode_images (llava/model/llava_arch.py:298-390).  `resize_idx` =
+    s2_resize_output_to_scale_idx: the scale whose grid every scale is area-interpolated to (-1 / last = the NVILA recipe,
+    scripts/NVILA/stage1_9tile.sh:22; an earlier scale of s x s tiles gives every image s x s output blocks, :346-358).
+      desc      [n_blocks, 6] i32  {first tile of the image, bh | obh << 16, bw | obw << 16, block row, block col, single}  for vila_s2_merge_bf16
+                (bh x bw = tiles of the image's last scale, obh x obw = its OUTPUT blocks; the high halves are 0 when they are equal)
       n_tiles   total tiles the tower must have produced (checked like the reference's assert, :360-362)
-      tile_desc [n_tiles, 8] i32   {first output block of the tile's image, bh, bw, scale index, tile row, tile col, single, 0}  for the
-                backward (vila_s2_merge_bwd_bf16)
-      perm      per image: for every output token (h w order over the merged (g' bh) x (g' bw) grid, :386-389) its row in the
+      tile_desc [n_tiles, 8] i32   {first output block of the tile's image, bh | obh << 16, bw | obw << 16, scale index, tile row, tile col,
+                single, 0}  for the backward (vila_s2_merge_bwd_bf16)
+      perm      per image: for every output token (h w order over the merged (g' obh) x (g' obw) grid, :386-389) its row in the
                 projector output [n_blocks * g'^2]   (merge_chessboard + "1 c h w -> (h w) c" as one row gather)
+      block_sizes_out  per image (obh, obw) — the reference's `new_block_sizes`
     """
+    n_scales = len(scales)
+    r = resize_idx % n_scales
     splits = [s // scales[0] for s in scales[:-1]]
     n_pre = sum(s * s for s in splits)
     gd = (grid + downsample - 1) // downsample
-    desc, tdesc, perms, base, blk = [], [], [], 0, 0
+    desc, tdesc, perms, out_bs, base, blk = [], [], [], [], 0, 0
     for bs in block_sizes:
         if bs is None:
             desc.append([base, 1, 1, 0, 0, 1])
             tdesc.append([blk, 1, 1, 0, 0, 0, 1, 0])
             perms.append(torch.arange(blk * gd * gd, (blk + 1) * gd * gd, dtype=torch.int32))
+            out_bs.append((1, 1))
             base += 1
             blk += 1
             continue
         bh, bw = int(bs[0]), int(bs[1])
-        for i in range(bh):
-            for j in range(bw):
-                desc.append([base, bh, bw, i, j, 0])
+        obh, obw = (bh, bw) if r == n_scales - 1 else (splits[r], splits[r])
+        w1 = bh | ((obh << 16) if (obh, obw) != (bh, bw) else 0)
+        w2 = bw | ((obw << 16) if (obh, obw) != (bh, bw) else 0)
+        for i in range(obh):
+            for j in range(obw):
+                desc.append([base, w1, w2, i, j, 0])
         # tiles of the image in tower order: scales ascending, each scale's chessboard row-major (merge_chessboard, llava_arch.py:255-275)
         for k, sp in enumerate(splits):
             for i in range(sp):
                 for j in range(sp):
-                    tdesc.append([blk, bh, bw, k, i, j, 0, 0])
+                    tdesc.append([blk, w1, w2, k, i, j, 0, 0])
         for i in range(bh):
             for j in range(bw):
-                tdesc.append([blk, bh, bw, len(splits), i, j, 0, 0])
-        Y = torch.arange(gd * bh)[:, None]
-        X = torch.arange(gd * bw)[None, :]
-        src = (blk + (Y // gd) * bw + (X // gd)) * gd * gd + (Y % gd) * gd + (X % gd)
+                tdesc.append([blk, w1, w2, len(splits), i, j, 0, 0])
+        Y = torch.arange(gd * obh)[:, None]
+        X = torch.arange(gd * obw)[None, :]
+        src = (blk + (Y // gd) * obw + (X // gd)) * gd * gd + (Y % gd) * gd + (X % gd)
         perms.append(src.reshape(-1).to(torch.int32))
+        out_bs.append((obh, obw))
         base += n_pre + bh * bw
-        blk += bh * bw
+        blk += obh * obw
     return SimpleNamespace(desc=torch.tensor(desc, dtype=torch.int32), tile_desc=torch.tensor(tdesc, dtype=torch.int32), n_tiles=base,
-                           n_blocks=blk, perms=perms, splits=splits)
+                           n_blocks=blk, perms=perms, splits=splits, block_sizes_out=out_bs)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -498,11 +498,9 @@ class SFTTrainer:
         if not getattr(cfg, "dynamic_s2", False):
             return None, [torch.arange(i * Tm, (i + 1) * Tm, dtype=torch.int64) for i in range(n_px)], n_px
         from .host import s2_plan
-        if cfg.s2_resize_output_to_scale_idx not in (-1, len(cfg.s2_scales) - 1):
-            raise NotImplementedError("dynamic_s2: only s2_resize_output_to_scale_idx = -1 (the NVILA recipe) is implemented")
         if block_sizes is None:
             raise ValueError("dynamic_s2 training needs media_config['image']['block_sizes'] (one (h, w) or None per image)")
-        plan = s2_plan(list(block_sizes), list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+        plan = s2_plan(list(block_sizes), list(cfg.s2_scales), cfg.vision.grid, cfg.downsample, cfg.s2_resize_output_to_scale_idx)
         if plan.n_tiles != n_px:
             raise AssertionError(f"The number of blocks ({plan.n_tiles}) does not match length of image_features ({n_px})!")
         return plan, [p.long() for p in plan.perms], plan.n_blocks

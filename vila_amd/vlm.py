@@ -173,11 +173,9 @@ class HipLlavaLlamaModel(nn.Module):
         # dynamic_s2 (llava_arch.py:369-390): tower on every tile of every scale, one merge kernel, projector on the
         # C*n_scales-wide blocks, chessboard re-merge of the projected blocks as a row gather
         cfg = self.cfg
-        if cfg.s2_resize_output_to_scale_idx not in (-1, len(cfg.s2_scales) - 1):
-            raise NotImplementedError("dynamic_s2: only s2_resize_output_to_scale_idx = -1 (the NVILA recipe) is implemented")
         if block_sizes is None:
             block_sizes = [None] * len(images)
-        plan = s2_plan(block_sizes, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample)
+        plan = s2_plan(block_sizes, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample, cfg.s2_resize_output_to_scale_idx)
         feats = self.get_vision_tower()(images)
         if plan.n_tiles != feats.shape[0]:
             raise AssertionError(f"The number of blocks ({plan.n_tiles}) does not match length of image_features ({feats.shape[0]})!")
