@@ -485,7 +485,7 @@ def vlm_generate(pixels_list, input_ids, w, cfg, max_new_tokens: int, **kw):
     return greedy_generate(e, w, cfg, max_new_tokens, **kw)
 
 
-def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True, block_sizes=None):
+def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True, block_sizes=None, videos=None):
     """Training forward of llava_llama.py:94-159 (packing branch): _embed -> repack -> llm(..., labels).
     dynamic_s2 (cfg.dynamic_s2, llava_arch.py:369-390): pixels_list = the tiles of every scale of every image, block_sizes = one entry per
     image (media_config["image"]["block_sizes"]); BasicImageEncoder appends the "\n" embedding to each IMAGE's merged tokens."""
@@ -495,6 +495,8 @@ def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_ite
         media = [torch.cat([f, end], 0) for f in feats]
     else:
         media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
+    if videos:                                                # BasicVideoEncoder (encoders/video/basic.py:43-53): one block per <vila/video> token
+        media = {"image": media, "video": basic_video_encoder(videos, w, cfg)}
     e, l, m = embed_splice(input_ids, media, w, cfg, labels=labels, attention_mask=attention_mask)
     if packed:
         pe, pm, pp, pl, seqlens = repack(e, m, l)

@@ -505,6 +505,40 @@ class SFTTrainer:
             raise AssertionError(f"The number of blocks ({plan.n_tiles}) does not match length of image_features ({n_px})!")
         return plan, [p.long() for p in plan.perms], plan.n_blocks
 
+    def _with_videos(self, images, videos):
+        """`videos` (list of [n_frames, 3, H, W], each standing for one <vila/video> token) under the BasicVideoEncoder (video/basic.py:13-53:
+        every frame = its tile's tokens + the "\n" end token, frames concatenated): the frames join the tower batch BEHIND the images, and a
+        video's block is its frames' blocks back to back — the same rows the image path makes, so forward and backward need nothing new.
+        -> (tiles in tower order, frames per video)."""
+        videos = list(videos or [])
+        if not videos:
+            return list(images), []
+        enc = getattr(self.model, "encoders", {}).get("video")
+        from .vlm import BasicVideoEncoder, TSPVideoEncoder
+        if isinstance(enc, TSPVideoEncoder) or (enc is not None and tuple(getattr(enc, "pool_sizes", ((1, 1, 1),))) != ((1, 1, 1),)):
+            raise NotImplementedError("SFT step with a pooling video encoder (TSPVideoEncoder): the pooling's backward is not built; "
+                                      "BasicVideoEncoder videos train like their frames")
+        if enc is not None and (getattr(enc, "start_tokens", None) is not None or getattr(enc, "end_tokens", "\n") != "\n"):
+            raise NotImplementedError("SFT step: video frames are framed by the image end token \"\\n\" only")
+        if getattr(self.cfg, "dynamic_s2", False):
+            raise NotImplementedError("SFT step: videos under dynamic_s2 are not built")
+        frames = [int(v.shape[0]) for v in videos]
+        return list(images) + [f for v in videos for f in v], frames
+
+    def _splice(self, input_ids, attention_mask, labels, rows, frames):
+        """splice_plan for the step: image i -> one block of len(rows[i]) + 1 rows; video v -> one block of its frames' blocks.  The flat media
+        space (images, then videos) is the per-tile space of `_media_rows`, whatever the grouping."""
+        cfg, model = self.cfg, self.model
+        n_img = len(rows) - sum(frames)
+        lens = {"image": [int(r.numel()) + 1 for r in rows[:n_img]]}
+        toks = {"image": cfg.image_token_id}
+        if frames:
+            it = iter(rows[n_img:])
+            lens["video"] = [sum(int(next(it).numel()) + 1 for _ in range(nf)) for nf in frames]
+            toks["video"] = cfg.video_token_id
+        return splice_plan(input_ids, attention_mask, labels, lens, toks, "right",
+                           max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
+
     @staticmethod
     def _media_rows(plan_img_src: torch.Tensor, rows: List[torch.Tensor]):
         """Map the splice plan's media-row indices (into the concatenation of the per-image blocks [tokens..., "\n"]) to projector rows:
@@ -565,7 +599,7 @@ class SFTTrainer:
 
     def forward_backward_c(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
                            attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None,
-                           block_sizes=None) -> torch.Tensor:
+                           block_sizes=None, videos=None) -> torch.Tensor:
         """forward_backward through ONE C-ABI call (`vila_sft_fwd_bwd`): the host plans the splice / pack (integers only), the library
         runs every forward and backward kernel and calls back per gradient bucket, where this class starts the exchange + AdamW on its
         optimizer stream exactly as the Python-orchestrated path does."""
@@ -581,11 +615,11 @@ class SFTTrainer:
         self.reducer.log.clear()
         self._touched = []
         c = cfg.llm
-        n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image)
+        images, frames = self._with_videos(images, videos)
+        n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image; videos: their frames)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
         s2, rows, n_pin = self._media_plan(n_img, block_sizes)
-        plan = splice_plan(input_ids, attention_mask, labels, [int(r.numel()) + 1 for r in rows], cfg.image_token_id, "right",
-                           max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
+        plan = self._splice(input_ids, attention_mask, labels, rows, frames)
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
         inv = torch.full((plan.B * plan.S,), -1, dtype=torch.int64)
@@ -653,7 +687,7 @@ class SFTTrainer:
     # ------------------------------------------------------------------ the step -------------------------------------------
     def forward_backward(self, input_ids: torch.Tensor, images: List[torch.Tensor], labels: torch.Tensor,
                          attention_mask: Optional[torch.Tensor] = None, num_items_in_batch: Optional[int] = None,
-                         block_sizes=None) -> torch.Tensor:
+                         block_sizes=None, videos=None) -> torch.Tensor:
         """Forward + backward of the packed batch; gradients land in self.flat.grads (already all-reduced when DP > 1).
         Returns the (local) loss = sum CE / num_items_in_batch as a device scalar.
         dynamic_s2 (the NVILA-8B recipe, scripts/NVILA/stage1_9tile.sh:19-22): `images` = the tiles of every scale of every image in
@@ -671,6 +705,7 @@ class SFTTrainer:
         c = cfg.llm
         H = c.hidden_size
         # ---- vision + projector (+ "\n" end token) ----
+        images, frames = self._with_videos(images, videos)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16) if len(images) else None
         n_img = 0 if pixels is None else pixels.shape[0]          # tiles (dynamic_s2: of every scale of every image)
         s2, rows, n_pin = self._media_plan(n_img, block_sizes)
@@ -683,8 +718,7 @@ class SFTTrainer:
         table = P("llm.model.embed_tokens.weight")
         # ---- splice + pack (llava_arch.py:412-490, 744-800) ----
         # training truncates every sample to tokenizer.model_max_length AFTER media expansion (llava_arch.py:519-526)
-        plan = splice_plan(input_ids, attention_mask, labels, [int(r.numel()) + 1 for r in rows], cfg.image_token_id, "right",
-                           max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
+        plan = self._splice(input_ids, attention_mask, labels, rows, frames)
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
         # packed row index of every padded-grid position
@@ -841,29 +875,33 @@ class SFTTrainer:
         self._media_elsewhere = any_media and not has_media
         return n_global
 
-    def step(self, input_ids, images, labels, attention_mask=None, block_sizes=None) -> float:
-        n_local = count_targets(input_ids, labels, attention_mask, self.cfg.image_token_id)
-        n_global = self._global_counts(n_local, len(images) > 0)
+    def step(self, input_ids, images, labels, attention_mask=None, block_sizes=None, videos=None) -> float:
+        n_local = count_targets(input_ids, labels, attention_mask, (self.cfg.image_token_id, self.cfg.video_token_id))
+        n_global = self._global_counts(n_local, len(images) + len(videos or []) > 0)
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
         try:
             fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
-            loss = fb(input_ids, images, labels, attention_mask, n_global, block_sizes)
+            loss = fb(input_ids, images, labels, attention_mask, n_global, block_sizes, **({"videos": videos} if videos else {}))
             self.optimizer_step()
         finally:
             self._bucket_step = False
         return loss
 
 
-def count_targets(input_ids, labels, attention_mask, image_token_id: int) -> int:
-    """Number of label positions that survive the shift + first-label masking of the packed row (host integer work)."""
+def count_targets(input_ids, labels, attention_mask, image_token_id) -> int:
+    """Number of label positions that survive the shift + first-label masking of the packed row (host integer work).
+    image_token_id: the media token id, or a tuple of them (image, video): a media token's own label never survives the splice."""
+    media_ids = tuple(image_token_id) if isinstance(image_token_id, (tuple, list)) else (int(image_token_id),)
     mask = attention_mask.bool() if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
     n = 0
     for k in range(input_ids.shape[0]):
         ids_k, lab_k = input_ids[k][mask[k]], labels[k][mask[k]]
         if ids_k.numel() == 0:                # fully masked row: contributes nothing
             continue
-        keep = (ids_k != image_token_id) & (lab_k != IGNORE_INDEX)
+        keep = lab_k != IGNORE_INDEX
+        for t in media_ids:
+            keep = keep & (ids_k != t)
         keep[0] = False                       # first token of a sample is never a target (llava_arch.py:760-762 + HF shift)
         n += int(keep.sum())
     return n
@@ -926,12 +964,12 @@ class AutogradSeam:
         self.all_trainable = all(tune.values())
         self.anchor = self.params[0][0]
 
-    def loss(self, input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes) -> torch.Tensor:
+    def loss(self, input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes, videos=None) -> torch.Tensor:
         tr = self.trainer
         fb = tr.forward_backward_c if tr.use_c_abi else tr.forward_backward
         tr._bucket_step = False
-        tr.agree_on_media(len(images) > 0)
-        return _SftLossFn.apply(self.anchor, self, lambda: fb(input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes))
+        tr.agree_on_media(len(images) + len(videos or []) > 0)
+        return _SftLossFn.apply(self.anchor, self, lambda: fb(input_ids, images, labels, attention_mask, num_items_in_batch, block_sizes, **({"videos": videos} if videos else {})))
 
     def deposit(self, g: torch.Tensor) -> None:
         grads = self.trainer.flat.grads

@@ -278,12 +278,13 @@ class HipLlavaLlamaModel(nn.Module):
                 inputs_embeds=None, num_items_in_batch=None, **kw):
         seam = getattr(self, "_seam", None)
         if seam is not None and self.training and labels is not None and inputs_embeds is None and torch.is_grad_enabled():
-            if any(k != "image" and len(v) for k, v in (media or {}).items()):
-                raise NotImplementedError("training through the autograd seam takes image media (video frames train as images upstream)")
+            if any(k not in ("image", "video") and len(v) for k, v in (media or {}).items()):
+                raise NotImplementedError("training through the autograd seam takes image and video media")
             images = list((media or {}).get("image", []))
+            videos = list((media or {}).get("video", []))            # BasicVideoEncoder: frames train like image tiles (train.py _with_videos)
             blocks = ((media_config or {}).get("image", {}) or {}).get("block_sizes")
             from .modules import CausalLMOutput
-            return CausalLMOutput(loss=seam.loss(input_ids, images, labels, attention_mask, num_items_in_batch, blocks), logits=None,
+            return CausalLMOutput(loss=seam.loss(input_ids, images, labels, attention_mask, num_items_in_batch, blocks, videos), logits=None,
                                   past_key_values=None)
         with torch.no_grad():
             return self._forward_eval(input_ids, media, media_config, attention_mask, labels, inputs_embeds, num_items_in_batch)
