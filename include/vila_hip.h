@@ -362,6 +362,12 @@ int vila_s2_merge_bwd_bf16(const void* dy, void* dx, const int32_t* tile_desc, i
  * ------------------------------------------------------------------------------------------------------------ */
 int vila_video_pool_bf16(const void* feats, void* out, int n_frames, int grid, int channels, int pool_t, int pool_h, int pool_w,
                          const void* start_rows, int n_start, const void* end_rows, int n_end, vila_stream_t stream);
+/* Adjoint of the pooling for the SFT step (row a13 over a7; the `mean` backward of tsp.py:10-11 under autograd):
+ *   dpooled [(n_frames/pool_t) * (grid/pool_h)(grid/pool_w), C] (gradient of the pooled FEATURE rows only) ->
+ *   dfeats  [n_frames, grid*grid, C]: dfeats[t][h][w] = dpooled[t/pool_t][h/pool_h][w/pool_w] / (pool_t pool_h pool_w);
+ *   accumulate != 0 adds into dfeats (the second and later pool sizes of one video). */
+int vila_video_pool_bwd_bf16(const void* dpooled, void* dfeats, int n_frames, int grid, int channels, int pool_t, int pool_h, int pool_w,
+                             int accumulate, vila_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * W4A16 decode (BASELINE configs[4]).  The reference's W4A16 backend is the external TinyChat

@@ -248,12 +248,15 @@ def basic_video_encoder(videos: Sequence[torch.Tensor], w, cfg) -> List[torch.Te
     return [video_process_features(f, None, end) for f in torch.split(feats, [int(v.shape[0]) for v in videos])]
 
 
-def tsp_video_encoder(videos: Sequence[torch.Tensor], w, cfg, pool_sizes, sep_ids: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
-    """video/tsp.py:54-64."""
+def tsp_video_encoder(videos: Sequence[torch.Tensor], w, cfg, pool_sizes, sep_ids: Optional[Sequence[int]] = None,
+                      start_ids: Optional[Sequence[int]] = None, end_ids: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+    """video/tsp.py:54-64.  end_ids None = the "\n" end token (the encoder's default end_tokens, tsp.py:18-19)."""
     feats = encode_images(torch.cat(list(videos), 0), w, cfg)
-    end = embed_tokens(torch.tensor([cfg.newline_token_id]), w)
+    end_ids = [cfg.newline_token_id] if end_ids is None else list(end_ids)
+    end = embed_tokens(torch.tensor(end_ids), w) if end_ids else None
+    start = embed_tokens(torch.tensor(list(start_ids)), w) if start_ids else None
     sep = embed_tokens(torch.tensor(list(sep_ids)), w) if sep_ids else None
-    return [tsp_process_features(f, pool_sizes, None, end, sep) for f in torch.split(feats, [int(v.shape[0]) for v in videos])]
+    return [tsp_process_features(f, pool_sizes, start, end, sep) for f in torch.split(feats, [int(v.shape[0]) for v in videos])]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -485,7 +488,8 @@ def vlm_generate(pixels_list, input_ids, w, cfg, max_new_tokens: int, **kw):
     return greedy_generate(e, w, cfg, max_new_tokens, **kw)
 
 
-def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True, block_sizes=None, videos=None):
+def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_items_in_batch=None, packed=True, block_sizes=None, videos=None,
+                 video_encoder=None):
     """Training forward of llava_llama.py:94-159 (packing branch): _embed -> repack -> llm(..., labels).
     dynamic_s2 (cfg.dynamic_s2, llava_arch.py:369-390): pixels_list = the tiles of every scale of every image, block_sizes = one entry per
     image (media_config["image"]["block_sizes"]); BasicImageEncoder appends the "\n" embedding to each IMAGE's merged tokens."""
@@ -495,8 +499,13 @@ def vlm_sft_loss(pixels_list, input_ids, labels, attention_mask, w, cfg, num_ite
         media = [torch.cat([f, end], 0) for f in feats]
     else:
         media = basic_image_encoder(pixels_list, w, cfg) if len(pixels_list) else []
-    if videos:                                                # BasicVideoEncoder (encoders/video/basic.py:43-53): one block per <vila/video> token
-        media = {"image": media, "video": basic_video_encoder(videos, w, cfg)}
+    if videos:                                                # one block per <vila/video> token
+        if video_encoder is None:                             # BasicVideoEncoder (encoders/video/basic.py:43-53)
+            vid = basic_video_encoder(videos, w, cfg)
+        else:                                                 # TSPVideoEncoder (encoders/video/tsp.py:14-64): dict(pool_sizes, start_ids, end_ids, sep_ids)
+            vid = tsp_video_encoder(videos, w, cfg, video_encoder["pool_sizes"], video_encoder.get("sep_ids"), video_encoder.get("start_ids"),
+                                    video_encoder.get("end_ids"))
+        media = {"image": media, "video": vid}
     e, l, m = embed_splice(input_ids, media, w, cfg, labels=labels, attention_mask=attention_mask)
     if packed:
         pe, pm, pp, pl, seqlens = repack(e, m, l)

@@ -545,9 +545,127 @@ def test_sft_step_with_video_media_matches_oracle_autograd(use_c):
         out.loss.backward()
         p = dict(m2.mm_projector.named_parameters())["layers.1.weight"]
         assert p.grad is not None and float(F.cosine_similarity(p.grad.float().cpu().flatten(), wr["mm_projector.layers.1.weight"].grad.flatten(), dim=0)) >= 0.99
-        # a pooling video encoder is refused, not silently mis-trained
+    else:
+        # the one-call driver has no pooling stage: a pooling video encoder is refused there, not silently mis-trained
         from vila_amd.vlm import TSPVideoEncoder
-        m2.encoders["video"] = TSPVideoEncoder(m2, [[2, 1, 1]])
+        model.encoders["video"] = TSPVideoEncoder(model, [[3, 1, 1]])
         with pytest.raises(NotImplementedError, match="pooling"):
-            m2(input_ids=ids, media={"image": [p.cuda() for p in images], "video": [video.cuda()]}, labels=labels, attention_mask=mask)
+            tr.forward_backward_c(ids, [p.cuda() for p in images], labels, mask, n_items, None, videos=[video.cuda()])
     print(f"SFT with video media ({'one C-ABI call' if use_c else 'python-orchestrated'}): loss {float(loss):.5f} vs oracle {float(ref):.5f}, worst cosine {worst:.4f}")
+
+
+class _MapTokenizer:
+    """The synthetic tokenizer plus a fixed string -> ids map for the video encoder's start / end / separator strings."""
+
+    def __init__(self, inner, table):
+        self._inner, self._table = inner, dict(table)
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def __call__(self, text):
+        from types import SimpleNamespace
+        if text in self._table:
+            return SimpleNamespace(input_ids=list(self._table[text]))
+        return self._inner(text)
+
+
+@pytest.mark.parametrize("pool_sizes,start,end,sep", [
+    ([[2, 1, 1]], None, "\n", None),                       # temporal pooling only (NVILA-Video's shape of recipe: scripts/NVILA/stage4.sh:50 uses [[8,1,1]])
+    ([[2, 2, 2], [1, 1, 1]], "<s>", "<e>", "<sep>"),      # two pool sizes over the same frames (pooled + unpooled), start / end / separator tokens
+    ([[4, 2, 1], [1, 1, 2]], None, None, "<sep>"),        # no end token, anisotropic windows
+])
+def test_sft_step_with_tsp_video_encoder_matches_oracle_autograd(pool_sizes, start, end, sep):
+    """Row a13 over row a7's TSPVideoEncoder (encoders/video/tsp.py:14-64, an nn.Module inside the graph the reference trains): the pooled
+    rows go through `vila_video_pool_bf16`, their gradients come back through its adjoint `vila_video_pool_bwd_bf16` (accumulating across
+    pool sizes), the start / end / separator tokens' gradients land in the embedding table.  Loss and EVERY parameter's gradient against fp32
+    autograd through the oracle's restatement of the encoder, plus the autograd seam on the same batch."""
+    from oracle import vila_oracle as O
+    from vila_amd import configs, synthetic
+    from vila_amd.train import SFTTrainer, count_targets
+    from vila_amd.vlm import build_model, TSPVideoEncoder
+    cfg = configs.tiny("mlp_downsample")
+    seed = 37
+    table = {"<s>": [21, 22], "<e>": [23], "<sep>": [24, 25, 26]}
+    tok = lambda t: None if t is None else ([cfg.newline_token_id] if t == "\n" else table[t])
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, seed).items()}
+    px = synthetic.make_pixels(cfg, 9, seed).to(torch.bfloat16)
+    images, vid_a, vid_b = [px[0]], px[1:5], px[5:9]                     # sample 0: image + 4-frame video; sample 1: 4-frame video
+    g = torch.Generator().manual_seed(seed)
+    L = 16
+    ids = torch.randint(0, 900, (2, L), generator=g)
+    ids[0, 0] = cfg.image_token_id
+    ids[0, 5] = cfg.video_token_id
+    ids[1, 3] = cfg.video_token_id
+    labels = torch.randint(0, 900, (2, L), generator=g)
+    labels[:, :7] = -100
+    mask = torch.ones(2, L, dtype=torch.bool); mask[1, 13:] = False
+    n_items = count_targets(ids, labels, mask, (cfg.image_token_id, cfg.video_token_id))
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    enc = {"pool_sizes": pool_sizes, "start_ids": tok(start), "end_ids": tok(end) or [], "sep_ids": tok(sep)}
+    ref = O.vlm_sft_loss([p.float() for p in images], ids, labels, mask, wr, cfg, num_items_in_batch=n_items, packed=True,
+                         videos=[vid_a.float(), vid_b.float()], video_encoder=enc)
+    ref.backward()
+
+    def make():
+        m = build_model(cfg, weights=w)
+        m.tokenizer = _MapTokenizer(m.tokenizer, table)
+        m.encoders["video"] = TSPVideoEncoder(m, pool_sizes, start_tokens=start, end_tokens=end, sep_tokens=sep)
+        return m
+    model = make()
+    tr = SFTTrainer(model, optimizer_state=False)
+    loss = tr.forward_backward(ids, [p.cuda() for p in images], labels, mask, n_items, None, videos=[vid_a.cuda(), vid_b.cuda()])
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref)), (float(loss), float(ref))
+    grads = tr.flat.named_grads()
+    worst, n_checked = 1.0, 0
+    for name, gref in ((k, v.grad) for k, v in wr.items()):
+        if name not in grads or gref is None:
+            continue
+        got = grads[name].float().cpu()
+        if float(gref.norm()) < 1e-6:
+            assert float(got.norm()) < 1e-3, name
+            continue
+        cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
+        worst = min(worst, cos)
+        n_checked += 1
+        assert cos >= 0.99, (name, cos)
+    assert n_checked > 20
+    # the tower's gradient exists only through the pooled rows for the videos: it must be there
+    assert float(grads["vision_tower.vision_tower.vision_model.embeddings.patch_embedding.weight"].float().norm()) > 0
+    # the encoder's own tokens were trained: their embedding rows carry gradient, as in the oracle
+    ge, ge_ref = grads["llm.model.embed_tokens.weight"].float().cpu(), wr["llm.model.embed_tokens.weight"].grad
+    for t in (tok(start) or []) + (tok(end) or []) + (tok(sep) or []):
+        assert float(ge_ref[t].norm()) > 0 and float(F.cosine_similarity(ge[t], ge_ref[t], dim=0)) >= 0.98, t
+    # inference forward of the same encoder agrees with the rows the step spliced (the forward the step reuses is the serving one)
+    m2 = make()
+    m2.enable_autograd(use_c_abi=False)
+    m2.train()
+    out = m2(input_ids=ids, media={"image": [p.cuda() for p in images], "video": [vid_a.cuda(), vid_b.cuda()]}, labels=labels, attention_mask=mask,
+             num_items_in_batch=n_items)
+    assert abs(float(out.loss) - float(ref)) < 1e-2 * abs(float(ref))
+    out.loss.backward()
+    p = dict(m2.mm_projector.named_parameters())["layers.1.weight"]
+    assert p.grad is not None and float(F.cosine_similarity(p.grad.float().cpu().flatten(), wr["mm_projector.layers.1.weight"].grad.flatten(), dim=0)) >= 0.99
+    print(f"SFT with TSPVideoEncoder {pool_sizes} start={start!r} end={end!r} sep={sep!r}: loss {float(loss):.5f} vs oracle {float(ref):.5f}, "
+          f"worst cosine {worst:.4f} over {n_checked} tensors")
+
+
+def test_video_pool_adjoint_is_the_transpose_of_the_pooling():
+    """<pool(x), y> == <x, pool_bwd(y)> on integer-valued inputs (exact in bf16 / fp32), and accumulate adds."""
+    from vila_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for nt, nl, Cc, pool in [(4, 4, 16, (2, 2, 2)), (6, 6, 8, (3, 2, 1)), (2, 3, 24, (1, 3, 3)), (8, 2, 8, (8, 1, 1))]:
+        x = torch.randint(-4, 5, (nt, nl * nl, Cc), generator=g).to(torch.bfloat16).cuda()
+        n_out = (nt // pool[0]) * (nl // pool[1]) * (nl // pool[2])
+        k = pool[0] * pool[1] * pool[2]
+        y = (torch.randint(-4, 5, (n_out, Cc), generator=g) * k).to(torch.bfloat16).cuda()       # multiples of the window: y / k exact
+        px = ops.video_pool(x * k, pool)                                                          # x * k: the mean is exact
+        by = ops.video_pool_bwd(y, nt, nl, pool)
+        lhs = float((px.double() * y.double()).sum())                                            # sum_w (sum_{i in w} x_i k / k) y_w
+        rhs = float((x.double() * by.double()).sum()) * k                                         # sum_i x_i (y_w / k), times k
+        assert lhs == rhs, (pool, lhs, rhs)
+        twice = ops.video_pool_bwd(y, nt, nl, pool, out=by.clone(), accumulate=True)
+        assert torch.equal(twice.float(), 2 * by.float())
+    with pytest.raises(ValueError, match="invalid for pooling"):
+        ops.video_pool(torch.zeros(3, 4, 8, dtype=torch.bfloat16).cuda(), (2, 1, 1))

@@ -130,3 +130,52 @@ def test_video_path_end_to_end_vs_oracle(enc):
     e, _, m = model._embed(ids[None], {"video": [video.cuda()], "image": [image.cuda()]})
     assert e.shape == e_ref.shape and torch.equal(m.cpu(), m_ref)
     assert rel_l2(e, e_ref) < 2e-2, f"spliced embeds rel={rel_l2(e, e_ref):.3e}"
+
+
+@pytest.mark.parametrize("pool_sizes,start,end,sep", [
+    ([[1, 1, 1]], [], [11], []),
+    ([[2, 1, 1]], [], [11], []),
+    ([[2, 2, 2], [1, 1, 1]], [21, 22], [23], [24, 25]),
+    ([[4, 1, 2], [2, 2, 1]], [], [], [24]),
+])
+def test_sft_media_block_table_reproduces_the_encoder_blocks(pool_sizes, start, end, sep):
+    """The SFT step's integer plan of the media blocks (`SFTTrainer._media_blocks`: rows of the media feature buffer / token rows) expands to
+    exactly the blocks the oracle's encoders build (basic.py:30-41, tsp.py:28-52) — host logic, no GPU."""
+    from types import SimpleNamespace
+    from vila_amd.train import SFTTrainer
+    cfg = configs.tiny("mlp_downsample")
+    Tm, H = cfg.tokens_per_tile, 6
+    nl = int(Tm ** 0.5)
+    g = torch.Generator().manual_seed(3)
+    frames = [4, 8]
+    n_img = 2
+    n_tiles = n_img + sum(frames)
+    proj = torch.randn(n_tiles, Tm, H, generator=g)
+    table = torch.randn(64, H, generator=g)
+    fake = SimpleNamespace(cfg=cfg, _video_tokens=lambda: (tuple(tuple(p) for p in pool_sizes), start, end, sep))
+    rows = [torch.arange(i * Tm, (i + 1) * Tm) for i in range(n_tiles)]
+    img_blocks, vid_blocks, pools, n_buf = SFTTrainer._media_blocks(fake, rows, frames, n_tiles * Tm)
+    # the buffer the driver builds: projector rows, then the pooled rows of every (video, pool size) in `pools` order
+    buf = [proj.reshape(-1, H)]
+    for t0, nf, pool, off, cnt in pools:
+        assert off == sum(b.shape[0] for b in buf)
+        f = proj[t0:t0 + nf].view(nf, nl, nl, H)
+        for dim, p in enumerate(pool):
+            f = O.pool(f, p, dim)
+        buf.append(f.reshape(-1, H))
+        assert buf[-1].shape[0] == cnt
+    buf = torch.cat(buf, 0)
+    assert buf.shape[0] == n_buf
+    expand = lambda blk: torch.stack([buf[v] if v >= 0 else table[-1 - v] for v in blk.tolist()], 0) if blk.numel() else torch.empty(0, H)
+    emb = lambda ids: table[torch.tensor(ids)] if ids else None
+    for i in range(n_img):
+        assert torch.equal(expand(img_blocks[i]), torch.cat([proj[i], table[cfg.newline_token_id][None]], 0))
+    t0 = n_img
+    for v, nf in enumerate(frames):
+        want = O.tsp_process_features(proj[t0:t0 + nf], pool_sizes, emb(start), emb(end), emb(sep))
+        got = expand(vid_blocks[v])
+        assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6), (v, got.shape, want.shape)
+        t0 += nf
+    with pytest.raises(ValueError, match="invalid for pooling"):
+        bad = SimpleNamespace(cfg=cfg, _video_tokens=lambda: (((3, 1, 1),), [], [11], []))
+        SFTTrainer._media_blocks(bad, rows, frames, n_tiles * Tm)

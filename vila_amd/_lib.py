@@ -176,6 +176,7 @@ PROTOTYPES = {
     "vila_llm_decode_step_w4_sample": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),
                                                C.POINTER(VilaDecodeState), c_void_p, c_size_t, C.POINTER(VilaSampling), c_void_p]),
     "vila_video_pool_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "vila_video_pool_bwd_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vila_sft_workspace_bytes": (c_size_t, [C.POINTER(VilaVitWeights), C.POINTER(VilaProjWeights), C.POINTER(VilaLlmWeights), C.POINTER(VilaSftBatch)]),
     "vila_sft_fwd_bwd": (c_int, [C.POINTER(VilaVitWeights), C.POINTER(VilaVitWeights), C.POINTER(VilaProjWeights), C.POINTER(VilaProjWeights),
                                  C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmWeights), C.POINTER(VilaSftBatch), c_void_p, c_void_p, c_size_t,

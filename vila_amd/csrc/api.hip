@@ -839,6 +839,10 @@ extern "C" int vila_video_pool_bf16(const void* feats, void* out, int n_frames, 
                                     const void* start_rows, int n_start, const void* end_rows, int n_end, vila_stream_t stream) {
     return launch_video_pool(B(feats), B(out), n_frames, grid, channels, pool_t, pool_h, pool_w, B(start_rows), n_start, B(end_rows), n_end, S(stream));
 }
+extern "C" int vila_video_pool_bwd_bf16(const void* dpooled, void* dfeats, int n_frames, int grid, int channels, int pool_t, int pool_h, int pool_w,
+                                        int accumulate, vila_stream_t stream) {
+    return launch_video_pool_bwd(B(dpooled), B(dfeats), n_frames, grid, channels, pool_t, pool_h, pool_w, accumulate, S(stream));
+}
 
 // =================================================================================================
 // W4A16 decode: int4 group-128 weights for the five decoder-layer projections, bf16 everything else

@@ -61,6 +61,7 @@ int launch_s2_merge_bwd(const bf16_t* dy, bf16_t* dx, const int32_t* tdesc, int 
 // video token assembly (video.hip): temporal / spatial mean pooling + start / end token rows per pooled frame
 int launch_video_pool(const bf16_t* feats, bf16_t* out, int nt, int nl, int C, int pt, int ph, int pw, const bf16_t* start_rows, int n_start,
                       const bf16_t* end_rows, int n_end, hipStream_t s);
+int launch_video_pool_bwd(const bf16_t* dpooled, bf16_t* dfeats, int nt, int nl, int C, int pt, int ph, int pw, int accumulate, hipStream_t s);
 
 // ---- W8A8 (gemm_i8.hip): Y = epi((Xq . Wq^T) * sx[m] * sw[n] + bias) (+ residual), int8 operands, int32 accumulate, bf16 out ----
 int launch_gemm_i8(const int8_t* A, int64_t lda, const int8_t* W, int64_t ldw, const float* sx, const float* sw, const bf16_t* bias,

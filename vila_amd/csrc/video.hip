@@ -58,3 +58,46 @@ int launch_video_pool(const bf16_t* feats, bf16_t* out, int nt, int nl, int C, i
     VILA_LAUNCH_CHECK();
     return 0;
 }
+
+// Adjoint of the pooling above for the SFT step (SURVEY.md §8 row a13 over row a7: TSPVideoEncoder is an nn.Module inside the autograd graph
+// the reference trains, video/tsp.py:28-52 — `mean` backward spreads each pooled row's gradient evenly over its window).
+//   dpooled [(nt/pt) * (nl/ph)(nl/pw), C]   gradient of the pooled FEATURE rows only (start / end token rows belong to the embedding table)
+//   dfeats  [nt, nl*nl, C]                  dfeats[t][h][w] (+)= dpooled[t/pt][h/ph][w/pw] / (pt ph pw)
+// A gather: every output element has exactly one source, so no atomics; `accumulate` adds into dfeats (second and later pool sizes of the
+// same video, fp32 add, one bf16 rounding per pool size).  HBM-bound: each dfeats byte written once, dpooled re-read pt*ph*pw times from L2.
+__global__ void video_pool_bwd_kernel(const bf16_t* __restrict__ dpooled, bf16_t* __restrict__ dfeats, int nl, int C, int pt, int ph, int pw,
+                                      int accumulate, int64_t total_chunks) {
+    const int c8 = C >> 3;
+    const int wo_n = nl / pw, n_feat = (nl / ph) * wo_n;
+    const float inv = 1.0f / (float)(pt * ph * pw);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c8;
+        const int c = (int)(i % c8) * 8;
+        const int t = (int)(row / (nl * nl)), hw = (int)(row % (nl * nl)), h = hw / nl, w = hw % nl;
+        const int64_t src = (int64_t)(t / pt) * n_feat + (h / ph) * wo_n + (w / pw);
+        const u32x4 g = *(const u32x4*)(dpooled + src * C + c);
+        bf16_t* dst = dfeats + row * C + c;
+        u32x4 o;
+        if (accumulate) {
+            const u32x4 old = *(const u32x4*)dst;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack2bf(lo_bf(old[j]) + lo_bf(g[j]) * inv, hi_bf(old[j]) + hi_bf(g[j]) * inv);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack2bf(lo_bf(g[j]) * inv, hi_bf(g[j]) * inv);
+        }
+        *(u32x4*)dst = o;
+    }
+}
+
+int launch_video_pool_bwd(const bf16_t* dpooled, bf16_t* dfeats, int nt, int nl, int C, int pt, int ph, int pw, int accumulate, hipStream_t s) {
+    VILA_REQUIRE(pt > 0 && ph > 0 && pw > 0 && nt > 0 && nl > 0, "video_pool_bwd: sizes must be positive");
+    VILA_REQUIRE(nt % pt == 0 && nl % ph == 0 && nl % pw == 0,
+                 "shape '[%d, %d, %d]' is invalid for pooling by (%d, %d, %d): every pooled dimension must divide evenly", nt, nl, nl, pt, ph, pw);
+    VILA_REQUIRE(C % 8 == 0, "video_pool_bwd: C=%d must be a multiple of 8", C);
+    const int64_t total = (int64_t)nt * nl * nl * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(video_pool_bwd_kernel, dim3(grid), dim3(256), 0, s, dpooled, dfeats, nl, C, pt, ph, pw, accumulate, total);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}

@@ -242,6 +242,21 @@ def video_pool(feats: torch.Tensor, pool, start_rows: Optional[torch.Tensor] = N
     return out
 
 
+def video_pool_bwd(dpooled: torch.Tensor, nt: int, nl: int, pool, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """Adjoint of video_pool's feature rows: dpooled [(nt/pt)(nl/ph)(nl/pw), C] -> dfeats [nt, nl*nl, C] (the `mean` backward of tsp.py:10-11);
+    accumulate adds into `out` (the later pool sizes of one video)."""
+    _need(dpooled, name="dpooled")
+    pt, ph, pw = (int(p) for p in pool)
+    Cc = dpooled.shape[-1]
+    assert dpooled.is_contiguous() and dpooled.numel() == (nt // pt) * (nl // ph) * (nl // pw) * Cc
+    if out is None:
+        assert not accumulate
+        out = torch.empty((nt, nl * nl, Cc), device=dpooled.device, dtype=dpooled.dtype)
+    assert out.is_contiguous() and out.numel() == nt * nl * nl * Cc
+    check(_lib.load().vila_video_pool_bwd_bf16(dpooled.data_ptr(), out.data_ptr(), nt, nl, Cc, pt, ph, pw, int(accumulate), _stream()), "video_pool_bwd")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # SFT-step operators (backward + optimizer)
 # ----------------------------------------------------------------------------------------------------------------------

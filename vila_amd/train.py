@@ -506,47 +506,84 @@ class SFTTrainer:
         return plan, [p.long() for p in plan.perms], plan.n_blocks
 
     def _with_videos(self, images, videos):
-        """`videos` (list of [n_frames, 3, H, W], each standing for one <vila/video> token) under the BasicVideoEncoder (video/basic.py:13-53:
-        every frame = its tile's tokens + the "\n" end token, frames concatenated): the frames join the tower batch BEHIND the images, and a
-        video's block is its frames' blocks back to back — the same rows the image path makes, so forward and backward need nothing new.
-        -> (tiles in tower order, frames per video)."""
+        """`videos` (list of [n_frames, 3, H, W], each standing for one <vila/video> token): the frames join the tower batch BEHIND the images
+        (video/basic.py:43-53, tsp.py:54-64 run encode_images on all frames at once).  -> (tiles in tower order, frames per video)."""
         videos = list(videos or [])
         if not videos:
             return list(images), []
-        enc = getattr(self.model, "encoders", {}).get("video")
-        from .vlm import BasicVideoEncoder, TSPVideoEncoder
-        if isinstance(enc, TSPVideoEncoder) or (enc is not None and tuple(getattr(enc, "pool_sizes", ((1, 1, 1),))) != ((1, 1, 1),)):
-            raise NotImplementedError("SFT step with a pooling video encoder (TSPVideoEncoder): the pooling's backward is not built; "
-                                      "BasicVideoEncoder videos train like their frames")
-        if enc is not None and (getattr(enc, "start_tokens", None) is not None or getattr(enc, "end_tokens", "\n") != "\n"):
-            raise NotImplementedError("SFT step: video frames are framed by the image end token \"\\n\" only")
         if getattr(self.cfg, "dynamic_s2", False):
             raise NotImplementedError("SFT step: videos under dynamic_s2 are not built")
-        frames = [int(v.shape[0]) for v in videos]
-        return list(images) + [f for v in videos for f in v], frames
+        return list(images) + [f for v in videos for f in v], [int(v.shape[0]) for v in videos]
 
-    def _splice(self, input_ids, attention_mask, labels, rows, frames):
-        """splice_plan for the step: image i -> one block of len(rows[i]) + 1 rows; video v -> one block of its frames' blocks.  The flat media
-        space (images, then videos) is the per-tile space of `_media_rows`, whatever the grouping."""
-        cfg, model = self.cfg, self.model
+    def _video_tokens(self):
+        """(pool_sizes, start ids, end ids, separator ids) of the model's video encoder (video/basic.py:13-28, tsp.py:14-26); a model without
+        one frames every video frame like an image: no start tokens, the "\n" end token."""
+        enc = getattr(self.model, "encoders", {}).get("video")
+        if enc is None:
+            return ((1, 1, 1),), [], [self.cfg.newline_token_id], []
+        tok = lambda t: [] if t is None else [int(x) for x in self.model.tokenizer(t).input_ids]
+        pools = tuple(tuple(int(x) for x in p) for p in getattr(enc, "pool_sizes", ((1, 1, 1),)))
+        return pools, tok(enc.start_tokens), tok(enc.end_tokens), tok(getattr(enc, "sep_tokens", None))
+
+    def _media_blocks(self, rows: List[torch.Tensor], frames: List[int], n_prow: int):
+        """The token block of every media placeholder as a row table over the MEDIA FEATURE BUFFER = [projector rows | pooled rows of every
+        (video, pool size)]: a value >= 0 is a row of that buffer, a value -1 - id is the embedding of token `id` (the "\n" end token of an
+        image, the start / end / separator tokens of the video encoder).
+          image i            rows[i] + ["\n"]                                             (encoders/image/basic.py:40-53)
+          video, pool 1,1,1  per frame  [start | rows[frame] | end], then the separator    (video/basic.py:30-41)
+          video, pooled      per pooled frame [start | its pooled rows | end], separator   (video/tsp.py:28-52), all pool sizes back to back
+        -> (image blocks, video blocks, pools = [(first tile, n_frames, pool, buffer row offset, n pooled rows)], buffer rows)"""
+        cfg = self.cfg
+        tokrow = lambda ids: torch.tensor([-1 - int(t) for t in ids], dtype=torch.int64)
         n_img = len(rows) - sum(frames)
-        lens = {"image": [int(r.numel()) + 1 for r in rows[:n_img]]}
-        toks = {"image": cfg.image_token_id}
+        nl_row = tokrow([cfg.newline_token_id])
+        img_blocks = [torch.cat([r, nl_row]) for r in rows[:n_img]]
+        vid_blocks, pools, n_buf = [], [], n_prow
         if frames:
-            it = iter(rows[n_img:])
-            lens["video"] = [sum(int(next(it).numel()) + 1 for _ in range(nf)) for nf in frames]
+            pool_sizes, start, end, sep = self._video_tokens()
+            start, end, sep = tokrow(start), tokrow(end), tokrow(sep)
+            Tm = cfg.tokens_per_tile
+            nl = int(round(Tm ** 0.5))
+            t0 = n_img
+            for nf in frames:
+                parts = []
+                for pool in pool_sizes:
+                    if pool == (1, 1, 1):
+                        for t in range(t0, t0 + nf):
+                            parts += [start, rows[t], end]
+                    else:
+                        pt, ph, pw = pool
+                        if nl * nl != Tm or pt <= 0 or ph <= 0 or pw <= 0 or nf % pt or nl % ph or nl % pw:   # the reference's view() raises
+                            raise ValueError(f"shape '[{nf}, {nl}, {nl}]' is invalid for pooling by ({pt}, {ph}, {pw}): every pooled dimension must divide evenly")
+                        n_feat = (nl // ph) * (nl // pw)
+                        for f in range(nf // pt):
+                            parts += [start, n_buf + f * n_feat + torch.arange(n_feat, dtype=torch.int64), end]
+                        pools.append((t0, nf, pool, n_buf, (nf // pt) * n_feat))
+                        n_buf += (nf // pt) * n_feat
+                    parts.append(sep)
+                vid_blocks.append(torch.cat(parts) if parts else torch.empty((0,), dtype=torch.int64))
+                t0 += nf
+        return img_blocks, vid_blocks, pools, n_buf
+
+    def _splice(self, input_ids, attention_mask, labels, img_blocks, vid_blocks):
+        """splice_plan for the step: one block per media placeholder.  The flat media space (images, then videos) is the row space of
+        `_media_rows`."""
+        cfg, model = self.cfg, self.model
+        lens = {"image": [int(b.numel()) for b in img_blocks]}
+        toks = {"image": cfg.image_token_id}
+        if vid_blocks:
+            lens["video"] = [int(b.numel()) for b in vid_blocks]
             toks["video"] = cfg.video_token_id
         return splice_plan(input_ids, attention_mask, labels, lens, toks, "right",
                            max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
 
     @staticmethod
-    def _media_rows(plan_img_src: torch.Tensor, rows: List[torch.Tensor]):
-        """Map the splice plan's media-row indices (into the concatenation of the per-image blocks [tokens..., "\n"]) to projector rows:
-        -> (feature row of every spliced media row or -1 for the "\n" end token)."""
-        if not rows:
+    def _media_rows(plan_img_src: torch.Tensor, blocks: List[torch.Tensor]):
+        """Map the splice plan's media-row indices (into the concatenation of the blocks of `_media_blocks`) to that table's values:
+        -> (media feature buffer row of every spliced media row, or -1 - token id for a token row)."""
+        if not blocks:
             return torch.empty((0,), dtype=torch.int64)
-        table = torch.cat([torch.cat([r, torch.tensor([-1], dtype=torch.int64)]) for r in rows]).to(plan_img_src.device)
-        return table[plan_img_src.long()]
+        return torch.cat(list(blocks)).to(plan_img_src.device)[plan_img_src.long()]
 
     # ------------------------------------------------------------------ one C-ABI call ------------------------------------
     def _c_structs(self, ptr):
@@ -619,18 +656,22 @@ class SFTTrainer:
         n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image; videos: their frames)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
         s2, rows, n_pin = self._media_plan(n_img, block_sizes)
-        plan = self._splice(input_ids, attention_mask, labels, rows, frames)
+        img_blocks, vid_blocks, pools, _ = self._media_blocks(rows, frames, n_pin * cfg.tokens_per_tile)
+        if pools:
+            raise NotImplementedError("vila_sft_fwd_bwd has no pooling stage: a pooling video encoder (TSPVideoEncoder) trains through the "
+                                      "operator-orchestrated driver (SFTTrainer.forward_backward, VILA_SFT_C_ABI=0)")
+        plan = self._splice(input_ids, attention_mask, labels, img_blocks, vid_blocks)
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
         inv = torch.full((plan.B * plan.S,), -1, dtype=torch.int64)
         inv[rp.rows] = torch.arange(T)
         i32 = lambda t: t.to(torch.int32).contiguous().to(dev)
         txt_src, txt_dst = i32(plan.txt_src), i32(inv[plan.txt_dst.long()])
-        mrow = self._media_rows(plan.img_src, rows)
+        mrow = self._media_rows(plan.img_src, img_blocks + vid_blocks)
         dst_p = inv[plan.img_dst.long()]
-        is_nl = mrow < 0
+        is_nl = mrow < 0                                  # token rows: "\n" and the video encoder's start / end / separator tokens
         feat_src, feat_dst, nl_dst = i32(mrow[~is_nl]), i32(dst_p[~is_nl]), i32(dst_p[is_nl])
-        nl_src = torch.full((int(nl_dst.numel()),), cfg.newline_token_id, dtype=torch.int32, device=dev)
+        nl_src = i32(-1 - mrow[is_nl])
         tgt = torch.full((T,), IGNORE_INDEX, dtype=torch.int64)
         tgt[:-1] = rp.labels[1:]
         valid = torch.nonzero(tgt != IGNORE_INDEX, as_tuple=False).flatten()
@@ -718,7 +759,9 @@ class SFTTrainer:
         table = P("llm.model.embed_tokens.weight")
         # ---- splice + pack (llava_arch.py:412-490, 744-800) ----
         # training truncates every sample to tokenizer.model_max_length AFTER media expansion (llava_arch.py:519-526)
-        plan = self._splice(input_ids, attention_mask, labels, rows, frames)
+        n_prow = proj.shape[0] * proj.shape[1] if n_img else 0                         # projector output rows
+        img_blocks, vid_blocks, pools, n_buf = self._media_blocks(rows, frames, n_prow)
+        plan = self._splice(input_ids, attention_mask, labels, img_blocks, vid_blocks)
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
         # packed row index of every padded-grid position
@@ -728,18 +771,22 @@ class SFTTrainer:
         x0 = torch.empty((T, H), device=dev, dtype=torch.bfloat16)
         ops.copy_rows(table, x0, plan.txt_src.to(dev), txt_dst, int(txt_dst.numel()))
         if n_img:
-            # media row i of the [n_img, Tm + 1] block list: r < Tm -> projector row, r == Tm -> the "\n" end token; rows cut off by the
+            # every spliced media row is a row of the media feature buffer or a token's embedding (`_media_blocks`); rows cut off by the
             # truncation are absent from plan.img_src / img_dst
-            mrow = self._media_rows(plan.img_src, rows).to(inv.device)
+            mrow = self._media_rows(plan.img_src, img_blocks + vid_blocks).to(inv.device)
             dst_p = inv[plan.img_dst.long()]
             is_nl = mrow < 0
             feat_src = mrow[~is_nl].to(torch.int32).to(dev)
             feat_dst = dst_p[~is_nl].to(torch.int32).to(dev)
             nl_dst = dst_p[is_nl].to(torch.int32).to(dev)
+            nl_src = (-1 - mrow[is_nl]).to(torch.int32).to(dev)
             n_feat, n_nl = int(feat_dst.numel()), int(nl_dst.numel())
-            n_prow = proj.shape[0] * proj.shape[1]                                     # projector output rows
-            ops.copy_rows(proj.reshape(n_prow, H), x0, feat_src, feat_dst, n_feat)
-            nl_src = torch.full((n_nl,), cfg.newline_token_id, dtype=torch.int32, device=dev)
+            media = proj.reshape(n_prow, H)
+            if pools:                                                                  # TSPVideoEncoder: mean over (t, h, w) windows (tsp.py:28-52)
+                Tm, grid_l = cfg.tokens_per_tile, int(round(cfg.tokens_per_tile ** 0.5))
+                media = torch.cat([media] + [ops.video_pool(proj[t0:t0 + nf], pool) for t0, nf, pool, _, _ in pools], 0)
+                assert media.shape[0] == n_buf
+            ops.copy_rows(media, x0, feat_src, feat_dst, n_feat)
             if n_nl:
                 ops.copy_rows(table, x0, nl_src, nl_dst, n_nl)
         pos = rp.position_ids.to(dev)
@@ -785,9 +832,12 @@ class SFTTrainer:
             ops.scatter_add_rows(dnl, ge, nl_src)
         self._ready("llm.model.embed_tokens.")
         if n_img and not getattr(self, "skip_proj_bwd", False):
-            full = n_feat == n_prow
-            dproj = (torch.empty if full else torch.zeros)((n_prow, H), device=dev, dtype=torch.bfloat16)   # truncated rows: zero grad
-            ops.copy_rows(dx0, dproj, feat_dst, feat_src, n_feat)
+            full = n_feat == n_buf
+            dmedia = (torch.empty if full else torch.zeros)((n_buf, H), device=dev, dtype=torch.bfloat16)   # truncated / pooled-only rows: zero
+            ops.copy_rows(dx0, dmedia, feat_dst, feat_src, n_feat)
+            dproj = dmedia[:n_prow]
+            for t0, nf, pool, off, cnt in pools:                                       # the pooled rows' gradients back onto their frames' rows
+                ops.video_pool_bwd(dmedia[off:off + cnt], nf, grid_l, pool, out=dproj[t0 * Tm:(t0 + nf) * Tm], accumulate=True)
             dfeats = self._proj_bwd(dproj.view(proj.shape[0], proj.shape[1], H), proj_saved)
             if s2 is not None:                                                         # adjoint of the merge: back onto the tower's tiles
                 dfeats = ops.s2_merge_bwd(dfeats, s2_tdesc, len(cfg.s2_scales), s2.splits)
