@@ -191,7 +191,13 @@ def projector_forward(x: torch.Tensor, w, ptype: str) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # a6/a7: encode_images plain branch (llava_arch.py:366-394), BasicImageEncoder.forward (encoders/image/basic.py:41-79)
 # ----------------------------------------------------------------------------------------------
-def encode_images(pixels, w, cfg) -> torch.Tensor:
+def encode_images(pixels, w, cfg, block_sizes=None):
+    """LlavaMetaForCausalLM.encode_images (llava_arch.py:366-394).  dynamic_s2: block_sizes None = one None per input (:367-368 — how the
+    video encoders reach it: every frame is a one-tile image whose features are repeated over the scales, :309-314); the per-image token
+    lists are stacked when they all have the same length (:389-390)."""
+    if getattr(cfg, "dynamic_s2", False):
+        outs = encode_images_dynamic_s2(pixels, [None] * len(pixels) if block_sizes is None else block_sizes, w, cfg)
+        return torch.stack(outs, 0) if all(o.shape[0] == outs[0].shape[0] for o in outs) else outs
     return projector_forward(vision_tower_forward(pixels, w, cfg.vision), w, cfg.mm_projector_type)
 
 

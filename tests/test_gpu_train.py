@@ -182,27 +182,35 @@ def test_adamw_matches_torch(ops, n):
 # ---------------------------------------------------------------------------------------------------------------------
 # whole step vs autograd through the CPU oracle
 # ---------------------------------------------------------------------------------------------------------------------
-def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max=6e-2, c_abi=(False,), block_sizes=None):
+def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max=6e-2, c_abi=(False,), block_sizes=None, video_frames=(), tsp=None):
     """One forward+backward of the HIP trainer vs fp32 autograd through the restated reference forward (packed branch of
     llava_llama.py:125-134): loss <= 1e-2 relative, every gradient tensor cosine >= cos_min and rel-L2 <= rel_max.
     c_abi: which drivers to check against the ONE oracle run — False = the Python-orchestrated operator calls, True = the whole
-    forward + backward as one `vila_sft_fwd_bwd` call with the grad-ready callback."""
+    forward + backward as one `vila_sft_fwd_bwd` call with the grad-ready callback.
+    video_frames: frame counts of the videos (one per <vila/video> token), their frames are drawn behind the `n_images` image tiles;
+    tsp: pool_sizes of a TSPVideoEncoder (None = the BasicVideoEncoder)."""
     from oracle import vila_oracle as O
     from vila_amd import synthetic
     from vila_amd.train import SFTTrainer, count_targets
-    from vila_amd.vlm import build_model
+    from vila_amd.vlm import build_model, TSPVideoEncoder
     w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, seed).items()}
-    px = synthetic.make_pixels(cfg, n_images, seed).to(torch.bfloat16)
-    n_items = count_targets(ids, labels, mask, cfg.image_token_id)
+    px_all = synthetic.make_pixels(cfg, n_images + sum(video_frames), seed).to(torch.bfloat16)
+    px, vids, at = px_all[:n_images], [], n_images
+    for nf in video_frames:
+        vids.append(px_all[at:at + nf]); at += nf
+    n_items = count_targets(ids, labels, mask, (cfg.image_token_id, cfg.video_token_id))
     wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
-    ref = O.vlm_sft_loss([p.float() for p in px], ids, labels, mask, wr, cfg, num_items_in_batch=n_items, packed=True, block_sizes=block_sizes)
+    ref = O.vlm_sft_loss([p.float() for p in px], ids, labels, mask, wr, cfg, num_items_in_batch=n_items, packed=True, block_sizes=block_sizes,
+                         videos=[v.float() for v in vids], video_encoder=None if tsp is None else {"pool_sizes": tsp})
     ref.backward()
     out = []
     for use_c in c_abi:
         model = build_model(cfg, weights=w)
+        if tsp is not None:
+            model.encoders["video"] = TSPVideoEncoder(model, tsp)
         tr = SFTTrainer(model, optimizer_state=False)
         fb = tr.forward_backward_c if use_c else tr.forward_backward
-        loss = fb(ids, [p.cuda() for p in px], labels, mask, n_items, block_sizes)
+        loss = fb(ids, [p.cuda() for p in px], labels, mask, n_items, block_sizes, **({"videos": [v.cuda() for v in vids]} if vids else {}))
         torch.cuda.synchronize()
         assert abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref)), (use_c, float(loss), float(ref))
         grads = tr.flat.named_grads()
@@ -279,6 +287,26 @@ def test_sft_dynamic_s2_forward_backward_matches_oracle_autograd():
     res = _sft_vs_oracle(cfg, 5, ids, labels, mask, 12, c_abi=(False, True), block_sizes=blocks)
     orders = [[p for p, _, _ in tr.reducer.log] for tr, _, _, _ in res]
     assert orders[0] == orders[1] and "mm_projector." in orders[0]
+
+
+def test_sft_dynamic_s2_with_videos_matches_oracle_autograd():
+    """Videos inside the dynamic_s2 recipe (the NVILA-8B SFT stages mix both): the video encoders call encode_images WITHOUT block sizes
+    (video/basic.py:48, tsp.py:59), so every frame is a one-tile image whose features are repeated over the scales (llava_arch.py:309-314,
+    367-368).  One 2 x 2 image + a 2-frame video in sample 0, a 4-frame video in sample 1: BasicVideoEncoder through both drivers, then the
+    pooling encoder (its pooled rows sit behind projector BLOCKS whose index is no longer the tile index)."""
+    from vila_amd import configs
+    cfg = configs.tiny_s2()
+    g = torch.Generator().manual_seed(29)
+    L = 14
+    ids = torch.randint(0, 900, (2, L), generator=g)
+    ids[0, 1] = cfg.image_token_id; ids[0, 6] = cfg.video_token_id
+    ids[1, 2] = cfg.video_token_id
+    mask = torch.ones(2, L, dtype=torch.bool); mask[1, 11:] = False
+    labels = torch.randint(0, 900, (2, L), generator=g); labels[:, :7] = -100
+    n_tiles = 1 + 4 + 4                                                   # the image: 1x and 2x scales in full, its own 2 x 2 blocks at the last scale
+    res = _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, c_abi=(False, True), block_sizes=[(2, 2)], video_frames=(2, 4))
+    assert abs(res[0][1] - res[1][1]) < 1e-2 * abs(res[0][1])
+    _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, c_abi=(False,), block_sizes=[(2, 2)], video_frames=(2, 4), tsp=[[2, 2, 1], [1, 1, 1]])
 
 
 def test_sft_dynamic_s2_at_8b_widths_matches_oracle_autograd():

@@ -511,9 +511,14 @@ class SFTTrainer:
         videos = list(videos or [])
         if not videos:
             return list(images), []
-        if getattr(self.cfg, "dynamic_s2", False):
-            raise NotImplementedError("SFT step: videos under dynamic_s2 are not built")
         return list(images) + [f for v in videos for f in v], [int(v.shape[0]) for v in videos]
+
+    def _block_sizes_with_frames(self, block_sizes, frames):
+        """dynamic_s2: the video encoders call encode_images WITHOUT block sizes (video/basic.py:48, tsp.py:59), i.e. every frame is a one-tile
+        image with block size None (llava_arch.py:367-368, 309-314: its features are repeated over the scales)."""
+        if not frames or not getattr(self.cfg, "dynamic_s2", False):
+            return block_sizes
+        return list(block_sizes or []) + [None] * sum(frames)
 
     def _video_tokens(self):
         """(pool_sizes, start ids, end ids, separator ids) of the model's video encoder (video/basic.py:13-28, tsp.py:14-26); a model without
@@ -532,7 +537,7 @@ class SFTTrainer:
           image i            rows[i] + ["\n"]                                             (encoders/image/basic.py:40-53)
           video, pool 1,1,1  per frame  [start | rows[frame] | end], then the separator    (video/basic.py:30-41)
           video, pooled      per pooled frame [start | its pooled rows | end], separator   (video/tsp.py:28-52), all pool sizes back to back
-        -> (image blocks, video blocks, pools = [(first tile, n_frames, pool, buffer row offset, n pooled rows)], buffer rows)"""
+        -> (image blocks, video blocks, pools = [(first projector block, n_frames, pool, buffer row offset, n pooled rows)], buffer rows)"""
         cfg = self.cfg
         tokrow = lambda ids: torch.tensor([-1 - int(t) for t in ids], dtype=torch.int64)
         n_img = len(rows) - sum(frames)
@@ -556,9 +561,12 @@ class SFTTrainer:
                         if nl * nl != Tm or pt <= 0 or ph <= 0 or pw <= 0 or nf % pt or nl % ph or nl % pw:   # the reference's view() raises
                             raise ValueError(f"shape '[{nf}, {nl}, {nl}]' is invalid for pooling by ({pt}, {ph}, {pw}): every pooled dimension must divide evenly")
                         n_feat = (nl // ph) * (nl // pw)
+                        b0 = int(rows[t0][0]) // Tm                 # the frames' projector blocks (dynamic_s2: images before them own several)
+                        for i in range(nf):
+                            assert torch.equal(rows[t0 + i], torch.arange((b0 + i) * Tm, (b0 + i + 1) * Tm, dtype=torch.int64))
                         for f in range(nf // pt):
                             parts += [start, n_buf + f * n_feat + torch.arange(n_feat, dtype=torch.int64), end]
-                        pools.append((t0, nf, pool, n_buf, (nf // pt) * n_feat))
+                        pools.append((b0, nf, pool, n_buf, (nf // pt) * n_feat))
                         n_buf += (nf // pt) * n_feat
                     parts.append(sep)
                 vid_blocks.append(torch.cat(parts) if parts else torch.empty((0,), dtype=torch.int64))
@@ -655,7 +663,7 @@ class SFTTrainer:
         images, frames = self._with_videos(images, videos)
         n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image; videos: their frames)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
-        s2, rows, n_pin = self._media_plan(n_img, block_sizes)
+        s2, rows, n_pin = self._media_plan(n_img, self._block_sizes_with_frames(block_sizes, frames))
         img_blocks, vid_blocks, pools, _ = self._media_blocks(rows, frames, n_pin * cfg.tokens_per_tile)
         if pools:
             raise NotImplementedError("vila_sft_fwd_bwd has no pooling stage: a pooling video encoder (TSPVideoEncoder) trains through the "
@@ -749,7 +757,7 @@ class SFTTrainer:
         images, frames = self._with_videos(images, videos)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16) if len(images) else None
         n_img = 0 if pixels is None else pixels.shape[0]          # tiles (dynamic_s2: of every scale of every image)
-        s2, rows, n_pin = self._media_plan(n_img, block_sizes)
+        s2, rows, n_pin = self._media_plan(n_img, self._block_sizes_with_frames(block_sizes, frames))
         if n_img:
             feats, vit_saved = self._vit_fwd(pixels)
             if s2 is not None:
