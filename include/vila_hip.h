@@ -327,6 +327,12 @@ typedef struct {
      * (the final chessboard merge is folded into it by the host plan), and the backward runs vila_s2_merge_bwd_bf16 (s2_tile_desc,
      * device [n_images][8]).  s2_n_blocks = 0: the plain single-scale path (the fields are ignored). */
     const int32_t* s2_desc; const int32_t* s2_tile_desc; int s2_n_blocks; int s2_n_scales; int32_t s2_splits[4];
+    /* pooling video encoder (TSPVideoEncoder, encoders/video/tsp.py:28-52).  n_pools > 0 => behind the projector's rows the step keeps
+     * n_media_rows - (projector rows) POOLED rows: pools = HOST array [n_pools][7] = {first projector input of the video's frames, n_frames,
+     * pool_t, pool_h, pool_w, first row of this (video, pool size)'s pooled rows in the buffer, their count}; forward = vila_video_pool_bf16
+     * per entry, backward = vila_video_pool_bwd_bf16 accumulated onto the frames' projector rows.  feat_src then indexes the whole buffer
+     * [projector rows | pooled rows].  n_pools = 0: feat_src indexes the projector rows only (n_media_rows is ignored). */
+    const int32_t* pools; int n_pools; int n_media_rows;
 } VilaSftBatch;
 size_t vila_sft_workspace_bytes(const VilaVitWeights* vit, const VilaProjWeights* proj, const VilaLlmWeights* llm, const VilaSftBatch* batch);
 int vila_sft_fwd_bwd(const VilaVitWeights* vit, const VilaVitWeights* vit_grad, const VilaProjWeights* proj, const VilaProjWeights* proj_grad,

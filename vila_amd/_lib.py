@@ -79,7 +79,8 @@ class VilaSftBatch(C.Structure):
                 ("nl_src", c_void_p), ("nl_dst", c_void_p), ("n_nl", c_int),
                 ("positions", c_void_p), ("cu_seqlens", c_void_p), ("n_seq", c_int), ("max_seqlen", c_int),
                 ("target_rows", c_void_p), ("targets", c_void_p), ("n_targets", c_int), ("loss_scale", c_float),
-                ("s2_desc", c_void_p), ("s2_tile_desc", c_void_p), ("s2_n_blocks", c_int), ("s2_n_scales", c_int), ("s2_splits", C.c_int32 * 4)]
+                ("s2_desc", c_void_p), ("s2_tile_desc", c_void_p), ("s2_n_blocks", c_int), ("s2_n_scales", c_int), ("s2_splits", C.c_int32 * 4),
+                ("pools", c_void_p), ("n_pools", c_int), ("n_media_rows", c_int)]
 
 
 GRAD_READY_CB = C.CFUNCTYPE(None, c_void_p, c_int, c_int)

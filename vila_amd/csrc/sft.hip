@@ -116,6 +116,18 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     const int n_pin = s2 ? b->s2_n_blocks : n_img;              // projector inputs ("images" of the projector)
     const int Dp = s2 ? b->s2_n_scales * D : D;                 // projector input channels
     const int gd = (g_ + kdown - 1) / kdown, Tm = gd * gd, C1 = kdown * kdown * Dp, Mp_ = n_pin * Tm;
+    const int n_pools = n_img > 0 ? b->n_pools : 0;            // pooling video encoder: pooled rows behind the projector's rows
+    const int Mbuf = n_pools > 0 ? b->n_media_rows : Mp_;
+    VILA_REQUIRE(n_pools >= 0 && (n_pools == 0 || (b->pools != nullptr && Mbuf >= Mp_)), "sft: pools needs the host array and n_media_rows >= the projector's %d rows", Mp_);
+    for (int i = 0; i < n_pools; ++i) {
+        const int32_t* q = b->pools + 7 * i;
+        VILA_REQUIRE(q[0] >= 0 && q[1] > 0 && q[0] + q[1] <= n_pin && q[2] > 0 && q[3] > 0 && q[4] > 0, "sft: pools[%d]: frames %d..%d of %d projector inputs, pool (%d, %d, %d)", i,
+                     q[0], q[0] + q[1], n_pin, q[2], q[3], q[4]);
+        VILA_REQUIRE(q[1] % q[2] == 0 && gd % q[3] == 0 && gd % q[4] == 0,
+                     "shape '[%d, %d, %d]' is invalid for pooling by (%d, %d, %d): every pooled dimension must divide evenly", q[1], gd, gd, q[2], q[3], q[4]);
+        VILA_REQUIRE(q[6] == (q[1] / q[2]) * (gd / q[3]) * (gd / q[4]) && q[5] >= Mp_ && q[5] + q[6] <= Mbuf, "sft: pools[%d]: rows %d..%d outside the pooled part %d..%d of the buffer",
+                     i, q[5], q[5] + q[6], Mp_, Mbuf);
+    }
     int s2_splits[4] = {1, 1, 1, 1};
     for (int k = 0; s2 && k < b->s2_n_scales - 1 && k < 4; ++k) s2_splits[k] = b->s2_splits[k];
     std::vector<VitSaved> vsv(vs.n_layers_run);
@@ -167,7 +179,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         p_y = a.take<bf16_t>((size_t)Mp_ * C1); p_yn = a.take<bf16_t>((size_t)Mp_ * C1);
         RUN(launch_space_to_depth(x, p_y, n_pin, g_, Dp, kdown, c.s));
         RUN(launch_layernorm(p_y, B(pj->ln1_w), B(pj->ln1_b), p_yn, Mp_, C1, 1e-5f, c.s));
-        proj = a.take<bf16_t>((size_t)Mp_ * H);
+        proj = a.take<bf16_t>((size_t)Mbuf * H);                      // [projector rows | pooled rows]
         if (kdown == 2) {
             p_z1 = a.take<bf16_t>((size_t)Mp_ * H); p_h1 = a.take<bf16_t>((size_t)Mp_ * H);
             VILA_TRY(gemm(c, p_yn, C1, B(pj->fc1_w), C1, B(pj->fc1_b), nullptr, 0, p_z1, H, Mp_, H, C1));
@@ -184,6 +196,12 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
             RUN(launch_act_fwd(p_z2, p_h2, (int64_t)Mp_ * H, 2, c.s));
             VILA_TRY(gemm(c, p_h2, H, B(pj->fc3_w), H, B(pj->fc3_b), nullptr, 0, proj, H, Mp_, H, H));
         }
+    }
+
+    // pooled rows of a pooling video encoder (tsp.py:28-52), behind the projector's rows
+    for (int i = 0; i < n_pools; ++i) {
+        const int32_t* q = b->pools + 7 * i;
+        RUN(launch_video_pool(proj + (size_t)q[0] * Tm * H, proj + (size_t)q[5] * H, q[1], gd, H, q[2], q[3], q[4], nullptr, 0, nullptr, 0, c.s));
     }
 
     // ================= splice into the packed row (llava_arch.py:412-490, 744-800: planned on the host) =================
@@ -314,9 +332,13 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     if (n_img == 0) return 0;
 
     // ================= projector backward =================
-    bf16_t* dproj = a.take<bf16_t>((size_t)Mp_ * H);
-    if (!c.dry) VILA_HIP(hipMemsetAsync(dproj, 0, (size_t)Mp_ * H * 2, c.s));            // rows cut off by the truncation keep a zero gradient
+    bf16_t* dproj = a.take<bf16_t>((size_t)Mbuf * H);
+    if (!c.dry) VILA_HIP(hipMemsetAsync(dproj, 0, (size_t)Mbuf * H * 2, c.s));           // rows cut off by the truncation keep a zero gradient
     if (b->n_feat > 0) RUN(launch_copy_rows(dx, dproj, b->feat_dst, b->feat_src, b->n_feat, H, c.s));
+    for (int i = 0; i < n_pools; ++i) {                                                   // pooled rows' gradients back onto their frames' rows
+        const int32_t* q = b->pools + 7 * i;
+        RUN(launch_video_pool_bwd(dproj + (size_t)q[5] * H, dproj + (size_t)q[0] * Tm * H, q[1], gd, H, q[2], q[3], q[4], 1, c.s));
+    }
     bf16_t* dz1 = nullptr;
     if (kdown == 2) {
         bf16_t* dh1 = a.take<bf16_t>((size_t)Mp_ * H);

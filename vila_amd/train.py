@@ -664,10 +664,7 @@ class SFTTrainer:
         n_img = len(images)                             # tiles (dynamic_s2: the tiles of every scale of every image; videos: their frames)
         pixels = torch.stack(list(images), 0).to(device=dev, dtype=torch.bfloat16).contiguous() if n_img else None
         s2, rows, n_pin = self._media_plan(n_img, self._block_sizes_with_frames(block_sizes, frames))
-        img_blocks, vid_blocks, pools, _ = self._media_blocks(rows, frames, n_pin * cfg.tokens_per_tile)
-        if pools:
-            raise NotImplementedError("vila_sft_fwd_bwd has no pooling stage: a pooling video encoder (TSPVideoEncoder) trains through the "
-                                      "operator-orchestrated driver (SFTTrainer.forward_backward, VILA_SFT_C_ABI=0)")
+        img_blocks, vid_blocks, pools, n_buf = self._media_blocks(rows, frames, n_pin * cfg.tokens_per_tile)
         plan = self._splice(input_ids, attention_mask, labels, img_blocks, vid_blocks)
         rp = repack(plan.mask, plan.labels)
         T = int(rp.rows.numel())
@@ -700,6 +697,9 @@ class SFTTrainer:
             b.s2_desc, b.s2_tile_desc, b.s2_n_blocks, b.s2_n_scales = P(s2_desc), P(s2_tdesc), n_pin, len(cfg.s2_scales)
             for k, v in enumerate(s2.splits[:4]):
                 b.s2_splits[k] = int(v)
+        if pools:                                         # TSPVideoEncoder: the pooled rows behind the projector's (host array, read during the call)
+            pool_arr = (C.c_int32 * (7 * len(pools)))(*[int(x) for b0, nf, pool, off, cnt in pools for x in (b0, nf, *pool, off, cnt)])
+            b.pools, b.n_pools, b.n_media_rows = C.cast(pool_arr, C.c_void_p), len(pools), n_buf
         if getattr(self, "_cw", None) is None:
             self._cw = self._c_structs(lambda n: flat.param(n).data_ptr())
             self._cg = self._c_structs(lambda n: flat.grad(n).data_ptr())
