@@ -214,3 +214,46 @@ def test_oracle_autograd_equals_the_reference_executed_gradients(golden_dir):
             assert err < 2e-3, f"{name}: leading values rel {err:.2e}"
         worst = max(worst, (name, err), key=lambda t: t[1])
     print(f"oracle autograd vs reference-executed gradients: worst leading-value deviation {worst[1]:.2e} ({worst[0]})")
+
+
+def test_oracle_autograd_through_the_pooling_video_encoder_equals_the_reference_executed_gradients(golden_dir):
+    """Row a13 over row a7: tests/golden/tiny_sft_grads_video.npz holds the gradients torch autograd produces through the REFERENCE'S own
+    `TSPVideoEncoder._process_features` / `pool` (ast-extracted, executed unchanged), its SigLIP + projector and HF Qwen2 — an image and two
+    4-frame videos, pool sizes [[2,2,1],[1,1,1]], start / end / separator tokens (oracle/make_golden_grads_video.py).  Autograd through the oracle's
+    restatement on the same weights and batch gives the same loss, the same gradient for every one of the 86 parameter tensors, and the same
+    embedding-gradient rows for the encoder's own tokens."""
+    import os
+    from oracle.make_golden_grads_video import case
+    path = os.path.join(golden_dir, "tiny_sft_grads_video.npz")
+    if not os.path.exists(path):
+        pytest.skip("video gradient fixture not present")
+    fx = np.load(path)
+    cfg, w, px, ids, labels, mask = case()
+    assert np.array_equal(ids.numpy(), fx["input_ids"]) and np.array_equal(labels.numpy(), fx["labels"])
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    enc = {"pool_sizes": fx["pool_sizes"].tolist(), "start_ids": fx["start_ids"].tolist(), "end_ids": fx["end_ids"].tolist(), "sep_ids": fx["sep_ids"].tolist()}
+    blocks = O.tsp_video_encoder([px[1:5], px[5:9]], w, cfg, enc["pool_sizes"], enc["sep_ids"], enc["start_ids"], enc["end_ids"])
+    assert [int(b.shape[0]) for b in blocks] == fx["video_block_rows"].tolist()
+    loss = O.vlm_sft_loss([px[0]], ids, labels, mask, wr, cfg, num_items_in_batch=int(fx["num_items"]), packed=True, videos=[px[1:5], px[5:9]], video_encoder=enc)
+    assert abs(float(loss) - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"])), (float(loss), float(fx["loss"]))
+    loss.backward()
+    names = [str(n) for n in fx["names"]]
+    assert len(names) == 86
+    worst = ("", 0.0)
+    for i, name in enumerate(names):
+        g = wr[name].grad
+        g = torch.zeros_like(wr[name]) if g is None else g
+        gn, gv = float(fx[f"gn_{i}"]), torch.from_numpy(fx[f"gv_{i}"])
+        if gn < 1e-6:
+            assert float(g.norm()) < 1e-6, name
+            continue
+        assert abs(float(g.double().norm()) / gn - 1) < 2e-4, f"{name}: |grad| {float(g.norm()):.6e} vs reference {gn:.6e}"
+        lead = g.reshape(-1)[:64]
+        err = float((lead - gv).norm() / max(float(gv.norm()), 1e-12 * gn))
+        if float(gv.norm()) > 1e-3 * gn / (g.numel() ** 0.5) * 8:
+            assert err < 2e-3, f"{name}: leading values rel {err:.2e}"
+        worst = max(worst, (name, err), key=lambda t: t[1])
+    rows = torch.from_numpy(fx["token_rows"])
+    got, want = wr["llm.model.embed_tokens.weight"].grad[rows], torch.from_numpy(fx["token_row_grads"])
+    assert float(want.norm()) > 0 and float((got - want).norm() / want.norm()) < 1e-4
+    print(f"oracle autograd (TSPVideoEncoder) vs reference-executed gradients: worst leading-value deviation {worst[1]:.2e} ({worst[0]})")
