@@ -153,10 +153,29 @@ def test_w4_decode_tiny_vs_oracle():
     _decode_case(cfg, 3, (-7, -6, -5), 12, 8)
 
 
-def test_w4_decode_8b_widths_vs_oracle():
+@pytest.mark.parametrize("n_prompt", [16, 560])
+def test_w4_decode_8b_widths_vs_oracle(n_prompt):
+    """hd = 128: the decode attention runs per-head blocks over 256-key slices and the W4 o_proj kernel merges the slices in its prologue
+    (`gemv_w4_kernel<4>`); contexts of 273+ (two slices) and 817+ (four) keys.  The sliced path against the one-block-per-head attention +
+    plain W4 o_proj (`vila_decode_force_attn(0)`): same logits up to the merge's rounding."""
+    from vila_amd import _lib
     cfg = configs.reduced_8b(layers_v=2, layers_l=2, vocab=32000)
     cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
-    _decode_case(cfg, 5, (-9, -8, -7), 16, 5)
+    model = _decode_case(cfg, 5, (-9, -8, -7), n_prompt, 5)
+    px = synthetic.make_pixels(cfg, 1, 5).to(torch.bfloat16)
+    ids = synthetic.make_prompt(cfg, n_prompt, 1, 5)[None]
+    e, _, _ = model._embed(ids, {"image": [px[0].cuda()]})
+    lib = _lib.load()
+    try:
+        _, lg_sliced = model.llm.generate(inputs_embeds=e, max_new_tokens=5, return_logits=True, use_graph=False, eos_token_id=-1)
+        lib.vila_decode_force_attn(0)
+        model.llm._drop_decode_session()                       # the eager session holds no captured graph, but start clean
+        _, lg_plain = model.llm.generate(inputs_embeds=e, max_new_tokens=5, return_logits=True, use_graph=False, eos_token_id=-1)
+    finally:
+        lib.vila_decode_force_attn(2)
+        model.llm._drop_decode_session()
+    assert rel_l2(lg_sliced[1:], lg_plain[1:]) < 1e-2, rel_l2(lg_sliced[1:], lg_plain[1:])
+    assert not torch.equal(lg_sliced[1:], lg_plain[1:]) or n_prompt < 0          # (two different kernels really ran)
 
 
 def test_w4_refuses_ungrouped_k():

@@ -891,6 +891,7 @@ static int decode_step_w4_impl(const VilaLlmWeights* w, const VilaLlmLayerW4* ql
     bf16_t* ao = a.take<bf16_t>(QS);
     void* smp_ws = a.take<char>(sample_workspace_bytes());
     VILA_REQUIRE(a.ok(), "llm_decode_w4: workspace arena overflow");
+    const bool split256 = decode_attn_mode() >= 1 && cache->max_ctx <= 2048 && hd == 128 && QS <= 7 * 16 * 128;   // as the bf16 step (§4.3)
     VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s));
     bf16_t* cur = x; bf16_t* nxt = x2;
     for (int l = 0; l < sh.n_layers; ++l) {
@@ -906,9 +907,11 @@ static int decode_step_w4_impl(const VilaLlmWeights* w, const VilaLlmLayerW4* ql
         AttnDecodeArgs ad{};
         ad.q = q; ad.kcache = kc; ad.vcache = vc; ad.o = ao; ad.part_o = part_o; ad.part_ml = part_ml; ad.pos_ptr = st->pos;
         ad.nq = sh.q_heads; ad.nkv = sh.kv_heads; ad.hd = hd; ad.max_ctx = cache->max_ctx; ad.n_splits = ns; ad.scale = 1.0f / sqrtf((float)hd);
+        ad.split256 = split256 ? 1 : 0;                        // per-head blocks over 256-key slices; the slices meet in the o_proj kernel's prologue
         VILA_TRY(launch_attn_decode(ad, s));
         GemvW4Args o{};
         o.x = ao; o.Wq = (const uint32_t*)Q.o_q; o.Wsz = (const uint32_t*)Q.o_sz; o.residual = cur; o.y = nxt; o.N = H; o.K = QS; o.mode = 0;
+        if (split256) { o.mode = 4; o.part_o = part_o; o.part_ml = part_ml; o.pos_ptr = st->pos; o.n_splits = cdiv(cache->max_ctx, 256); o.split_keys = 256; }
         VILA_TRY(launch_gemv_w4(o, s));
         GemvW4Args gu{};
         gu.x = nxt; gu.norm_w = B(L.ln2_w); gu.eps = sh.rms_eps; gu.Wq = (const uint32_t*)Q.gateup_q; gu.Wsz = (const uint32_t*)Q.gateup_sz;

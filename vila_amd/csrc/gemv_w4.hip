@@ -96,7 +96,48 @@ __device__ __forceinline__ void stage_x_w4(const bf16_t* __restrict__ x, const b
     __syncthreads();
 }
 
-// MODE 0: y = W x (+bias)(+residual) ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
+// stage x = the merge of the decode attention's per-slice partials (the flash-decoding combine of gemv.hip's stage_x_attn, here for the
+// W4 o_proj): o[h][d] = sum_s exp(m_s - M) part_o[s][h][d] / sum_s exp(m_s - M) l_s, rounded to bf16 like the attention output, plus the
+// group sums of the rounded values.  Heads are 128 wide = one quantisation group = 16 chunks of 8.
+__device__ __forceinline__ void stage_x_attn_w4(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active, int nq,
+                                                bf16_t* sx, float* xg, float* wsm /* [n_active * nq] */) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int h = tid; h < nq; h += nt) {
+        float M = -INFINITY;
+        for (int s = 0; s < n_active; ++s) M = fmaxf(M, part_ml[((int64_t)s * nq + h) * 2]);
+        float L = 0.f;
+        for (int s = 0; s < n_active; ++s) {
+            const float* ml = part_ml + ((int64_t)s * nq + h) * 2;
+            L += __expf(ml[0] - M) * ml[1];
+        }
+        const float invL = 1.f / L;
+        for (int s = 0; s < n_active; ++s) wsm[s * nq + h] = __expf(part_ml[((int64_t)s * nq + h) * 2] - M) * invL;
+    }
+    __syncthreads();
+    const int nch = nq * 16;                                    // chunks of 8; a multiple of 16, so aligned 16-lane groups are in range together
+    for (int c = tid; c < nch; c += nt) {
+        const int h = c >> 4;
+        float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_active; ++s) {
+            const float* src = part_o + ((int64_t)s * nq) * 128 + c * 8;
+            const f32x4 p0 = *(const f32x4*)src, p1 = *(const f32x4*)(src + 4);
+            const float w = wsm[s * nq + h];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e[k] = fmaf(w, p0[k], e[k]); e[4 + k] = fmaf(w, p1[k], e[4 + k]); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = pack2bf(e[2 * k], e[2 * k + 1]); e[2 * k] = lo_bf(o[k]); e[2 * k + 1] = hi_bf(o[k]); }
+        *(u32x4*)(sx + c * 8) = o;
+        float a = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
+        if ((c & 15) == 0) xg[h] = a;
+    }
+    __syncthreads();
+}
+
+// MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
 // (q/k rows interleaved so RoPE partners i, i + hd/2 are neighbours).  UB = groups (KB) per wave and item; PIPE = the next
 // item's weights are issued before the current item is consumed (persistent blocks walking several tiles).
 template <int MODE, int UB, bool PIPE>
@@ -132,7 +173,7 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     auto epi_fetch = [&](int tile_) {
         if (tid >= 16) return;
         const int pr = tile_ * 16 + tid;
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 4) {
             if (pr < p.N) {
                 e0 = p.bias != nullptr ? bf2f(p.bias[pr]) : 0.f;
                 e1 = p.residual != nullptr ? bf2f(p.residual[pr]) : 0.f;
@@ -157,7 +198,12 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     uint32_t sa[UB], sb[PIPE ? UB : 1];
     issue(tile, gb, wa, sa);
     epi_fetch(tile);
-    stage_x_w4(p.x, p.norm_w, p.eps, K, sx, xg, scratch);
+    if constexpr (MODE == 4) {
+        const int n_active = (*p.pos_ptr + p.split_keys) / p.split_keys;     // ceil((pos + 1) / split_keys)
+        stage_x_attn_w4(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
+    } else {
+        stage_x_w4(p.x, p.norm_w, p.eps, K, sx, xg, scratch);
+    }
 
     float total = 0.f;
     for (;;) {
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
                 float v = 0.f, vp = 0.f;                        // own row and the partner row (n ^ 1)
                 for (int i = 0; i < W; ++i) { v += rd[i * 16 + tid]; vp += rd[i * 16 + (tid ^ 1)]; }
                 const int pr = tile * 16 + tid;                 // packed row
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 4) {
                     if (pr < p.N) {
                         v += e0;
                         if (p.residual != nullptr) v = bfround(v) + e1;
@@ -263,11 +309,17 @@ int launch_gemv_w4(const GemvW4Args& a, hipStream_t s) {
     const int resident = 256 * (16 / W);
     const bool pipe = n_tiles > resident;
     const int grid = pipe ? resident : n_tiles;
-    const size_t lds = (size_t)a.K * 2 + (size_t)G * 4 + 2 * W4_MAX_WAVES * 16 * 4 + W4_MAX_WAVES * 4;
+    size_t lds = (size_t)a.K * 2 + (size_t)G * 4 + 2 * W4_MAX_WAVES * 16 * 4 + W4_MAX_WAVES * 4;
+    if (a.mode == 4) {
+        VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.n_splits > 0 && a.split_keys > 0 && !deep,
+                     "gemv_w4: attention-merge mode needs the partials, the position and K <= %d", 7 * W4_MAX_WAVES * 128);
+        lds += (size_t)a.n_splits * G * 4;                     // the merge weights [n_splits][heads]
+    }
     VILA_REQUIRE(lds <= 160 * 1024, "gemv_w4: K=%d does not fit the 160 KB LDS", a.K);
 #define W4_LAUNCH(MODE, UB_, PIPE_) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles)
     if (a.mode == 1) { if (pipe) W4_LAUNCH(1, 7, true); else W4_LAUNCH(1, 7, false); }
     else if (a.mode == 3) W4_LAUNCH(3, 7, false);
+    else if (a.mode == 4) { if (pipe) W4_LAUNCH(4, 7, true); else W4_LAUNCH(4, 7, false); }
     else if (deep) W4_LAUNCH(0, 10, false);
     else if (pipe) W4_LAUNCH(0, 7, true);
     else W4_LAUNCH(0, 7, false);
