@@ -1,13 +1,16 @@
 #!/bin/bash
+# VAL_LIGHT=1: the test-suite, one SFT line, the default bench line, the other modes, smoke and the two kernel traces only (no PMC passes,
+# no batch / Lite-3B / C-ABI / forced-group lines) — for a late re-validation when only a few GPU-minutes are left.
 # Full GPU validation pass: test-suite, every bench line (default, SFT, C-ABI SFT, forced process group, other modes), MFMA counters,
 # kernel traces and the TTFT timeline.  Run on the GPU box from the repo root (gpurun -- bash tools/validate_gpu.sh); results under gpurun_out/.
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p "$O"
 timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -25 > "$O/val_pytest.log"
 tail -3 "$O/val_pytest.log"
-for i in 1 2; do
+for i in 1 $([ -z "$VAL_LIGHT" ] && echo 2); do
   timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_$i.err" | tee "$O/val_sft_$i.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
 done
+if [ -z "$VAL_LIGHT" ]; then
 VILA_SFT_C_ABI=1 timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_c.err" | tee "$O/val_sft_c.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft c-abi ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
 VILA_BENCH_FORCE_DIST=1 timeout 300 python bench.py --mode sft --steps 3 --warmup 1 2>"$O/val_sft_forcedist.err" | tee "$O/val_sft_forcedist.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[0]); print('sft force-dist (nccl, world 1) ->', d['ms_per_step'], 'ms')"
 # the default line with the process group forced up in a world of one: the SFT side measurement takes the RCCL path the driver's --gpus N takes
@@ -17,6 +20,7 @@ import json
 d = json.loads(open('gpurun_out/val_bench_forcedist.json').read()); s = d.get('sft') or {}
 print('bench (forced nccl group, world 1): value', d['value'], '| sft', s.get('ms_per_step'), 'ms, exchange_active', s.get('exchange_active'), 'bytes', s.get('exchange_bytes'), s.get('error'))
 "
+fi
 timeout 600 python bench.py > "$O/val_bench.json" 2> "$O/val_bench.err"
 python - <<'P'
 import json
@@ -38,6 +42,7 @@ for line in open("gpurun_out/val_other_modes.jsonl"):
     except Exception as e:
         print("bad line", e)
 P
+if [ -z "$VAL_LIGHT" ]; then
 : > "$O/val_batch_decode.jsonl"
 for b in 2 4 8 16; do
   timeout 300 python bench.py --batch $b --steps 32 --warmup 4 2>>"$O/val_batch_decode.err" | tail -1 >> "$O/val_batch_decode.jsonl"
@@ -53,7 +58,9 @@ python -c "
 import json
 d = json.loads(open('gpurun_out/val_bench_lite3b.json').read().strip().splitlines()[-1]); print('lite-3b', d['value'], d['unit'], 'ttft', d.get('ttft_ms'))
 "
+fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+if [ -z "$VAL_LIGHT" ]; then
 timeout 600 bash tools/pmc.sh val --no-sft --no-sustain --steps 8 --warmup 2 | tail -2
 for CTR in FETCH_SIZE WRITE_SIZE; do
   DB=$(find "$O/pmc_val_$CTR" -name "*.db" | head -1)
@@ -69,6 +76,7 @@ timeout 900 bash tools/pmc_mfma.sh val_sft --mode sft --steps 2 --warmup 1 | tai
 cp "$O/pmc_mfma_val_sft/summary.txt" "$O/val_pmc_mfma_sft_step.txt" 2>/dev/null
 timeout 600 bash tools/pmc_mfma.sh val_ttft --no-sft --no-sustain --steps 8 --warmup 2 | tail -1
 cp "$O/pmc_mfma_val_ttft/summary.txt" "$O/val_pmc_mfma_ttft_decode.txt" 2>/dev/null
+fi
 timeout 600 bash tools/profile.sh val_sft --mode sft --steps 3 --warmup 1 2>&1 | tail -1
 if [ -f "$O/prof_val_sft/trace_results.db" ]; then
   python tools/rocpd_summary.py "$O/prof_val_sft/trace_results.db" "$O/val_sft_kernel_stats.csv"; rm -f "$O/prof_val_sft/trace_results.db"
@@ -80,4 +88,4 @@ if [ -f "$O/prof_val/trace_results.db" ]; then
   rm -f "$O/prof_val/trace_results.db"
 fi
 find "$O" -name "*.db" -size +1M -delete
-head -8 "$O/val_pmc_mfma_sft_step.txt"
+[ -z "$VAL_LIGHT" ] && head -8 "$O/val_pmc_mfma_sft_step.txt"; true
