@@ -31,7 +31,7 @@ except Exception as e:
     print("bench parse failed", e)
 P
 : > "$O/val_other_modes.jsonl"
-for args in "--w4" "--w8-vit" "--dynamic-s2" "--mode video" "--mode video --tsp"; do
+for args in "--w4" "--w8-vit" "--dynamic-s2" "--mode video" "--mode video --tsp" "--prompt-tokens 32"; do
   timeout 400 python bench.py $args --no-sft --no-sustain --no-cpu-baseline 2>>"$O/val_other_modes.err" | tail -1 >> "$O/val_other_modes.jsonl"
 done
 python - <<'P'

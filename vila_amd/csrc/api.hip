@@ -285,7 +285,7 @@ extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T)
     b += align_up((size_t)T * F * 2, 256);                     // act
     b += 2 * align_up((size_t)T * (s->head_dim / 2) * 4, 256); // rope cos/sin
     b += align_up((size_t)(T > 8 ? T : 8) * H * 2, 256);       // gathered last rows / final norm (the pruned last layer keeps 2 x n_last <= 8 rows there)
-    b += align_up((size_t)6 * T * H * 4, 256);                 // split-K fp32 slabs (down_proj; tail round of gate/up) at small T
+    b += align_up((size_t)8 * T * H * 4, 256);                 // split-K fp32 slabs (down_proj: up to 8 slices; tail round of gate/up) at small T
     return b + 8192;
 }
 
@@ -308,8 +308,8 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
     float* cs = a.take<float>((size_t)T * hd / 2);
     float* sn = a.take<float>((size_t)T * hd / 2);
     bf16_t* lastbuf = a.take<bf16_t>((size_t)(T > 8 ? T : 8) * H);
-    float* skws = a.take<float>((size_t)6 * T * H);
-    const size_t skws_bytes = (size_t)6 * T * H * 4;
+    float* skws = a.take<float>((size_t)8 * T * H);
+    const size_t skws_bytes = (size_t)8 * T * H * 4;
     VILA_REQUIRE(a.ok(), "llm_prefill: workspace arena overflow");
     if (cache != nullptr) VILA_REQUIRE(max_seqlen <= cache->max_ctx, "llm_prefill: sequence (%d) longer than the KV cache (%d)", max_seqlen, cache->max_ctx);
 
