@@ -198,6 +198,15 @@ int main(int argc, char** argv) {
         };
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
     }
+    if (!strcmp(what, "presmall")) {   // short prompts (text-only chat, one image + a short question), cold weights: automatic choice vs split-K 256^2 vs the 128x64 ring
+        g_cold = 1;
+        std::vector<Case> pc = {
+            {"LLM down+res M=64", 64, 3584, 18944, 0, 0, 1}, {"LLM down+res M=160", 160, 3584, 18944, 0, 0, 1}, {"LLM down+res M=289", 289, 3584, 18944, 0, 0, 1},
+            {"LLM qkv M=64", 64, 4608, 3584, 0, 0, 0}, {"LLM qkv M=289", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=64", 64, 3584, 3584, 0, 0, 1}, {"LLM o+res M=289", 289, 3584, 3584, 0, 0, 1},
+        };
+        for (auto& c : pc) run_case(c, {300, 305, 307, 300, 305, 307}, ws, ws_bytes);
+        g_cold = 0;
+    }
     if (!strcmp(what, "precold")) {    // the same question with COLD weights (what a forward pass sees), one and eight images, S = 769 prefill
         g_cold = 1;
         std::vector<Case> pc = {

@@ -226,11 +226,12 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (sel == 4) sel = 0;
     }
     // under-filled grid of 256^2 tiles (S = 769 prefill: 56 tiles for N = 3584): slice K over grid.y when a workspace is given
-    // (M >= 512 for the short contractions; a LONG contraction — down_proj, K = 18944 — is sliced from M = 192 on: at S = 289 (one image + a
-    // 32-token prompt, BASELINE configs[1]'s short prompt) the ring kernel walked 296 K-tiles per block, 149 us per layer, where 2 x 14 tiles x 8
-    // slices take 56 us incl. the reduce: TTFT 13.2 -> 10.7 ms, profiles/r04_ttft_s289_ab.log)
+    // (M >= 512 for the short contractions; a LONG contraction — down_proj, K = 18944 — is sliced at ANY M: at S = 289 (one image + a 32-token
+    // prompt, BASELINE configs[1]'s short prompt) the ring kernel walked 296 K-tiles per block, 149 us per layer, where 2 x 14 tiles x 8 slices
+    // take 57 + 11 us incl. the reduce: TTFT 13.2 -> 12.0 ms, profiles/r04_ttft_s289_ab.log; text-only prompts of 64 / 160 rows:
+    // profiles/r04_gemm_bench_presmall.log)
     const int kt_all_ = cdiv(a.K, 64);
-    if ((sel == 0 || sel == 5) && EPI == EPI_NONE && !OUT_F32 && a.ws != nullptr && (a.M >= 512 || (a.M >= 192 && kt_all_ >= 128)) && gemm256_supported(a)) {
+    if ((sel == 0 || sel == 5) && EPI == EPI_NONE && !OUT_F32 && a.ws != nullptr && (a.M >= 512 || kt_all_ >= 128) && gemm256_supported(a)) {
         const int kt = kt_all_;
         // as many K-slices as keep every block resident at once (one 512-thread block per CU), at most 8, at least 8 K-tiles each;
         // slices need not be equal (the last one takes the remainder): 42 tiles x 6 slices fills 252 CUs where 4 would fill 168
