@@ -257,3 +257,53 @@ def test_oracle_autograd_through_the_pooling_video_encoder_equals_the_reference_
     got, want = wr["llm.model.embed_tokens.weight"].grad[rows], torch.from_numpy(fx["token_row_grads"])
     assert float(want.norm()) > 0 and float((got - want).norm() / want.norm()) < 1e-4
     print(f"oracle autograd (TSPVideoEncoder) vs reference-executed gradients: worst leading-value deviation {worst[1]:.2e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("name", ["eval_right", "eval_left", "train_trunc", "train_tsp"])
+def test_embed_splice_and_repack_equal_the_reference_executed_run(golden_dir, name):
+    """Rows a6-a9: tests/golden/embed_splice_ref.npz is the output of the REFERENCE'S OWN `_embed` / `__truncate_sequence` / `__batchify_sequence` /
+    `repack_multimodal_data` / `encode_images` and encoder classes (ast-extracted from llava_arch.py and encoders/*, executed unchanged over the
+    reference SigLIP + projector; oracle/make_golden_embed.py): three ragged samples with image and video tokens, a media id hidden in the padding,
+    both padding sides, training-mode truncation through the middle of a video block, the pooling video encoder.  (1) the oracle's restatement
+    reproduces embeddings, labels, mask and the packed row; (2) so does the HOST plan the HIP path executes (`vila_amd.host.splice_plan` /
+    `repack`: integers exactly, embeddings by gathering the rows the plan names)."""
+    import os
+    from oracle.make_golden_embed import case
+    from vila_amd import host
+    path = os.path.join(golden_dir, "embed_splice_ref.npz")
+    if not os.path.exists(path):
+        pytest.skip("embed fixture not present")
+    fx = np.load(path)
+    cfg = configs.tiny("mlp_downsample")
+    w, px, ids, labels, mask = case(cfg)
+    assert np.array_equal(ids.numpy(), fx["input_ids"]) and np.array_equal(mask.numpy(), fx["mask"])
+    side = "left" if name == "eval_left" else "right"
+    max_len = int(fx["train_trunc_max_len"]) if name == "train_trunc" else None
+    imgs = O.basic_image_encoder([px[0], px[1]], w, cfg)
+    vids = O.tsp_video_encoder([px[2:5]], w, cfg, fx["train_tsp_pools"].tolist()) if name == "train_tsp" else O.basic_video_encoder([px[2:5]], w, cfg)
+    want_e, want_l, want_m = (torch.from_numpy(fx[f"{name}_{k}"]) for k in ("embeds", "labels", "mask"))
+    # (1) the oracle
+    e, l, m = O.embed_splice(ids, {"image": [t.clone() for t in imgs], "video": [t.clone() for t in vids]}, w, cfg, labels=labels, attention_mask=mask,
+                             padding_side=side, max_length=max_len)
+    assert e.shape == want_e.shape and torch.equal(l, want_l) and torch.equal(m, want_m)
+    assert float((e - want_e).abs().max()) < 2e-5 * float(want_e.abs().max())
+    pe, pm, pp, pl, seqlens = O.repack(e, m, l)
+    assert torch.equal(pm, torch.from_numpy(fx[f"{name}_packed_mask"])) and torch.equal(pp, torch.from_numpy(fx[f"{name}_packed_pos"]))
+    assert torch.equal(pl, torch.from_numpy(fx[f"{name}_packed_labels"]).to(pl.dtype))
+    assert float((pe - torch.from_numpy(fx[f"{name}_packed_embeds"])).abs().max()) < 2e-5 * float(want_e.abs().max())
+    # (2) the host plan of the HIP path
+    plan = host.splice_plan(ids, mask, labels, {"image": [int(t.shape[0]) for t in imgs], "video": [int(t.shape[0]) for t in vids]},
+                            {"image": cfg.image_token_id, "video": cfg.video_token_id}, side, max_length=max_len)
+    assert torch.equal(plan.labels, want_l) and torch.equal(plan.mask, want_m)
+    table, H = w["llm.model.embed_tokens.weight"], cfg.llm.hidden_size
+    flat = torch.cat(list(imgs) + list(vids), 0)                       # the flat media space: images, then videos (host.splice_plan)
+    got = torch.zeros(plan.B * plan.S, H)
+    got[plan.txt_dst.long()] = table[plan.txt_src.long()]
+    got[plan.img_dst.long()] = flat[plan.img_src.long()]
+    assert float((got.view(plan.B, plan.S, H) - want_e).abs().max()) < 2e-5 * float(want_e.abs().max())
+    rp = host.repack(plan.mask, plan.labels)
+    n = int(rp.rows.numel())                                            # the reference's trailing dummy token is never materialised (host.repack)
+    assert n + 1 == fx[f"{name}_packed_pos"].shape[1]
+    assert torch.equal(rp.position_ids, torch.from_numpy(fx[f"{name}_packed_pos"])[0, :n])
+    assert torch.equal(rp.labels, torch.from_numpy(fx[f"{name}_packed_labels"])[0, :n].to(rp.labels.dtype))
+    assert rp.seqlens.tolist() == want_m.sum(1).tolist()
