@@ -5,6 +5,7 @@
 `ast` and exec'd UNCHANGED inside a class of the same name (`LlavaMetaForCausalLM`, so the double-underscore names mangle as in the reference):
     llava/model/llava_arch.py:   LlavaMetaForCausalLM._embed (412-490), .__embed_media_tokens (492-517), .__truncate_sequence (519-526),
                                  .__batchify_sequence (528-555), .repack_multimodal_data (557-800); LlavaMetaModel.encode_images (366-394)
+    llava/model/utils/packing.py: _get_unpad_data, set_seqlens_in_batch (12-25)   — the varlen description of the packed row
     llava/model/encoders/base.py: BaseEncoder;  encoders/image/basic.py: BasicImageEncoder;  encoders/video/basic.py: BasicVideoEncoder;
     encoders/video/tsp.py: pool, TSPVideoEncoder                                                          (whole classes, unchanged)
 The shim supplies only what the methods reach for: `self.llm.model.embed_tokens` (an nn.Embedding holding the synthetic table), `self.tokenizer`
@@ -89,6 +90,10 @@ def load_reference():
     exec(compile(_class_source(f"{REF}/encoders/video/basic.py", "BasicVideoEncoder"), "encoders/video/basic.py", "exec"), ns)
     exec(compile(_function_source(f"{REF}/encoders/video/tsp.py", "pool"), "encoders/video/tsp.py", "exec"), ns)
     exec(compile(_class_source(f"{REF}/encoders/video/tsp.py", "TSPVideoEncoder"), "encoders/video/tsp.py", "exec"), ns)
+    # flash-attn varlen description of the packed row (llava/model/utils/packing.py:12-25), as llava_llama.py:125-130 sets it up
+    ns["F"] = torch.nn.functional
+    exec(compile(_function_source(f"{REF}/utils/packing.py", "_get_unpad_data"), "utils/packing.py", "exec"), ns)
+    exec(compile(_function_source(f"{REF}/utils/packing.py", "set_seqlens_in_batch"), "utils/packing.py", "exec"), ns)
     body = "\n\n".join(_methods_source(f"{REF}/llava_arch.py", "LlavaMetaModel", MODEL_METHODS) +
                        _methods_source(f"{REF}/llava_arch.py", "LlavaMetaForCausalLM", ARCH_METHODS))
     exec(compile("class LlavaMetaForCausalLM(torch.nn.Module):\n" + body + "\n", "llava_arch.py", "exec"), ns)
@@ -167,7 +172,10 @@ def main():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")           # the reference warns when it truncates
                 e, l, am = m._embed(ids.clone(), media(), {"image": {}, "video": {}}, labels.clone(), mask.clone())
+            ns["set_seqlens_in_batch"](torch.sum(am, dim=1))                       # llava_llama.py:126-128
             pe, pm, pp, pl = m.repack_multimodal_data(e, am, None, l)
+            idx, cu, mx = ns["_get_unpad_data"](pm)                              # what HF's flash-attention path asks for the packed row
+            fx[f"{name}_unpad_indices"], fx[f"{name}_cu_seqlens"], fx[f"{name}_max_seqlen"] = idx.numpy(), cu.numpy(), np.int64(mx)
             for k, t in (("embeds", e), ("labels", l), ("mask", am), ("packed_embeds", pe), ("packed_mask", pm), ("packed_pos", pp), ("packed_labels", pl)):
                 fx[f"{name}_{k}"] = t.numpy()
             print(f"{name}: embeds {tuple(e.shape)}, seqlens {am.sum(1).tolist()}, packed {tuple(pe.shape)}")

@@ -307,3 +307,8 @@ def test_embed_splice_and_repack_equal_the_reference_executed_run(golden_dir, na
     assert torch.equal(rp.position_ids, torch.from_numpy(fx[f"{name}_packed_pos"])[0, :n])
     assert torch.equal(rp.labels, torch.from_numpy(fx[f"{name}_packed_labels"])[0, :n].to(rp.labels.dtype))
     assert rp.seqlens.tolist() == want_m.sum(1).tolist()
+    # the varlen description the reference hands flash-attn for the packed row (packing.py `_get_unpad_data` after `set_seqlens_in_batch`)
+    assert torch.equal(rp.cu_seqlens, torch.from_numpy(fx[f"{name}_cu_seqlens"])) and rp.max_seqlen == int(fx[f"{name}_max_seqlen"])
+    assert fx[f"{name}_unpad_indices"].tolist() == list(range(n))               # every kept row, in order; the dummy token is dropped there too
+    idx_o, cu_o, mx_o = O.get_unpad_data(pm, seqlens)
+    assert torch.equal(cu_o, torch.from_numpy(fx[f"{name}_cu_seqlens"])) and mx_o == int(fx[f"{name}_max_seqlen"]) and idx_o.tolist() == list(range(n))
