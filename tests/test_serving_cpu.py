@@ -124,6 +124,24 @@ def test_prompt_split_matches_extract_media():
     assert _split_prompt("a typed <vila/video> token") == ("a typed  token", [])     # every MEDIA_TOKENS value, not only <image>
 
 
+def test_prompt_split_equals_the_reference_executed_extract_media():
+    """tests/golden/prompt_split_ref.json = the reference's own `extract_media` (llava/utils/media.py:93-122, ast-extracted and executed with
+    the reference's MEDIA_TOKENS / make_list / Image / Video; oracle/make_golden_prompt.py) on prompts with images, a 3-frame video, typed
+    media tokens and whitespace: `_split_prompt` rewrites the text identically and collects the same number of images."""
+    import json
+    import os
+    from vila_amd.serving import MEDIA_TOKENS, Video, _split_prompt
+    path = os.path.join(os.path.dirname(__file__), "golden", "prompt_split_ref.json")
+    fx = json.load(open(path))
+    assert fx["media_tokens"] == MEDIA_TOKENS
+    assert len(fx["cases"]) >= 8
+    for c in fx["cases"]:
+        parts = [object() if p == "IMG" else Video([object()] * int(p[3:])) if p.startswith("VID") else p for p in c["parts"]]
+        text, images = _split_prompt(parts)
+        assert text == c["text"], (c["parts"], text, c["text"])
+        assert len(images) == c["n_images"]
+
+
 class _BatchModel(_Model):
     """Answers a padded batch: row b replies with the b-th canned text, then EOS, then padding."""
     texts = ["a red square", "w1 w2", "you are helpful"]

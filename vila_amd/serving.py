@@ -77,10 +77,20 @@ def load_image(url: str):
     return Image.open(io.BytesIO(base64.b64decode(m.group(2)))).convert("RGB")
 
 
+class Video:
+    """A video prompt part: its already-extracted frames (images, or one [T, H, W, 3] array).  In this snapshot of the reference a `Video` part
+    becomes `num_video_frames` `<image>` tokens and its frames join the IMAGE list (llava/utils/media.py:114-119); picking the frames out of a
+    file (`_load_video`, cv2) stays with the caller."""
+
+    def __init__(self, frames) -> None:
+        self.frames = list(frames)
+
+
 def _split_prompt(prompt: Union[str, Sequence[Any]]):
     """llava/utils/media.py:93-122 (extract_media): text with exactly one `<image>` per image part (the "\n" after an image is NOT
-    text: BasicImageEncoder appends it as an embedding, encoders/image/basic.py:22-27), images in order; media tokens typed by the
-    user inside a text part are removed and the part stripped (:104-108)."""
+    text: BasicImageEncoder appends it as an embedding, encoders/image/basic.py:22-27), images in order; a `Video` part is one `<image>`
+    per frame (:114-119); media tokens typed by the user inside a text part are removed and the part stripped (:104-108).
+    Pinned by tests/golden/prompt_split_ref.json = the reference's own function executed on the same prompts."""
     text, images = "", []
     for part in ([prompt] if isinstance(prompt, str) else prompt):
         if isinstance(part, str):
@@ -88,6 +98,9 @@ def _split_prompt(prompt: Union[str, Sequence[Any]]):
                 if token in part:
                     part = part.replace(token, "").strip()
             text += part
+        elif isinstance(part, Video):
+            images.extend(part.frames)
+            text += IMAGE_TOKEN * len(part.frames)
         else:
             images.append(part)
             text += IMAGE_TOKEN
