@@ -89,3 +89,81 @@ def test_saved_checkpoint_loads_into_the_reference_classes(tmp_path, proj, tied)
     m2 = checkpoint.load_pretrained(d, device="cpu")
     for k, t in ours.items():
         assert torch.equal(m2.state_dict()[k], t), k
+
+
+def _reference_save_pretrained():
+    """`LlavaMetaModel.save_pretrained` / get_llm / get_vision_tower / get_mm_projector (llava/model/llava_arch.py:157-220), taken from the file
+    with ast and executed unchanged inside a class of the same name (`import llava.model` itself needs deepspeed)."""
+    import ast
+    import os.path as osp
+    import textwrap
+    from collections import OrderedDict
+    path = f"{REF}/llava/model/llava_arch.py"
+    src = open(path).read()
+    want = ["save_pretrained", "get_llm", "get_vision_tower", "get_mm_projector"]
+    body = []
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == "LlavaMetaModel":
+            got = {fn.name: ast.get_source_segment(src, fn) for fn in node.body if isinstance(fn, ast.FunctionDef)}
+            body = [textwrap.indent(textwrap.dedent(got[n]), "    ") for n in want]
+    ns = {"os": os, "osp": osp, "OrderedDict": OrderedDict, "torch": torch}
+    exec(compile("class LlavaMetaModel(torch.nn.Module):\n" + "\n\n".join(body) + "\n", "llava_arch.py", "exec"), ns)
+    return ns["LlavaMetaModel"]
+
+
+@pytest.mark.parametrize("proj,tied", [("mlp_downsample", False), ("mlp_downsample_3x3_fix", True)])
+def test_checkpoint_written_by_the_reference_loads_into_the_hip_model(tmp_path, proj, tied):
+    """The other direction, with the writer being the REFERENCE'S OWN code: its `save_pretrained` (ast-extracted, executed unchanged) over HF
+    `Qwen2ForCausalLM`, the reference `SiglipVisionModel` (+ an HF `SiglipImageProcessor`, as the tower wrapper holds), the reference
+    `MultimodalProjector` and a `LlavaConfig` (llava/model/configuration_llava.py, loaded by file path) writes the three-folder layout;
+    `vila_amd.checkpoint.load_pretrained` reads the config out of it (projector type from `mm_projector_cfg`, sizes from the embedded
+    sub-configs) and every tensor arrives bit for bit."""
+    pytest.importorskip("transformers")
+    from types import SimpleNamespace
+    from transformers import SiglipImageProcessor
+    from oracle import make_golden as G
+    from vila_amd import synthetic
+    cfg = configs.tiny(proj, tied=tied)
+    w = {k: v.to(torch.bfloat16) for k, v in synthetic.make_weights(cfg, 21).items()}
+    ms, bp = G.ref_siglip(), G.ref_projector()
+    lc = G.load_by_path("ref_configuration_llava", f"{REF}/llava/model/configuration_llava.py")
+    v = cfg.vision
+    vc = ms.SiglipVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size, num_hidden_layers=v.num_hidden_layers,
+                               num_attention_heads=v.num_attention_heads, image_size=v.image_size, patch_size=v.patch_size,
+                               num_channels=v.num_channels, layer_norm_eps=v.layer_norm_eps, hidden_act="gelu_pytorch_tanh")
+    tower = ms.SiglipVisionModel(vc).to(torch.bfloat16)
+    tower.load_state_dict({k[len("vision_tower.vision_tower."):]: t for k, t in w.items() if k.startswith("vision_tower.")}, strict=False)
+    projector = bp.MultimodalProjector(bp.MultimodalProjectorConfig(cfg.mm_projector_type),
+                                       SimpleNamespace(mm_hidden_size=cfg.mm_hidden_size, hidden_size=cfg.llm.hidden_size)).to(torch.bfloat16)
+    projector.load_state_dict({k[len("mm_projector."):]: t for k, t in w.items() if k.startswith("mm_projector.")}, strict=True)
+    llm, _ = G.build_hf_llm(cfg, {k: t.float() for k, t in w.items()})
+    llm = llm.to(torch.bfloat16)
+    m = _reference_save_pretrained()()
+    m.llm = llm
+    m.mm_projector = projector
+    wrapper = torch.nn.Module()                                    # VisionTower (multimodal_encoder/vision_encoder.py:32-52): .vision_tower, .config, .image_processor
+    wrapper.vision_tower = tower
+    wrapper.config = tower.config
+    wrapper.image_processor = SiglipImageProcessor(size={"height": v.image_size, "width": v.image_size})
+    m.vision_tower = wrapper
+    m.config = lc.LlavaConfig(hidden_size=cfg.llm.hidden_size, mm_hidden_size=cfg.mm_hidden_size, mm_vision_select_layer=-2,
+                              mm_vision_select_feature="cls_patch", mm_projector_type=cfg.mm_projector_type)
+    d = str(tmp_path / "ref_ckpt")
+    m.save_pretrained(d)                                             # the reference's own writer
+    assert sorted(x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))) == ["llm", "mm_projector", "vision_tower"]
+    got_cfg = checkpoint.config_from_pretrained(d)
+    assert got_cfg.mm_projector_type == proj
+    assert (got_cfg.llm.hidden_size, got_cfg.llm.num_hidden_layers, got_cfg.llm.num_key_value_heads, got_cfg.llm.vocab_size, got_cfg.llm.tie_word_embeddings) == \
+           (cfg.llm.hidden_size, cfg.llm.num_hidden_layers, cfg.llm.num_key_value_heads, cfg.llm.vocab_size, tied)
+    assert (got_cfg.vision.hidden_size, got_cfg.vision.num_hidden_layers, got_cfg.vision.image_size, got_cfg.vision.patch_size) == \
+           (v.hidden_size, v.num_hidden_layers, v.image_size, v.patch_size)
+    assert got_cfg.llm.rope_theta == cfg.llm.rope_theta and got_cfg.llm.eos_token_id == cfg.llm.eos_token_id and got_cfg.llm.rms_norm_eps == cfg.llm.rms_norm_eps
+    assert got_cfg.vision.select_layer == -2 and got_cfg.dynamic_s2 is False and got_cfg.s2_resize_output_to_scale_idx == -1      # nulls in the reference's config.json -> defaults
+    hip = checkpoint.load_pretrained(d, device="cpu")
+    ours = hip.state_dict()
+    n = 0
+    for k, t in w.items():
+        if k in ours:
+            assert torch.equal(ours[k], t), k
+            n += 1
+    assert n >= 60 and all(k in ours for k in w if not (tied and k == "llm.lm_head.weight"))

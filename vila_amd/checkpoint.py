@@ -122,20 +122,37 @@ def config_from_pretrained(model_dir: str) -> VilaConfig:
         path = cfg if isinstance(cfg, str) else os.path.join(model_dir, folder)
         return json.load(open(os.path.join(path, "config.json")))
     l, v = sub("llm_cfg", "llm"), sub("vision_tower_cfg", "vision_tower")
+
+    def opt(d, key, default):
+        """A key the reference's LlavaConfig writes as null (every field it was not given: configuration_llava.py:26-70) counts as absent."""
+        val = d.get(key)
+        return default if val is None else val
     llm = LlmConfig(hidden_size=l["hidden_size"], intermediate_size=l["intermediate_size"], num_hidden_layers=l["num_hidden_layers"],
                     num_attention_heads=l["num_attention_heads"], num_key_value_heads=l["num_key_value_heads"],
-                    head_dim=l.get("head_dim", l["hidden_size"] // l["num_attention_heads"]), vocab_size=l["vocab_size"],
-                    rms_norm_eps=l.get("rms_norm_eps", 1e-6), rope_theta=l.get("rope_theta", 1e6),
-                    tie_word_embeddings=l.get("tie_word_embeddings", False), eos_token_id=l.get("eos_token_id", 151645))
+                    head_dim=opt(l, "head_dim", l["hidden_size"] // l["num_attention_heads"]), vocab_size=l["vocab_size"],
+                    rms_norm_eps=opt(l, "rms_norm_eps", 1e-6), rope_theta=_rope_theta(l),
+                    tie_word_embeddings=bool(opt(l, "tie_word_embeddings", False)), eos_token_id=_first_id(opt(l, "eos_token_id", 151645)))
     vis = VisionConfig(hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"], num_hidden_layers=v["num_hidden_layers"],
                        num_attention_heads=v["num_attention_heads"], image_size=v["image_size"], patch_size=v["patch_size"],
-                       num_channels=v.get("num_channels", 3), layer_norm_eps=v.get("layer_norm_eps", 1e-6),
-                       select_layer=top.get("mm_vision_select_layer", -2))
-    scales = top.get("s2_scales", "448,896,1344")
+                       num_channels=opt(v, "num_channels", 3), layer_norm_eps=opt(v, "layer_norm_eps", 1e-6),
+                       select_layer=opt(top, "mm_vision_select_layer", -2))
+    scales = opt(top, "s2_scales", "448,896,1344")
     return VilaConfig(vision=vis, llm=llm, mm_projector_type=resolve_projector_type(top, model_dir),
-                      image_token_id=top.get("image_token_id", 151649), newline_token_id=top.get("newline_token_id", 198),
-                      dynamic_s2=bool(top.get("dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
-                      s2_resize_output_to_scale_idx=top.get("s2_resize_output_to_scale_idx", -1), name=os.path.basename(model_dir.rstrip("/")))
+                      image_token_id=opt(top, "image_token_id", 151649), newline_token_id=opt(top, "newline_token_id", 198),
+                      dynamic_s2=bool(opt(top, "dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
+                      s2_resize_output_to_scale_idx=opt(top, "s2_resize_output_to_scale_idx", -1), name=os.path.basename(model_dir.rstrip("/")))
+
+
+def _rope_theta(l: dict) -> float:
+    """`rope_theta` at the top of the LLM config (transformers <= 4.x, what the reference pins) or inside `rope_parameters` (5.x)."""
+    if l.get("rope_theta") is not None:
+        return float(l["rope_theta"])
+    rp = l.get("rope_parameters") or {}
+    return float(rp.get("rope_theta", 1e6))
+
+
+def _first_id(v) -> int:
+    return int(v[0]) if isinstance(v, (list, tuple)) else int(v)
 
 
 def load_weights_into(model, model_dir: str, strict: bool = True) -> Dict[str, list]:
