@@ -158,7 +158,10 @@ def test_checkpoint_written_by_the_reference_loads_into_the_hip_model(tmp_path, 
     assert (got_cfg.vision.hidden_size, got_cfg.vision.num_hidden_layers, got_cfg.vision.image_size, got_cfg.vision.patch_size) == \
            (v.hidden_size, v.num_hidden_layers, v.image_size, v.patch_size)
     assert got_cfg.llm.rope_theta == cfg.llm.rope_theta and got_cfg.llm.eos_token_id == cfg.llm.eos_token_id and got_cfg.llm.rms_norm_eps == cfg.llm.rms_norm_eps
-    assert got_cfg.vision.select_layer == -2 and got_cfg.dynamic_s2 is False and got_cfg.s2_resize_output_to_scale_idx == -1      # nulls in the reference's config.json -> defaults
+    top = json.load(open(os.path.join(d, "config.json")))
+    assert top["s2_scales"] is None and top["image_aspect_ratio"] is None                  # what the reference's LlavaConfig writes for fields it was not given
+    assert got_cfg.vision.select_layer == -2 and got_cfg.dynamic_s2 is False and got_cfg.s2_scales == (448, 896, 1344)
+    assert got_cfg.s2_resize_output_to_scale_idx == top["s2_resize_output_to_scale_idx"] == 0   # LlavaConfig's own default (the NVILA scripts pass -1)
     hip = checkpoint.load_pretrained(d, device="cpu")
     ours = hip.state_dict()
     n = 0
