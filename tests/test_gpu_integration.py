@@ -136,3 +136,51 @@ def test_llm_seam_matches_hf_forward_and_generate(vlm_pair):
     if float(top2[0] - top2[1]) > 4 * err:
         assert int(ids[0, 0]) == int(ref["ids"][0, 0])
     assert ids.shape == (1, 6)
+
+
+def _collated_batch(device):
+    """The batch the REFERENCE'S OWN DataCollator produced (tests/golden/collate_batch_ref.npz, oracle/make_golden_collate.py), rebuilt from the
+    seeded pixel pool: exactly the dict `Trainer` hands `model(**batch)`."""
+    import os
+    import numpy as np
+    from vila_amd import configs, synthetic
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "collate_batch_ref.npz"))
+    cfg = configs.tiny_s2()
+    pool = synthetic.make_pixels(cfg, 15, int(fx["seed"])).to(torch.bfloat16)
+    images = [pool[int(k)].to(device) for k in fx["image_pool_index"]]
+    videos = [pool[int(k):int(k) + int(n)].to(device) for k, n in zip(fx["video_first_pool_index"], fx["video_frames"])]
+    blocks = [None if b[0] < 0 else (int(b[0]), int(b[1])) for b in fx["block_sizes"]]
+    batch = {"input_ids": torch.from_numpy(fx["input_ids"]).to(device), "media": {"image": images, "video": videos},
+             "media_config": {"image": {"block_sizes": blocks, "original_image_sizes": [None] * len(blocks)}, "video": {}},
+             "labels": torch.from_numpy(fx["labels"]).to(device), "attention_mask": torch.from_numpy(fx["attention_mask"]).to(device),
+             "gt_selection_maps": None}
+    assert sorted(batch["media_config"]) == list(fx["media_config_keys"]) and sorted(batch["media_config"]["image"]) == list(fx["image_config_keys"])
+    return cfg, pool, batch, blocks
+
+
+def test_the_reference_collators_batch_goes_straight_into_the_hip_model():
+    """`loss = model(**batch).loss; loss.backward()` with `batch` = the output of the reference's DataCollator (dynamic_s2 recipe: a 2 x 2-block
+    image of 9 tiles, a text-only sample, a one-tile image + a 3-frame video; padded with the tokenizer's pad id, `gt_selection_maps=None` riding
+    along as in the reference): training mode through the autograd seam, and eval mode — both against the fp32 oracle on the same batch."""
+    from oracle import vila_oracle as O
+    from vila_amd import synthetic
+    from vila_amd.vlm import build_model
+    cfg, pool, batch, blocks = _collated_batch("cuda")
+    w = {k: v.to(torch.bfloat16).float() for k, v in synthetic.make_weights(cfg, 23).items()}
+    ids, labels, mask = batch["input_ids"].cpu(), batch["labels"].cpu(), batch["attention_mask"].cpu()
+    tiles = [t.float().cpu() for t in batch["media"]["image"]]
+    vids = [v.float().cpu() for v in batch["media"]["video"]]
+    ref = float(O.vlm_sft_loss(tiles, ids, labels, mask, w, cfg, packed=True, block_sizes=blocks, videos=vids))
+    model = build_model(cfg, weights=w)
+    model.enable_autograd(use_c_abi=False)
+    model.train()
+    out = model(**batch)
+    assert out.loss.requires_grad and abs(float(out.loss) - ref) < 1e-2 * abs(ref), (float(out.loss), ref)
+    out.loss.backward()
+    g = dict(model.mm_projector.named_parameters())["layers.1.weight"].grad
+    assert g is not None and float(g.float().norm()) > 0
+    model.eval()
+    with torch.no_grad():
+        ev = model(**batch)
+    assert abs(float(ev.loss) - ref) < 1e-2 * abs(ref), (float(ev.loss), ref)
+    print(f"reference-collated batch: training loss {float(out.loss):.5f}, eval loss {float(ev.loss):.5f}, oracle {ref:.5f}")

@@ -298,3 +298,40 @@ def test_dp_step_gloo_world2_text_only_rank_takes_part_in_every_media_bucket():
     assert m0 == m1, "masters differ after a step in which only one rank had images"
     assert steps0 == steps1 and steps1["mm_projector."] == 1
     assert g0 == g1 > 0                                          # the text-only rank received the other rank's projector gradient
+
+
+def test_reference_collated_batch_is_what_the_step_plans_on():
+    """CPU half of tests/test_gpu_integration.py::test_the_reference_collators_batch_goes_straight_into_the_hip_model: the batch the reference's
+    own DataCollator produced (tests/golden/collate_batch_ref.npz) has the keys `model(**batch)` takes, its block sizes and media counts add up to
+    the tiles the dynamic_s2 plan expects, and the target count of the step equals the oracle's on that batch."""
+    import os
+    import numpy as np
+    from types import SimpleNamespace
+    from vila_amd import configs
+    from vila_amd.host import s2_plan
+    from vila_amd.train import SFTTrainer, count_targets
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "collate_batch_ref.npz"))
+    cfg = configs.tiny_s2()
+    assert list(fx["media_config_keys"]) == ["image", "video"] and list(fx["image_config_keys"]) == ["block_sizes", "original_image_sizes"]
+    assert bool(fx["gt_selection_maps_is_none"])
+    ids, labels, mask = (torch.from_numpy(fx[k]) for k in ("input_ids", "labels", "attention_mask"))
+    assert torch.equal(mask, ids != int(fx["pad_id"])) and bool((labels[~mask] == -100).all())
+    blocks = [None if b[0] < 0 else (int(b[0]), int(b[1])) for b in fx["block_sizes"]]
+    n_img_tokens, n_vid_tokens = int((ids == cfg.image_token_id).sum()), int((ids == cfg.video_token_id).sum())
+    assert len(blocks) == n_img_tokens == 2 and len(fx["video_frames"]) == n_vid_tokens == 1
+    frames = [int(n) for n in fx["video_frames"]]
+    fake = SimpleNamespace(cfg=cfg, _video_tokens=lambda: (((1, 1, 1),), [], [cfg.newline_token_id], []))
+    all_blocks = SFTTrainer._block_sizes_with_frames(fake, blocks, frames)
+    plan = s2_plan(all_blocks, list(cfg.s2_scales), cfg.vision.grid, cfg.downsample, cfg.s2_resize_output_to_scale_idx)
+    assert plan.n_tiles == len(fx["image_pool_index"]) + sum(frames)               # the tower batch: image tiles, then frames
+    s2, rows, n_pin = SFTTrainer._media_plan(fake, plan.n_tiles, all_blocks)
+    img_blocks, vid_blocks, pools, n_buf = SFTTrainer._media_blocks(fake, rows, frames, n_pin * cfg.tokens_per_tile)
+    assert len(img_blocks) == 2 and len(vid_blocks) == 1 and not pools
+    n_targets = count_targets(ids, labels, mask, (cfg.image_token_id, cfg.video_token_id))
+    want = 0
+    for k in range(ids.shape[0]):
+        i_k, l_k = ids[k][mask[k]], labels[k][mask[k]]
+        keep = (l_k != -100) & (i_k != cfg.image_token_id) & (i_k != cfg.video_token_id)
+        keep[0] = False
+        want += int(keep.sum())
+    assert n_targets == want > 0
