@@ -142,6 +142,62 @@ def test_prompt_split_equals_the_reference_executed_extract_media():
         assert len(images) == c["n_images"]
 
 
+def test_video_frame_selection_equals_the_reference_executed_load_video(tmp_path):
+    """tests/golden/video_sampling_ref.json = the reference's own `_load_video` (llava/utils/media.py:39-86, ast-extracted, executed over a
+    stand-in capture that serves index-stamped frames, and over real PNG directories; oracle/make_golden_video_sampling.py): evenly spread
+    frames, the fps rule with its clamp, containers that report more frames than they hold, a zero-fps container, repeated indices."""
+    import json
+    import os
+    from PIL import Image
+    from vila_amd.serving import load_video_frames, video_frame_indices
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "video_sampling_ref.json")))
+    assert len(fx["file"]) >= 9 and len(fx["dir"]) >= 3
+    for c in fx["file"]:
+        got = video_frame_indices(c["grabbable"], c["num_frames"], c["fps"], c["video_fps"])
+        assert got == c["indices"], (c, got)
+    for c in fx["dir"]:
+        d = tmp_path / f"frames_{c['n_files']}_{c['num_frames']}"
+        d.mkdir()
+        for i in range(c["n_files"]):
+            Image.new("RGB", (2, 2), (i, 0, 0)).save(d / f"frame_{i:04d}.png")
+        frames = load_video_frames(str(d), num_frames=c["num_frames"])
+        assert [f.getpixel((0, 0))[0] for f in frames] == c["indices"]
+    clip = tmp_path / "clip.mp4"
+    clip.write_bytes(b"not a video")
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="OpenCV"):
+            load_video_frames(str(clip))
+
+
+def test_video_url_content_becomes_one_image_token_per_frame(monkeypatch):
+    """server.py:47-52, 214-221: a `video_url` part carries `frames` / `fps`; its frames reach the model as images, one `<image>` each
+    (extract_media).  The decoder is stubbed (no OpenCV here); a non-base64 URL is refused, local paths included."""
+    import base64
+    from fastapi.testclient import TestClient
+    tok = _Tok()
+    m = _Model(tok)
+    seen = {}
+
+    def fake_frames(path, num_frames=8, fps=0.0):
+        seen.update(path=path, num_frames=num_frames, fps=fps)
+        return [np.zeros((56, 56, 3), np.uint8)] * 3
+    monkeypatch.setattr(serving, "load_video_frames", fake_frames)
+    client = TestClient(serving.create_app(m, tok, "NVILA-8B"))
+    url = "data:video/mp4;base64," + base64.b64encode(b"fake mp4 bytes").decode()
+    body = {"model": "NVILA-8B", "temperature": 0.0,
+            "messages": [{"role": "user", "content": [{"type": "video_url", "video_url": {"url": url}, "frames": 3, "fps": 0}, {"type": "text", "text": "what happens ?"}]}]}
+    r = client.post("/chat/completions", json=body)
+    assert r.status_code == 200, r.text
+    ids, media = m.calls[-1][0], m.calls[-1][1]
+    assert int((ids == m.cfg.image_token_id).sum()) == 3 and len(media["image"]) == 3
+    assert seen["num_frames"] == 3 and seen["fps"] == 0.0 and seen["path"].endswith(".mp4") and open(seen["path"], "rb").read() == b"fake mp4 bytes"
+    body["messages"][0]["content"][0]["video_url"]["url"] = "/etc/passwd"
+    r = client.post("/chat/completions", json=body)
+    assert r.status_code == 500 and "Invalid video url" in r.json()["error"]
+
+
 class _BatchModel(_Model):
     """Answers a padded batch: row b replies with the b-th canned text, then EOS, then padding."""
     texts = ["a red square", "w1 w2", "you are helpful"]

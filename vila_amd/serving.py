@@ -12,8 +12,10 @@ The tokenizer is whatever the checkpoint ships (`transformers.AutoTokenizer`), h
 from __future__ import annotations
 
 import base64
+import glob
 import io
 import json
+import os
 import re
 import time
 import uuid
@@ -84,6 +86,71 @@ class Video:
 
     def __init__(self, frames) -> None:
         self.frames = list(frames)
+
+
+_VIDEO_URL = re.compile(r"^data:video/(mp4);base64,(.*)$")            # server.py:57
+
+
+def video_frame_indices(frame_count: int, num_frames: int, fps: float = 0.0, video_fps: float = 0.0) -> List[int]:
+    """Which frames of a `frame_count`-frame video the reference keeps (llava/utils/media.py:62-72): with `fps > 0` one frame every 1 / fps
+    seconds of the video's duration, clamped to `num_frames`; else `num_frames` positions spread evenly over the whole video
+    (`np.round(np.linspace(0, n - 1, num_frames))`).  Pinned by tests/golden/video_sampling_ref.json = the reference's own `_load_video`
+    executed over a synthetic capture."""
+    if fps and fps > 0:
+        duration = frame_count / video_fps if video_fps > 0 else 0
+        stamps = np.arange(0, duration, 1.0 / fps)[:num_frames]
+        return [int(t * video_fps) for t in stamps]
+    return [int(i) for i in np.round(np.linspace(0, frame_count - 1, num_frames)).astype(int)]
+
+
+def load_video_frames(path: str, num_frames: int = 8, fps: float = 0.0):
+    """`_load_video` (llava/utils/media.py:39-86): a DIRECTORY of frame images (sorted, `num_frames` spread evenly) or a video file (needs
+    OpenCV, which this image does not ship: imported lazily, a missing module is reported as such) -> list of PIL images."""
+    from PIL import Image
+    if os.path.isdir(path):
+        files = sorted(glob.glob(os.path.join(path, "*")))
+        if not files:
+            raise ValueError(f"Video '{path}' has no frames.")
+        return [Image.open(files[i]).convert("RGB") for i in video_frame_indices(len(files), num_frames)]
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError("decoding a video FILE needs OpenCV (cv2), as in the reference (llava/utils/media.py:47); pass a directory of frames "
+                           "or a serving.Video(frames) part instead") from e
+    cap = cv2.VideoCapture(path)
+    video_fps = cap.get(cv2.CAP_PROP_FPS)
+    n = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+    while n > 0:                                                     # the container's frame count may overshoot (:53-59)
+        cap.set(cv2.CAP_PROP_POS_FRAMES, n - 1)
+        if cap.grab():
+            break
+        n -= 1
+    else:
+        raise ValueError(f"Video '{path}' has no frames.")
+    frames = {}
+    idx = video_frame_indices(n, num_frames, fps, video_fps)
+    for i in idx:
+        if i in frames:
+            continue
+        cap.set(cv2.CAP_PROP_POS_FRAMES, i)
+        ok, frame = cap.read()
+        if ok:
+            frames[i] = Image.fromarray(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB))
+    return [frames[i] for i in idx if i in frames]
+
+
+def load_video(url: str) -> str:
+    """`load_video` of server.py:60-78: a `data:video/mp4;base64,` URL is written to a temporary .mp4 whose path is returned.  Remote http(s)
+    fetches are left to the caller (no network in this build); local paths are NOT accepted from a request (the Python API takes them:
+    `load_video_frames(path)` / `Video(frames)`)."""
+    m = _VIDEO_URL.match(url)
+    if m:
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), f"{uuid.uuid5(uuid.NAMESPACE_DNS, url)}.mp4")
+        with open(path, "wb") as f:
+            f.write(base64.b64decode(m.group(2)))
+        return path
+    raise ValueError(f"Invalid video url: {url[:64]}")
 
 
 def _split_prompt(prompt: Union[str, Sequence[Any]]):
@@ -493,6 +560,10 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: O
                             parts.append(c["text"])
                         elif c.get("type") == "image_url":
                             parts.append(load_image(c["image_url"]["url"]))
+                        elif c.get("type") == "video_url":           # server.py:47-52, 214-221: `frames` (default 8) / `fps` (default 2) ride in the content
+                            frames = c.get("frames", 8) if c.get("frames") is not None else 8
+                            fps = c.get("fps", 2) if c.get("fps") is not None else 2
+                            parts.append(Video(load_video_frames(load_video(c["video_url"]["url"]), num_frames=int(frames), fps=float(fps))))
                         else:
                             raise NotImplementedError(f"Unsupported content type: {c.get('type')}")
             elif m.role == "assistant" and isinstance(m.content, str):
