@@ -10,7 +10,8 @@
     encoders/video/tsp.py: pool, TSPVideoEncoder                                                          (whole classes, unchanged)
 The shim supplies only what the methods reach for: `self.llm.model.embed_tokens` (an nn.Embedding holding the synthetic table), `self.tokenizer`
 (media_token_ids, padding_side, model_max_length, `tokenizer("\\n").input_ids`), `self.encoders`, `self.training`, `self.device`,
-`get_vision_tower()` = the reference SigLIP (`modeling_siglip.py`, hidden_states[-2], `VisionTower.feature_select` with cls_patch) and
+`get_vision_tower()` = the reference's `VisionTower` (its `__init__` / `feature_select` / `forward`, extracted the same way) around the reference SigLIP
+(`modeling_siglip.py`) and
 `get_mm_projector()` = the reference projector (both loaded by file path, as oracle/make_golden.py does); `get_pg_manager()` returns None (no
 sequence parallelism) and `distributed.all_gather(x)` returns `[x]` (one rank).
 
@@ -70,8 +71,9 @@ def _methods_source(path, cls, names):
     src = open(path).read()
     for node in ast.parse(src).body:
         if isinstance(node, ast.ClassDef) and node.name == cls:
-            got = {fn.name: ast.get_source_segment(src, fn) for fn in node.body if isinstance(fn, ast.FunctionDef)}
-            return [textwrap.indent(textwrap.dedent(got[n]), "    ") for n in names]
+            deco = lambda fn: "".join("@" + ast.get_source_segment(src, d) + "\n" for d in fn.decorator_list)      # (get_source_segment starts at `def`)
+            got = {fn.name: deco(fn) + textwrap.dedent(ast.get_source_segment(src, fn, padded=True)) for fn in node.body if isinstance(fn, ast.FunctionDef)}
+            return [textwrap.indent(got[n], "    ") for n in names]
     raise KeyError((path, cls))
 
 
@@ -94,6 +96,9 @@ def load_reference():
     ns["F"] = torch.nn.functional
     exec(compile(_function_source(f"{REF}/utils/packing.py", "_get_unpad_data"), "utils/packing.py", "exec"), ns)
     exec(compile(_function_source(f"{REF}/utils/packing.py", "set_seqlens_in_batch"), "utils/packing.py", "exec"), ns)
+    # VisionTower.__init__ / feature_select / forward and its dtype / device properties (multimodal_encoder/vision_encoder.py:32-52, 133-184)
+    vt = "\n\n".join(_methods_source(f"{REF}/multimodal_encoder/vision_encoder.py", "VisionTower", ["__init__", "feature_select", "forward", "dtype", "device"]))
+    exec(compile("class VisionTower(torch.nn.Module):\n" + vt + "\n", "multimodal_encoder/vision_encoder.py", "exec"), ns)
     body = "\n\n".join(_methods_source(f"{REF}/llava_arch.py", "LlavaMetaModel", MODEL_METHODS) +
                        _methods_source(f"{REF}/llava_arch.py", "LlavaMetaForCausalLM", ARCH_METHODS))
     exec(compile("class LlavaMetaForCausalLM(torch.nn.Module):\n" + body + "\n", "llava_arch.py", "exec"), ns)
@@ -128,8 +133,10 @@ def build_model(ns, cfg, w, side="right", max_len=4096, tsp=None):
     m.llm = types.SimpleNamespace(model=types.SimpleNamespace(embed_tokens=emb))
     m.tokenizer = _Tokenizer(cfg, side, max_len)
     m.config = types.SimpleNamespace(dynamic_s2=False)
-    # VisionTower.forward (vision_encoder.py:44-52, 32-41: select_layer -2, select_feature cls_patch as every NVILA script passes)
-    m.get_vision_tower = lambda: (lambda images: tower(images, output_hidden_states=True).hidden_states[cfg.vision.select_layer])
+    # the reference's own VisionTower wrapper around the reference SigLIP (select_layer -2, select_feature cls_patch as every NVILA script passes)
+    vt = ns["VisionTower"]("siglip", types.SimpleNamespace(mm_vision_select_layer=cfg.vision.select_layer, mm_vision_select_feature="cls_patch"))
+    vt.vision_tower = tower
+    m.get_vision_tower = lambda: vt
     m.get_mm_projector = lambda: proj
     object.__setattr__(m, "_dev", torch.device("cpu"))
     type(m).device = property(lambda self: self._dev)
