@@ -162,6 +162,19 @@ def test_video_frame_selection_equals_the_reference_executed_load_video(tmp_path
             Image.new("RGB", (2, 2), (i, 0, 0)).save(d / f"frame_{i:04d}.png")
         frames = load_video_frames(str(d), num_frames=c["num_frames"])
         assert [f.getpixel((0, 0))[0] for f in frames] == c["indices"]
+    # the OpenCV branch of load_video_frames over the SAME stand-in capture the reference ran on (this image has no cv2: it is injected)
+    import sys
+    import numpy as np_
+    from oracle.make_golden_video_sampling import fake_cv2
+    for c in fx["file"]:
+        sys.modules["cv2"] = fake_cv2(c["frame_count"], c["grabbable"], c["video_fps"])
+        try:
+            if c["grabbable"] == 0:
+                continue
+            frames = load_video_frames("clip.mp4", num_frames=c["num_frames"], fps=c["fps"])
+        finally:
+            del sys.modules["cv2"]
+        assert [int(np_.asarray(f)[0, 0, 2]) + 256 * int(np_.asarray(f)[0, 0, 1]) for f in frames] == c["indices"], c
     clip = tmp_path / "clip.mp4"
     clip.write_bytes(b"not a video")
     try:
