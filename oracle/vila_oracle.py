@@ -20,6 +20,16 @@ Round 3: the same three pieces of reference code were also run ONCE AT FULL SIZE
 `oracle/make_golden_full_ref.py` -> `tests/golden/nvila8b_full_depth_ref.npz`), and the oracle's own full-depth fixture equals that
 run to 2.4e-6 of the largest logit with identical greedy ids (`tests/test_oracle_golden.py`).
 
+Round 4: every remaining restated piece is held to the reference's OWN code, taken from its files with `ast` and executed unchanged
+(`llava.model` itself cannot be imported here: deepspeed / hydra):
+  * `embed_splice`, `repack`, `get_unpad_data`, `encode_images`, the image / video encoders  <- `LlavaMetaForCausalLM._embed`, `__truncate_sequence`,
+    `__batchify_sequence`, `repack_multimodal_data`, `LlavaMetaModel.encode_images`, `VisionTower`, `BaseEncoder` / `BasicImageEncoder` /
+    `BasicVideoEncoder` / `TSPVideoEncoder`, packing.py `_get_unpad_data`           (oracle/make_golden_embed.py -> embed_splice_ref.npz)
+  * autograd through `vlm_sft_loss`, also through the pooling video encoder  <- reference SigLIP + projector + encoders + HF Qwen2 under autograd
+                                                                    (make_golden_grads.py, make_golden_grads_video.py -> tiny_sft_grads*.npz)
+  * the dynamic_s2 merge / tiler / image pre-processing, the video encoders' forward, the sampling chain: make_golden_s2*.py, make_golden_video.py,
+    make_golden_sampling.py; full depth at NVILA-8B / Lite-3B size: make_golden_full_ref.py, make_golden_lite3b.py.
+
 All tensors fp32 unless noted.  `w` is a flat dict keyed by the reference's state_dict names
 (SURVEY.md Appendix C).
 """
