@@ -170,3 +170,43 @@ def test_checkpoint_written_by_the_reference_loads_into_the_hip_model(tmp_path, 
             assert torch.equal(ours[k], t), k
             n += 1
     assert n >= 60 and all(k in ours for k in w if not (tied and k == "llm.lm_head.weight"))
+
+
+def test_our_checkpoint_resolves_through_the_reference_config_loader(tmp_path):
+    """How the reference finds the three sub-models of a checkpoint: `LlavaConfig.from_pretrained(dir)` (configuration_llava.py, HF
+    PretrainedConfig) then `get_model_config(config)` (llava/model/utils/utils.py:25-55, ast-extracted, executed unchanged) -> [llm, vision_tower,
+    mm_projector] paths.  On a checkpoint written by `vila_amd.checkpoint.save_pretrained` the config parses, carries the fields the reference's
+    builders read, and the three paths exist and hold a config.json + weights each."""
+    pytest.importorskip("transformers")
+    import ast
+    import os.path as osp
+    from transformers import AutoConfig, PretrainedConfig
+    from oracle import make_golden as G
+    cfg = configs.tiny("mlp_downsample")
+    m = _rand_model(cfg, 7)
+    d = str(tmp_path / "ckpt")
+    checkpoint.save_pretrained(m, d)
+    lc = G.load_by_path("ref_configuration_llava", f"{REF}/llava/model/configuration_llava.py")
+    config = lc.LlavaConfig.from_pretrained(d)
+    config.resume_path = d                                               # llava/model/builder.py:110-113 does this right after loading the config
+    assert config.hidden_size == cfg.llm.hidden_size and config.mm_hidden_size == cfg.mm_hidden_size
+    assert config.mm_vision_select_layer == -2 and config.mm_vision_select_feature == "cls_patch"
+    # builder.py:159-167 `prepare_config_for_eval` (extracted, executed unchanged): needs `vision_tower_cfg` and takes the dtype
+    bsrc = open(f"{REF}/llava/model/builder.py").read()
+    pfn = next(n for n in ast.parse(bsrc).body if isinstance(n, ast.FunctionDef) and n.name == "prepare_config_for_eval")
+    bns = {"PretrainedConfig": PretrainedConfig}
+    exec(compile(ast.get_source_segment(bsrc, pfn), "builder.py", "exec"), bns)
+    bns["prepare_config_for_eval"](config, {"torch_dtype": torch.bfloat16})
+    assert config.model_dtype == "torch.bfloat16" and isinstance(config.vision_tower_cfg, dict)
+    src = open(f"{REF}/llava/model/utils/utils.py").read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "get_model_config")
+    ns = {"os": os, "osp": osp, "PretrainedConfig": PretrainedConfig, "repo_exists": lambda p: False, "HFValidationError": Exception,
+          "snapshot_download": None}
+    exec(compile(ast.get_source_segment(src, fn), "utils.py", "exec"), ns)
+    paths = ns["get_model_config"](config)
+    assert [os.path.basename(p) for p in paths] == ["llm", "vision_tower", "mm_projector"]
+    for p in paths:
+        assert os.path.isfile(os.path.join(p, "config.json")) and any(f.endswith(".safetensors") for f in os.listdir(p)), p
+    llm_cfg = AutoConfig.from_pretrained(paths[0])                      # language_model/builder.py:66-70 does exactly this
+    assert llm_cfg.model_type == "qwen2" and llm_cfg.hidden_size == cfg.llm.hidden_size
+    assert json.load(open(os.path.join(paths[2], "config.json")))["mm_projector_type"] == "mlp_downsample"
