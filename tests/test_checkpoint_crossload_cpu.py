@@ -72,6 +72,14 @@ def test_saved_checkpoint_loads_into_the_reference_classes(tmp_path, proj, tied)
         if k.startswith("vision_tower.vision_tower."):
             assert torch.equal(ref_sd[k[len("vision_tower.vision_tower."):]].to(torch.bfloat16), t), k
 
+    # ... and through the reference class's own from_pretrained (multimodal_encoder/siglip_encoder.py loads the tower this way): nothing missing
+    tower2, vinfo = ms.SiglipVisionModel.from_pretrained(os.path.join(d, "vision_tower"), torch_dtype=torch.bfloat16, output_loading_info=True)
+    assert not vinfo["missing_keys"] and not vinfo["unexpected_keys"] and not vinfo["mismatched_keys"], vinfo
+    sd2 = tower2.state_dict()
+    for k, t in ours.items():
+        if k.startswith("vision_tower.vision_tower."):
+            assert torch.equal(sd2[k[len("vision_tower.vision_tower."):]], t), k
+
     # ---- mm_projector/ into the reference's MultimodalProjector; the type comes from the folder's own config ----
     bp = ref_projector()
     pcfg = json.load(open(os.path.join(d, "mm_projector", "config.json")))

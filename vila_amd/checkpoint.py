@@ -77,7 +77,10 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
                "eos_token_id": c.eos_token_id, "torch_dtype": "bfloat16", "hidden_act": "silu"}
     vt_cfg = {"model_type": "siglip_vision_model", "hidden_size": v.hidden_size, "intermediate_size": v.intermediate_size,
               "num_hidden_layers": v.num_hidden_layers, "num_attention_heads": v.num_attention_heads, "image_size": v.image_size,
-              "patch_size": v.patch_size, "num_channels": v.num_channels, "layer_norm_eps": v.layer_norm_eps, "hidden_act": "gelu_pytorch_tanh"}
+              "patch_size": v.patch_size, "num_channels": v.num_channels, "layer_norm_eps": v.layer_norm_eps, "hidden_act": "gelu_pytorch_tanh",
+              # VILA never uses SigLIP's pooling head; saying so makes the reference's SiglipVisionModel (modeling_siglip.py:1166) build none, so
+              # its from_pretrained finds every parameter it has in this folder (no "newly initialized" head)
+              "vision_use_head": False}
     pj_cfg = {"model_type": "v2l_projector", "mm_projector_type": cfg.mm_projector_type}
     for (attr, folder, strip), sub_cfg in zip(_PARTS, (llm_cfg, vt_cfg, pj_cfg)):
         sd = getattr(model, attr).state_dict()
