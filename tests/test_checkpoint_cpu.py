@@ -2,6 +2,7 @@
 import json
 import os
 
+import pytest
 import torch
 from safetensors import safe_open
 from safetensors.torch import save_file
@@ -138,3 +139,39 @@ def test_optimizer_state_without_bucket_counts_resumes_bias_correction_at_the_sa
     tr4 = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
     tr4.flat.load_optimizer_state(sd)
     assert tr4.flat.bucket_step_floor == 37 and tr4.flat.bucket_steps == {"mm_projector.": 38}
+
+
+def test_tokenizer_is_saved_in_llm_and_drives_the_media_ids_on_load(tmp_path):
+    """llava_arch.py:164-165 saves the tokenizer into llm/; language_model/builder.py:190-211 loads it from there, adds the media tokens and records
+    their ids — which is where `<image>` / `<vila/video>` get their ids from (the reference's config.json does not carry them).  An offline-built
+    fast tokenizer stands for Qwen2's: its ids differ from the config defaults, so the loaded model must follow the tokenizer."""
+    pytest.importorskip("transformers")
+    pytest.importorskip("tokenizers")
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"[UNK]": 0, "\n": 1, "hello": 2, "world": 3, "what": 4, "is": 5, "this": 6}
+    t = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    t.pre_tokenizer = pre_tokenizers.Split(" ", "removed")
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]")
+    tok.add_tokens(["<image>", "<vila/video>"], special_tokens=True)
+    ids = {"image": tok.convert_tokens_to_ids("<image>"), "video": tok.convert_tokens_to_ids("<vila/video>")}
+    tok.media_token_ids = dict(ids)
+    cfg = configs.tiny("mlp_downsample")
+    assert ids["image"] != cfg.image_token_id                        # the test is only meaningful if the tokenizer disagrees with the defaults
+    m = HipLlavaLlamaModel(cfg, device="cpu", tokenizer=tok)
+    d = str(tmp_path / "ckpt")
+    checkpoint.save_pretrained(m, d)
+    assert os.path.exists(os.path.join(d, "llm", "tokenizer.json")) and os.path.exists(os.path.join(d, "llm", "config.json"))
+    m2 = checkpoint.load_pretrained(d, device="cpu")
+    assert hasattr(m2.tokenizer, "save_pretrained") and m2.tokenizer.padding_side == "right"
+    assert m2.tokenizer.media_token_ids == ids and m2.tokenizer.media_tokens == {"image": "<image>", "video": "<vila/video>"}
+    assert (m2.cfg.image_token_id, m2.cfg.video_token_id) == (ids["image"], ids["video"])
+    nl = m2.tokenizer("\n").input_ids                               # (next to a qwen2 config.json AutoTokenizer re-tokenises this toy vocabulary its own way)
+    assert m2.cfg.newline_token_id == (nl[0] if len(nl) == 1 else cfg.newline_token_id)
+    got = m2.tokenizer("hello <image> world").input_ids
+    assert ids["image"] in got and got.count(ids["image"]) == 1
+    # a checkpoint without tokenizer files keeps the stand-in and the ids of its config.json
+    d2 = str(tmp_path / "plain")
+    checkpoint.save_pretrained(HipLlavaLlamaModel(cfg, device="cpu"), d2)
+    m3 = checkpoint.load_pretrained(d2, device="cpu")
+    assert not hasattr(m3.tokenizer, "save_pretrained") and m3.cfg.image_token_id == cfg.image_token_id

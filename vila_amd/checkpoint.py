@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import json
 import os
-from typing import Dict, Iterable
+from typing import Optional, Dict, Iterable
 
 import torch
 from safetensors import safe_open
@@ -96,6 +96,9 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
            "_name_or_path": output_dir}
     with open(os.path.join(output_dir, "config.json"), "w") as f:
         json.dump(top, f, indent=1)
+    tok = getattr(model, "tokenizer", None)                     # llava_arch.py:164-165: the tokenizer lives in llm/ (a synthetic stand-in has nothing to save)
+    if tok is not None and hasattr(tok, "save_pretrained"):
+        tok.save_pretrained(os.path.join(output_dir, "llm"))
 
 
 def resolve_projector_type(top: dict, model_dir: str = "") -> str:
@@ -180,11 +183,44 @@ def load_weights_into(model, model_dir: str, strict: bool = True) -> Dict[str, l
     return report
 
 
+MEDIA_TOKENS = {"image": "<image>", "video": "<vila/video>"}          # llava/constants.py:32-35
+
+
+def load_tokenizer(model_dir: str, model_max_length: Optional[int] = None):
+    """The tokenizer half of `build_llm_and_tokenizer` (language_model/builder.py:190-211): `AutoTokenizer.from_pretrained(<dir>/llm,
+    padding_side="right", use_fast=True, legacy=False)`, `model_max_length`, the media tokens added as special tokens and their ids recorded
+    in `media_token_ids`.  None when the folder holds no tokenizer files or transformers is absent (the model then keeps its stand-in)."""
+    llm_dir = os.path.join(model_dir, "llm")
+    if not any(os.path.exists(os.path.join(llm_dir, f)) for f in ("tokenizer.json", "tokenizer_config.json", "tokenizer.model", "vocab.json")):
+        return None
+    try:
+        from transformers import AutoTokenizer
+    except ImportError:
+        return None
+    tok = AutoTokenizer.from_pretrained(llm_dir, padding_side="right", use_fast=True, legacy=False)
+    if model_max_length is not None:
+        tok.model_max_length = model_max_length
+    tok.media_tokens = dict(MEDIA_TOKENS)
+    tok.media_token_ids = {}
+    for name, token in MEDIA_TOKENS.items():
+        tok.add_tokens([token], special_tokens=True)
+        tok.media_token_ids[name] = tok.convert_tokens_to_ids(token)
+    return tok
+
+
 def load_pretrained(model_dir: str, device="cuda", dtype=torch.bfloat16):
-    """`llava.load(model_path)` for the HIP model: config from config.json, weights from the three sub-folders."""
+    """`llava.load(model_path)` for the HIP model: config from config.json, weights from the three sub-folders, the tokenizer from llm/ when one
+    was saved there — the media-token and newline ids of the config then follow THAT tokenizer, as in the reference (the ids are not stored in its
+    config.json)."""
     from .vlm import HipLlavaLlamaModel
     cfg = config_from_pretrained(model_dir)
-    model = HipLlavaLlamaModel(cfg, device, dtype)
+    tok = load_tokenizer(model_dir)
+    if tok is not None:
+        cfg.image_token_id, cfg.video_token_id = int(tok.media_token_ids["image"]), int(tok.media_token_ids["video"])
+        nl = tok("\n").input_ids
+        if len(nl) == 1:
+            cfg.newline_token_id = int(nl[0])
+    model = HipLlavaLlamaModel(cfg, device, dtype, tokenizer=tok)
     load_weights_into(model, model_dir)
     return model
 
