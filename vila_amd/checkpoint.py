@@ -91,7 +91,8 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
     top = {"model_type": "llava_llama", "architectures": ["LlavaLlamaModel"], "llm_cfg": llm_cfg, "vision_tower_cfg": vt_cfg,
            "mm_projector_cfg": pj_cfg, "mm_projector_type": cfg.mm_projector_type, "mm_vision_select_layer": v.select_layer,
            "mm_vision_select_feature": "cls_patch", "dynamic_s2": cfg.dynamic_s2, "s2_scales": ",".join(str(s) for s in cfg.s2_scales),
-           "s2_resize_output_to_scale_idx": cfg.s2_resize_output_to_scale_idx, "hidden_size": c.hidden_size,
+           "s2_resize_output_to_scale_idx": cfg.s2_resize_output_to_scale_idx, "image_aspect_ratio": cfg.image_aspect_ratio or None,
+           "min_tiles": cfg.min_tiles, "max_tiles": cfg.max_tiles, "video_max_tiles": cfg.video_max_tiles, "hidden_size": c.hidden_size,
            "mm_hidden_size": cfg.mm_hidden_size, "image_token_id": cfg.image_token_id, "newline_token_id": cfg.newline_token_id,
            "_name_or_path": output_dir}
     with open(os.path.join(output_dir, "config.json"), "w") as f:
@@ -146,7 +147,9 @@ def config_from_pretrained(model_dir: str) -> VilaConfig:
     return VilaConfig(vision=vis, llm=llm, mm_projector_type=resolve_projector_type(top, model_dir),
                       image_token_id=opt(top, "image_token_id", 151649), newline_token_id=opt(top, "newline_token_id", 198),
                       dynamic_s2=bool(opt(top, "dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
-                      s2_resize_output_to_scale_idx=opt(top, "s2_resize_output_to_scale_idx", -1), name=os.path.basename(model_dir.rstrip("/")))
+                      s2_resize_output_to_scale_idx=opt(top, "s2_resize_output_to_scale_idx", -1),
+                      image_aspect_ratio=str(opt(top, "image_aspect_ratio", "")), min_tiles=int(opt(top, "min_tiles", 1)),
+                      max_tiles=int(opt(top, "max_tiles", 12)), video_max_tiles=int(opt(top, "video_max_tiles", 1)), name=os.path.basename(model_dir.rstrip("/")))
 
 
 def _rope_theta(l: dict) -> float:

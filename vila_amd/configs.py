@@ -96,12 +96,23 @@ class VilaConfig:
     dynamic_s2: bool = False
     s2_scales: tuple = (448, 896, 1344)
     s2_resize_output_to_scale_idx: int = -1
-    max_tiles: int = 12              # configuration_llava.py:52 — the most tiles the last dynamic_s2 scale may use (mm_utils.py:341)
+    max_tiles: int = 12              # configuration_llava.py:52 — the most tiles the last dynamic_s2 scale / the `dynamic` tiler may use (mm_utils.py:299,341)
+    min_tiles: int = 1               # configuration_llava.py:51 — `dynamic_preprocess(min_num=...)` (mm_utils.py:477)
+    video_max_tiles: int = 1         # configuration_llava.py:53
+    # How `process_image` (mm_utils.py:442-523) turns a picture into tower inputs: "resize" (NVILA stage 4), "pad" (expand to a square on the
+    # processor's mean colour), "dynamic" (InternVL-style tiles + thumbnail: every NVILA-Lite script), "dynamic_s2" (every NVILA 9-tile script).
+    # "" = not stated: "dynamic_s2" when the dynamic_s2 flag is on, else the processor's default (SigLIP: resize).
+    image_aspect_ratio: str = ""
 
     @property
     def mm_hidden_size(self) -> int:
         """VisionTowerDynamicS2.hidden_size = C * len(scales) (vision_encoder.py:274-276)."""
         return self.vision.hidden_size * (len(self.s2_scales) if self.dynamic_s2 else 1)
+
+    @property
+    def aspect_mode(self) -> str:
+        """The `image_aspect_ratio` the pre-processing follows (see the field)."""
+        return self.image_aspect_ratio or ("dynamic_s2" if self.dynamic_s2 else "")
 
     @property
     def downsample(self) -> int:

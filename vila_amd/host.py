@@ -5,6 +5,8 @@
   * `repack`       — `repack_multimodal_data`, non-SP branch (llava_arch.py:744-800) + `_get_unpad_data`
                      (llava/model/utils/packing.py:12-21): packed row, restarted positions, cu_seqlens
   * `s2_plan`      — tile / block bookkeeping of the dynamic_s2 merge (llava_arch.py:298-390)
+  * `dynamic_tile_plan`, `dynamic_preprocess`, `expand2square` — the `dynamic` tiler of the NVILA-Lite recipe and the `pad` mode
+    (llava/mm_utils.py:299-338, 505-516)
   * `find_closest_aspect_ratio`, `dynamic_s2_tile_plan`, `dynamic_s2_preprocess` — the dynamic_s2 TILER (llava/mm_utils.py:283-296,
                      341-405): which tile grid an image of a given size gets, and the resize + crop that produces the tiles
 """
@@ -218,3 +220,43 @@ def dynamic_s2_preprocess(image, s2_scales=(448, 896, 1344), max_num: int = 12, 
         resized = image.resize(size)
         tiles.extend(resized.crop(b) for b in boxes)
     return tiles, block_size
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# `dynamic` tiler (every NVILA-Lite script: `--image_aspect_ratio dynamic`): llava/mm_utils.py:299-338 (dynamic_preprocess), :505-518 (pad)
+# ----------------------------------------------------------------------------------------------------------------------
+def dynamic_tile_plan(width: int, height: int, min_num: int = 1, max_num: int = 12, image_size: int = 384, use_thumbnail: bool = True):
+    """The integer half of `dynamic_preprocess` (mm_utils.py:299-338) -> ((target_w, target_h), crop boxes in tile order, thumbnail?).
+    The (cols, rows) grid with min_num <= cols * rows <= max_num closest to the image's aspect ratio (`find_closest_aspect_ratio`), tiles
+    walked row-major; a whole-image thumbnail follows the tiles unless the grid is 1 x 1."""
+    ratios = {(i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1) for j in range(1, n + 1) if min_num <= i * j <= max_num}
+    ratios = sorted(ratios, key=lambda x: x[0] * x[1])
+    cols, rows = find_closest_aspect_ratio(width / height, ratios, width, height, image_size)
+    tw, th = image_size * cols, image_size * rows
+    boxes = [((i % cols) * image_size, (i // cols) * image_size, (i % cols + 1) * image_size, (i // cols + 1) * image_size)
+             for i in range(cols * rows)]
+    return (tw, th), boxes, bool(use_thumbnail and len(boxes) != 1)
+
+
+def dynamic_preprocess(image, min_num: int = 1, max_num: int = 12, image_size: int = 384, use_thumbnail: bool = True):
+    """mm_utils.py:299-338 on a PIL image -> list of PIL tiles of image_size^2 (+ the thumbnail).  `Image.resize` with its default filter,
+    exactly as the reference calls it."""
+    w, h = image.size
+    size, boxes, thumb = dynamic_tile_plan(w, h, min_num, max_num, image_size, use_thumbnail)
+    resized = image.resize(size)
+    tiles = [resized.crop(b) for b in boxes]
+    if thumb:
+        tiles.append(image.resize((image_size, image_size)))
+    return tiles
+
+
+def expand2square(pil_img, background_color):
+    """mm_utils.py:505-516 (`image_aspect_ratio == "pad"`): the picture centred on a square canvas of its longer side."""
+    from PIL import Image
+    width, height = pil_img.size
+    if width == height:
+        return pil_img
+    side = max(width, height)
+    result = Image.new(pil_img.mode, (side, side), background_color)
+    result.paste(pil_img, (0, (width - height) // 2) if width > height else ((height - width) // 2, 0))
+    return result

@@ -58,16 +58,54 @@ def preprocess_image(img, size: int) -> torch.Tensor:
     return (x * (1.0 / 255.0) - 0.5) / 0.5
 
 
-def preprocess_media(images, cfg):
-    """The media half of `generate_content` (llava_arch.py:857-879): one image under the dynamic_s2 recipe becomes the tiles of every scale
-    (`dynamic_s2_preprocess`, mm_utils.py:341-405 -> vila_amd.host) with media_config["image"]["block_sizes"] = [block_size]; otherwise every
-    image is resized to the tower's resolution (`process_images`).  -> (list of [3, size, size] float tensors, media_config)."""
-    from .host import dynamic_s2_preprocess
+def process_image(img, cfg, enable_dynamic_res: bool = False, enable_dynamic_s2: bool = False, max_tiles: Optional[int] = None):
+    """`process_image` (mm_utils.py:442-523) for the SigLIP tower, `cfg.aspect_mode` standing for `data_args.image_aspect_ratio`:
+      * "dynamic_s2" + enable_dynamic_s2 -> ([n_tiles, 3, S, S], block_size): the tiles of every scale (`dynamic_s2_preprocess`)
+      * "dynamic*"   + enable_dynamic_res -> [n_tiles, 3, S, S]: the grid closest to the picture's aspect ratio + a thumbnail
+        (`dynamic_preprocess`, min_tiles .. max_tiles, `max_tiles=` overrides the config's)
+      * "resize" -> PIL resize to S x S; "pad" -> centred on a square of the processor's mean colour (`expand2square`), then the processor
+      * anything else -> the processor's default, which for SigLIP is the resize
+    every tile / picture through `preprocess_image` (= `SiglipImageProcessor.preprocess`).  Pinned by tests/golden/dynamic_tiles.npz = the
+    reference's own function executed on the same pictures."""
+    from .host import dynamic_preprocess, dynamic_s2_preprocess, expand2square
+    pil = _to_pil(img)
     size = cfg.vision.image_size
-    if getattr(cfg, "dynamic_s2", False) and len(images) == 1:
-        tiles, block_size = dynamic_s2_preprocess(_to_pil(images[0]), list(cfg.s2_scales), int(getattr(cfg, "max_tiles", 12)), size)
-        return [preprocess_image(t, size) for t in tiles], {"image": {"block_sizes": [block_size]}}
-    return [preprocess_image(im, size) for im in images], {}
+    mode = cfg.aspect_mode
+    if "dynamic_s2" in mode and enable_dynamic_s2:
+        tiles, block_size = dynamic_s2_preprocess(pil, list(cfg.s2_scales), int(cfg.max_tiles), size)
+        return torch.stack([preprocess_image(t, size) for t in tiles]), block_size
+    if "dynamic" in mode and enable_dynamic_res:
+        max_num = int(max_tiles) if max_tiles is not None else int(cfg.max_tiles)
+        tiles = dynamic_preprocess(pil, min_num=int(cfg.min_tiles), max_num=max_num, image_size=size)
+        return torch.stack([preprocess_image(t, size) for t in tiles])
+    if mode == "resize":
+        pil = pil.resize((size, size))
+    if mode == "pad":
+        pil = expand2square(pil, tuple(int(x * 255) for x in (0.5, 0.5, 0.5)))           # SiglipImageProcessor.image_mean
+    return preprocess_image(pil, size)
+
+
+def process_images(images, cfg, enable_dynamic_res: bool = False, max_tiles: Optional[int] = None) -> torch.Tensor:
+    """`process_images` (mm_utils.py:526-541): every picture through `process_image`; tiled pictures ([n, 3, S, S] each) are concatenated,
+    whole ones stacked; pictures whose results differ in shape (different tile counts) are refused with the reference's message."""
+    new_images = [process_image(im, cfg, enable_dynamic_res=enable_dynamic_res, max_tiles=max_tiles) for im in images]
+    if not all(x.shape == new_images[0].shape for x in new_images):
+        raise ValueError("The shape of images in new_images is different!")
+    return torch.cat(new_images, dim=0) if new_images[0].dim() == 4 else torch.stack(new_images, dim=0)
+
+
+def preprocess_media(images, cfg):
+    """The media half of `generate_content` (llava_arch.py:857-879): ONE image under a tiling recipe becomes its tiles — `dynamic_s2`: the
+    tiles of every scale with media_config["image"]["block_sizes"] = [block_size]; `dynamic`: the aspect-ratio grid + thumbnail (the prompt
+    then carries one `<image>\n` per tile, see `prepare_prompt`); otherwise every image goes through `process_images` whole.
+    -> (list of [3, size, size] float tensors, media_config)."""
+    mode = cfg.aspect_mode
+    if len(images) == 1 and mode == "dynamic_s2":
+        tiles, block_size = process_image(images[0], cfg, enable_dynamic_s2=True)
+        return list(tiles), {"image": {"block_sizes": [block_size]}}
+    if len(images) == 1 and mode == "dynamic":
+        return list(process_image(images[0], cfg, enable_dynamic_res=True)), {}
+    return ([] if not images else list(process_images(images, cfg))), {}
 
 
 def load_image(url: str):
@@ -174,6 +212,17 @@ def _split_prompt(prompt: Union[str, Sequence[Any]]):
     return text, images
 
 
+def prepare_prompt(prompt: Union[str, Sequence[Any]], cfg):
+    """Prompt parts -> (text, tiles, media_config): `extract_media` + the media branch of `generate_content` (llava_arch.py:842-879).  Under
+    the `dynamic` recipe a single image's `<image>` becomes one `<image>\n` per tile (:864-866; the dataset path builds the same text,
+    mm_utils.py:408-424).  The text is stripped like `tokenize_conversation` does with every message (llava/utils/tokenizer.py:77-78)."""
+    text, images = _split_prompt(prompt)
+    tiles, media_config = preprocess_media(images, cfg)
+    if len(images) == 1 and cfg.aspect_mode == "dynamic":
+        text = text.replace(IMAGE_TOKEN, f"{IMAGE_TOKEN}\n" * len(tiles))
+    return text.strip(), tiles, media_config
+
+
 def chat_text(text: str, system: Optional[str] = None) -> str:
     """Qwen2 chat form with the generation prompt appended (tokenize_conversation(add_generation_prompt=True), llava/utils/tokenizer.py)."""
     s = f"<|im_start|>system\n{system}<|im_end|>\n" if system else ""
@@ -196,11 +245,10 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
                      seed: Optional[int] = None) -> str:
     """Text + images in, decoded reply out — the contract of `LlavaLlamaModel.generate_content` for image / text prompts.
     temperature > 0 samples (server.py:185-187: do_sample = temperature > 0, with the request's top_p and HF's default top_k = 50)."""
-    text, images = _split_prompt(prompt)
     cfg = model.cfg
     dev = device or str(model.device)
+    text, tiles, media_config = prepare_prompt(prompt, cfg)
     ids = encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
-    tiles, media_config = preprocess_media(images, cfg)
     media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
     gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
@@ -227,11 +275,10 @@ def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequen
     dev = device or str(model.device)
     rows, tiles, blocks = [], [], []
     for prompt in prompts:
-        text, imgs = _split_prompt(prompt)
+        text, t, mc = prepare_prompt(prompt, cfg)             # per request, like generate_content: one image -> its tiles
         rows.append(encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id))
-        t, mc = preprocess_media(imgs, cfg)                   # per request, like generate_content: one image -> the dynamic_s2 tiles
         tiles.extend(t)
-        blocks.extend(mc.get("image", {}).get("block_sizes", [None] * len(imgs)))
+        blocks.extend(mc.get("image", {}).get("block_sizes", [None] * len(t)))
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
     pad = pad_token_id if pad_token_id is not None else (getattr(tokenizer, "pad_token_id", None) or 0)
@@ -341,9 +388,8 @@ class HipBatchEngine:
         """Prompt -> spliced embeddings [S, H] on the device (tower + projector + splice run here, on the worker thread)."""
         cfg = self.model.cfg
         dev = str(self.model.device)
-        text, images = _split_prompt(prompt)
+        text, tiles, media_config = prepare_prompt(prompt, cfg)
         ids = encode_with_images(self.tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
-        tiles, media_config = preprocess_media(images, cfg)
         media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
         e, _, _ = self.model._embed(ids, media, media_config)
         return e[0]
