@@ -406,3 +406,148 @@ def test_endpoint_routes_every_request_through_the_one_worker_thread():
     assert app.state.batcher.model_lock.acquire(timeout=1)             # the lock the sampled request ran under is free again
     app.state.batcher.model_lock.release()
     app.state.batcher.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# streaming (server.py:241-270): tokens leave as they are generated — TextStream == HF's TextIteratorStreamer, SSE framing, the batcher
+# ----------------------------------------------------------------------------------------------------------------------
+def _bpe_tokenizer():
+    """A byte-level BPE tokenizer trained here on a few lines (no files, no network): sub-word pieces, spaces inside tokens, newlines,
+    CJK — everything the streamer's release rule looks at."""
+    tokenizers = pytest.importorskip("tokenizers")
+    transformers = pytest.importorskip("transformers")
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    tk = Tokenizer(models.BPE())
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    corpus = ["the quick brown fox jumps over the lazy dog", "a red square sits on a blue table\nnext to a green circle",
+              "streaming replies leave the server word by word", "图片里有一个红色的方块", "hello world, hello again!  two  spaces"] * 4
+    tk.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=320, special_tokens=["<|im_end|>"], initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    return transformers.PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="<|im_end|>")
+
+
+def test_text_stream_equals_hf_text_iterator_streamer_piece_by_piece():
+    """The release rule (up to the last space; everything after a newline or a CJK character; the rest at the end) against the class the
+    reference's server iterates (`transformers.TextIteratorStreamer`, server.py:22) — same token sequences, token by token, every piece
+    (the empty ones included) equal and in order."""
+    tok = _bpe_tokenizer()
+    from transformers import TextIteratorStreamer
+    texts = ["the quick brown fox", "a red square\nnext to a green circle\n", "图片里有一个红色的方块 and a fox", "hello  world,  two  spaces!", "x",
+             "streaming replies leave the server word by word"]
+    eos = tok.eos_token_id
+    for text in texts:
+        ids = tok(text, add_special_tokens=False).input_ids + [eos]
+        assert len(ids) > len(text.split())                                  # sub-word pieces: words DO span tokens
+        hf = TextIteratorStreamer(tok, skip_special_tokens=True)
+        mine = serving.TextStream(tok)
+        for t in ids:
+            hf.put(torch.tensor([t]))
+            mine.put(torch.tensor([t]))
+        hf.end()
+        mine.end()
+        want, got = list(hf), list(mine)
+        assert got == want, (text, got, want)
+        assert "".join(got) == tok.decode(ids, skip_special_tokens=True) == text
+        assert mine.token_ids == ids
+    # lists, nested one-row lists and whole chunks are taken token by token too; two rows are refused like HF does
+    a, b = serving.TextStream(tok), serving.TextStream(tok)
+    ids = tok("the quick brown fox jumps", add_special_tokens=False).input_ids
+    for t in ids:
+        a.put([t])
+    b.put([ids])
+    a.end(), b.end()
+    assert list(a) == list(b)
+    with pytest.raises(ValueError, match="batch size 1"):
+        serving.TextStream(tok).put([[1, 2], [3, 4]])
+    # a failure reaches the consumer; a producer that never streamed hands over the whole reply
+    s = serving.TextStream(tok)
+    s.put(ids[:2])
+    s.fail(RuntimeError("boom"))
+    with pytest.raises(RuntimeError, match="boom"):
+        list(s)
+    s = serving.TextStream(tok)
+    s.finish("whole reply")
+    assert "".join(s) == "whole reply"
+
+
+def test_sse_chunks_follow_the_reference_chunk_generator():
+    """server.py:243-268: a lone space is held back and prepended, a trailing stop string is cut (and the piece stripped), empty pieces send
+    nothing, `[DONE]` closes."""
+    ev = list(serving.sse_chunks(["", "a ", " ", "red", "", " square <|im_end|>", ""], "M"))
+    assert ev[-1] == "data: [DONE]\n\n" and all(e.startswith("data: ") and e.endswith("\n\n") for e in ev)
+    body = [json.loads(e[6:]) for e in ev[:-1]]
+    assert [b["choices"][0]["delta"]["content"] for b in body] == ["a ", " red", "square"]
+    assert all(b["object"] == "chat.completion.chunk" and b["model"] == "M" for b in body)
+
+
+def test_continuous_batcher_streams_a_row_while_it_decodes():
+    """A streamed request's pieces arrive while its row is still live (first token at admission, then after every chunk of steps), stop at the
+    EOS, and add up to the reply the future gets; a solo request streams through the engine's streamer or, failing that, as one piece."""
+    import time as _t
+
+    class _WordTok:
+        def decode(self, ids, skip_special_tokens=True):
+            return " ".join(str(i) for i in ids if not (skip_special_tokens and i == 1))
+    eng = _StubEngine(n_slots=2, step_sleep=0.01)
+    b = serving.ContinuousBatcher(eng, max_batch=2, chunk=4)
+    try:
+        st = serving.TextStream(_WordTok(), timeout=30)
+        fut = b.submit("A:21", 48, stream=st)
+        first = next(st)                                                  # blocks until the admission's token was put
+        early = not fut.done()                                            # 21 tokens x 10 ms per step: the row is still decoding
+        pieces = [first] + list(st)
+        assert early, "the first piece only arrived with the finished reply"
+        assert "".join(pieces) == fut.result(timeout=30) == _want(21)
+        assert st.token_ids == [100 + i for i in range(21)] + [1]         # every token once, the EOS included (HF puts it too), nothing after it
+        # max_new_tokens cuts the stream where it cuts the reply
+        st = serving.TextStream(_WordTok(), timeout=30)
+        fut = b.submit("B:30", 10, stream=st)
+        assert "".join(st) == fut.result(timeout=30) == _want(30, 10) and len(st.token_ids) == 10
+        # a solo request (sampled): the stub engine takes no streamer -> the whole reply as one piece
+        st = serving.TextStream(_WordTok(), timeout=30)
+        fut = b.submit("S:4", 16, stream=st, temperature=0.7)
+        assert "".join(st) == fut.result(timeout=30) == "solo S:4 t=0.7"
+        # a failing request fails its stream too
+        st = serving.TextStream(_WordTok(), timeout=30)
+        fut = b.submit("broken", 16, stream=st)                           # the stub's embed() cannot parse this prompt
+        with pytest.raises(Exception):
+            list(st)
+        assert fut.exception(timeout=30) is not None
+    finally:
+        b.close()
+
+
+def test_endpoint_streams_tokens_from_the_generate_call():
+    """`stream=True` without a batcher: the generate call runs on its own thread (the reference's Thread + TextIteratorStreamer) and the
+    endpoint forwards the pieces as they are put — here a model that feeds its streamer one token at a time."""
+    pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    tok = _Tok()
+
+    class _StreamingModel(_Model):
+        def generate(self, input_ids, media, max_new_tokens, eos_token_id, media_config=None, streamer=None, **sampling):
+            reply = self.tok("a red square on a table").input_ids + [1]
+            self.streamed = streamer is not None
+            for t in reply:
+                if streamer is not None:
+                    streamer.put(torch.tensor([t]))
+            if streamer is not None:
+                streamer.end()
+            return torch.tensor([reply])
+    m = _StreamingModel(tok)
+    client = TestClient(serving.create_app(m, tok, model_name="stub"))
+    body = {"model": "stub", "max_tokens": 8, "temperature": 0.0, "stream": True, "messages": [{"role": "user", "content": "what is this ?"}]}
+    r = client.post("/chat/completions", json=body)
+    assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream") and m.streamed
+    events = [e for e in r.text.split("\n\n") if e]
+    words = [json.loads(e[6:])["choices"][0]["delta"]["content"] for e in events[:-1]]
+    assert events[-1] == "data: [DONE]" and len(words) == 6 and "".join(words) == "a red square on a table"
+    # an error before any text is the reference's 500 body, not a broken stream
+    r = client.post("/chat/completions", json=dict(body, model="other"))
+    assert r.status_code == 500 and "configured to use the model" in r.json()["error"]
+
+    class _Failing(_Model):
+        def generate(self, *a, **k):
+            raise RuntimeError("tower on fire")
+    r = TestClient(serving.create_app(_Failing(tok), tok, model_name="stub")).post("/chat/completions", json=body)
+    assert r.status_code == 500 and "tower on fire" in r.json()["error"]

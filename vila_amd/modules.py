@@ -691,14 +691,18 @@ class HipQwen2ForCausalLM(_HipModule):
                  eos_token_id=None, do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
                  top_p: Optional[float] = None, seed: Optional[int] = None, pad_token_id: Optional[int] = None, generation_config=None,
                  use_graph: bool = True, return_logits: bool = False, forced_ids: Optional[torch.Tensor] = None, cache=None,
-                 max_length: Optional[int] = None, **kw):
+                 max_length: Optional[int] = None, streamer=None, **kw):
         """`llm.generate(inputs_embeds=, attention_mask=, **generation_kwargs)` as called at llava_arch.py:833 (HF semantics: returns ONLY the
         new tokens, [B, n_new]).  Greedy search or sampling (do_sample: temperature / top_k / top_p, HF order, on the device); explicit
         keyword arguments override `generation_config` (HF GenerationConfig-like: do_sample, temperature, top_k, top_p, max_new_tokens,
         eos_token_id, pad_token_id).  The whole step (28 layers + lm_head + token choice + position advance) is one hipGraph replay; the host
         polls for EOS every 16 tokens.  A padded batch (B > 1) is served one sequence at a time through the same cache and graph (each row
         costs a batch-1 decode: weights are streamed once per row and token) and right-padded with pad_token_id like HF.
-        forced_ids = teacher forcing for margin-aware parity tests."""
+        forced_ids = teacher forcing for margin-aware parity tests.
+        streamer = HF's `generate(streamer=...)` contract (what server.py:243 streams from): `put(LongTensor[1])` once per new token — the EOS
+        included, nothing for a prompt given as embeddings — as the host learns of them (every 16 graph replays), then `end()`; batch size 1."""
+        if streamer is not None and inputs_embeds.shape[0] > 1:
+            raise ValueError("TextStreamer only supports batch size 1")          # transformers/generation/streamers.py, TextStreamer.put
         gc = generation_config
         pick = lambda v, name, default: v if v is not None else (getattr(gc, name, None) if gc is not None and getattr(gc, name, None) is not None else default)
         do_sample = bool(pick(do_sample, "do_sample", False))
@@ -789,14 +793,22 @@ class HipQwen2ForCausalLM(_HipModule):
         else:
             torch.cuda.current_stream().synchronize()
             done = 0
-            stop = first.item() in eos_set
+            first_id = first.item()
+            stop = first_id in eos_set
+            if streamer is not None:
+                streamer.put(torch.tensor([first_id], dtype=torch.int64))
             with torch.cuda.stream(st.stream):
                 while done < n_steps and not stop:
                     chunk = min(16, n_steps - done)
                     for _ in range(chunk):
                         check(lib.vila_graph_launch(st.graph, st.stream.cuda_stream), "graph_launch")
+                    got = st.out_ids[:done + chunk].tolist()       # one sync per 16 tokens
+                    if streamer is not None:
+                        for t in got[done:]:
+                            streamer.put(torch.tensor([t], dtype=torch.int64))
+                            if t in eos_set:
+                                break
                     done += chunk
-                    got = st.out_ids[:done].tolist()       # one sync per 16 tokens
                     stop = any(t in eos_set for t in got)
             st.stream.synchronize()
             out = torch.cat([first, st.out_ids[:done]])
@@ -810,5 +822,10 @@ class HipQwen2ForCausalLM(_HipModule):
                 if t in eos_set:
                     out = out[: i + 1]
                     break
+        if streamer is not None:
+            if eager:                                       # the step-by-step paths learn of their tokens at the end
+                for t in out.tolist():
+                    streamer.put(torch.tensor([t], dtype=torch.int64))
+            streamer.end()
         out = out[None]
         return (out, torch.stack(step_logits)) if return_logits else out

@@ -3,9 +3,12 @@
 Mirrors the parts of the reference a client sees:
   * `LlavaLlamaModel.generate_content(prompt)` (llava/model/llava_arch.py:836-948): a prompt is a string or a list of parts (strings and
     images); media are extracted in order, pre-processed, the text gets one `<image>` token per image, greedy generation, decoded text
-  * `server.py:171-290`: POST /chat/completions with OpenAI-style messages (`text` / `image_url` parts, base64 data URLs), the response
-    object layout, `stream=True` as server-sent `chat.completion.chunk` events
-What stays in the reference: conversation templates beyond the Qwen2 chat form, video decoding, structured output (xgrammar).
+  * `server.py:171-290`: POST /chat/completions with OpenAI-style messages (`text` / `image_url` / `video_url` parts, base64 data URLs), the
+    response object layout, `stream=True` as server-sent `chat.completion.chunk` events that leave WHILE the reply is generated
+    (`TextStream` = `transformers.TextIteratorStreamer`'s release rule, fed by `llm.generate(streamer=...)` or by the continuous batcher)
+  * `process_image` / `process_images` (llava/mm_utils.py:442-541): every `image_aspect_ratio` mode — resize, pad, dynamic (the NVILA-Lite
+    tiler), dynamic_s2 (the NVILA tiler)
+What stays in the reference: conversation templates beyond the Qwen2 chat form, video FILE decoding (OpenCV), structured output (xgrammar).
 The tokenizer is whatever the checkpoint ships (`transformers.AutoTokenizer`), handed in by the caller; images are pre-processed the way
 `SiglipImageProcessor` does for NVILA (resize to the tower's resolution, bicubic, rescale 1/255, normalise mean = std = 0.5).
 """
@@ -14,9 +17,11 @@ from __future__ import annotations
 import base64
 import glob
 import io
+import itertools
 import json
 import os
 import re
+import threading
 import time
 import uuid
 from types import SimpleNamespace
@@ -240,11 +245,116 @@ def encode_with_images(tokenizer, text: str, image_token_id: int) -> torch.Tenso
     return torch.tensor(ids, dtype=torch.int64)
 
 
+def _is_cjk(cp: int) -> bool:
+    """transformers/generation/streamers.py `TextStreamer._is_chinese_char`: the CJK Unified Ideographs blocks."""
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F
+            or 0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+
+class TextStream:
+    """Token ids in, text pieces out, across threads — what `transformers.TextIteratorStreamer` is to the reference's server
+    (server.py:22, 241-270: `for new_text in streamer`).  `put` / `end` follow `TextStreamer.put` / `end` token by token: the cache of
+    undecoded tokens is decoded whole; text up to the last space is released (a word may still change with the next token), everything
+    after a newline (the cache restarts) or a CJK character.  Pieces — empty ones too, as HF queues them — wait in a queue for the
+    consumer; `fail(exc)` makes the consumer raise.  Pinned by tests/test_serving_cpu.py against HF's class run on the same token sequences."""
+
+    _END = object()
+
+    def __init__(self, tokenizer, skip_special_tokens: bool = True, timeout: Optional[float] = None):
+        import queue
+        self.tokenizer, self.skip_special_tokens, self.timeout = tokenizer, skip_special_tokens, timeout
+        self._cache: List[int] = []
+        self._print_len = 0
+        self._q: "queue.Queue" = queue.Queue()
+        self._ended = False
+        self.token_ids: List[int] = []                   # everything that was put (observability / tests)
+
+    def _decode(self) -> str:
+        return self.tokenizer.decode(self._cache, skip_special_tokens=self.skip_special_tokens)
+
+    def put(self, value) -> None:
+        ids = value.tolist() if hasattr(value, "tolist") else value
+        if isinstance(ids, int):
+            ids = [ids]
+        if ids and isinstance(ids[0], (list, tuple)):
+            if len(ids) > 1:
+                raise ValueError("TextStreamer only supports batch size 1")
+            ids = ids[0]
+        for t in ids:
+            self.token_ids.append(int(t))
+            self._cache.append(int(t))
+            text = self._decode()
+            if text.endswith("\n"):
+                piece = text[self._print_len:]
+                self._cache, self._print_len = [], 0
+            elif len(text) > 0 and _is_cjk(ord(text[-1])):
+                piece = text[self._print_len:]
+                self._print_len += len(piece)
+            else:
+                piece = text[self._print_len: text.rfind(" ") + 1]
+                self._print_len += len(piece)
+            self._q.put(piece)
+
+    def end(self) -> None:
+        piece = ""
+        if self._cache:
+            piece = self._decode()[self._print_len:]
+            self._cache, self._print_len = [], 0
+        self._q.put(piece)
+        self._q.put(self._END)
+        self._ended = True
+
+    def finish(self, text: str) -> None:
+        """For a producer whose `generate` took no streamer (it never called `put` / `end`): the whole reply as one piece, then the end."""
+        if not self._ended:
+            if not self.token_ids:
+                self._q.put(text)
+            self.end()
+
+    def fail(self, exc: BaseException) -> None:
+        self._q.put(exc)
+        self._ended = True
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> str:
+        item = self._q.get(timeout=self.timeout)
+        if item is self._END:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+
+def sse_chunks(pieces, model_name: str, stop_str: str = "<|im_end|>") -> Iterator[str]:
+    """The `chunk_generator` of server.py:243-268: text pieces -> server-sent `chat.completion.chunk` events.  A lone " " is held back and
+    prepended to the next piece; a piece that ends with the stop string loses it (and is stripped); empty pieces send nothing; `[DONE]` closes."""
+    prepend_space = False
+    chunk_id = 0
+    for new_text in pieces:
+        if new_text == " ":
+            prepend_space = True
+            continue
+        if stop_str and new_text.endswith(stop_str):
+            new_text = new_text[: -len(stop_str)].strip()
+            prepend_space = False
+        elif prepend_space:
+            new_text = " " + new_text
+            prepend_space = False
+        if len(new_text):
+            chunk = {"id": str(chunk_id), "object": "chat.completion.chunk", "created": time.time(), "model": model_name,
+                     "choices": [{"delta": {"content": new_text}}]}
+            yield f"data: {json.dumps(chunk)}\n\n"
+    yield "data: [DONE]\n\n"
+
+
 def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_new_tokens: int = 128, system: Optional[str] = None,
                      eos_token_id=None, device: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 50,
-                     seed: Optional[int] = None) -> str:
+                     seed: Optional[int] = None, streamer=None) -> str:
     """Text + images in, decoded reply out — the contract of `LlavaLlamaModel.generate_content` for image / text prompts.
-    temperature > 0 samples (server.py:185-187: do_sample = temperature > 0, with the request's top_p and HF's default top_k = 50)."""
+    temperature > 0 samples (server.py:185-187: do_sample = temperature > 0, with the request's top_p and HF's default top_k = 50).
+    streamer: a `TextStream` (or any HF streamer) that receives the new tokens while they are generated (`llm.generate(streamer=...)`)."""
     cfg = model.cfg
     dev = device or str(model.device)
     text, tiles, media_config = prepare_prompt(prompt, cfg)
@@ -254,6 +364,8 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
     gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
     if temperature and temperature > 0:
         gen.update(do_sample=True, temperature=float(temperature), top_p=float(top_p), top_k=int(top_k), seed=seed)
+    if streamer is not None:
+        gen.update(streamer=streamer)
     out = model.generate(input_ids=ids, media=media, media_config=media_config, **gen)
     toks = out[0].tolist()
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
@@ -409,8 +521,8 @@ class HipBatchEngine:
     def release(self, slots) -> None:
         self.model.llm.batch_release(self._session(), slots)
 
-    def solo(self, prompt, max_new_tokens, system, **gen) -> str:
-        return generate_content(self.model, self.tokenizer, prompt, max_new_tokens=max_new_tokens, system=system, **gen)
+    def solo(self, prompt, max_new_tokens, system, streamer=None, **gen) -> str:
+        return generate_content(self.model, self.tokenizer, prompt, max_new_tokens=max_new_tokens, system=system, streamer=streamer, **gen)
 
     def decode(self, toks) -> str:
         return self.tokenizer.decode(toks, skip_special_tokens=True).strip()
@@ -438,11 +550,14 @@ class ContinuousBatcher:
         self._thread = threading.Thread(target=self._loop, daemon=True)
         self._thread.start()
 
-    def submit(self, prompt, max_new_tokens: int = 128, system: Optional[str] = None, **gen):
-        """-> Future of the decoded reply.  gen: temperature / top_p / top_k / seed — a request with temperature > 0 is a solo one."""
+    def submit(self, prompt, max_new_tokens: int = 128, system: Optional[str] = None, stream: Optional["TextStream"] = None, **gen):
+        """-> Future of the decoded reply.  gen: temperature / top_p / top_k / seed — a request with temperature > 0 is a solo one.
+        stream: a `TextStream` that receives the request's tokens while the row is still decoding — its first token at admission, then
+        the new ones after every chunk of steps (server.py:241-270 streams a reply as it is generated); `end()` when the row retires,
+        `fail()` with the exception the future gets."""
         from concurrent.futures import Future
         f: Future = Future()
-        self._q.put(SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f))
+        self._q.put(SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f, stream=stream))
         return f
 
     def close(self):
@@ -455,6 +570,27 @@ class ContinuousBatcher:
         t = req.gen.get("temperature")
         return not t or t <= 0
 
+    @staticmethod
+    def _fail(req, ex) -> None:
+        if not req.fut.done():
+            req.fut.set_exception(ex)
+        if getattr(req, "stream", None) is not None:
+            req.stream.fail(ex)
+
+    def _emit(self, row, new) -> None:
+        """A row's new tokens -> its stream, like HF's `streamer.put` per token: up to AND including the first EOS, never past max_new_tokens."""
+        st = row.req.stream
+        if st is None or row.closed:
+            return
+        for t in new:
+            if row.sent >= row.req.max_new:
+                break
+            st.put([t])
+            row.sent += 1
+            if t in self.engine.eos:
+                row.closed = True
+                break
+
     def _finish(self, row, toks):
         eng = self.engine
         for k, t in enumerate(toks):                       # HF stops AFTER emitting eos; decode(skip_special_tokens) drops it
@@ -462,6 +598,8 @@ class ContinuousBatcher:
                 toks = toks[:k]
                 break
         row.req.fut.set_result(eng.decode(toks))
+        if row.req.stream is not None:
+            row.req.stream.end()
 
     def _loop(self):
         import collections
@@ -488,7 +626,7 @@ class ContinuousBatcher:
                 if self._stop:
                     for r in list(rows.values()) + [SimpleNamespace(req=p) for p in pending]:
                         if not r.req.fut.done():
-                            r.req.fut.set_exception(RuntimeError("batcher closed"))
+                            self._fail(r.req, RuntimeError("batcher closed"))
                     return
                 # ---- admit greedy requests at the head of the line into free rows; a solo request waits for the rows to drain ----
                 while pending and free:
@@ -503,8 +641,9 @@ class ContinuousBatcher:
                         pending.popleft()
                         slot = free.pop(0)
                         first = eng.admit(slot, e)
-                        row = SimpleNamespace(req=req, toks=[first], read=0)
+                        row = SimpleNamespace(req=req, toks=[first], read=0, sent=0, closed=False)
                         self.events.append(("admit", slot, steps, len(rows)))
+                        self._emit(row, [first])
                         if first in eng.eos or req.max_new <= 1:
                             self._finish(row, row.toks)
                             eng.release([slot])
@@ -515,16 +654,21 @@ class ContinuousBatcher:
                     except Exception as ex:                            # the request fails, the batch goes on
                         if pending and pending[0] is req:
                             pending.popleft()
-                        req.fut.set_exception(ex)
+                        self._fail(req, ex)
                 if not rows:
                     if pending and (not self._greedy(pending[0]) or pending[0].gen.get("_solo")):
                         req = pending.popleft()
                         gen = {k: v for k, v in req.gen.items() if k != "_solo" and v is not None}
                         self.events.append(("solo", steps))
                         try:
-                            req.fut.set_result(eng.solo(req.prompt, req.max_new, req.system, **gen))
+                            if req.stream is not None:
+                                gen["streamer"] = req.stream
+                            text = eng.solo(req.prompt, req.max_new, req.system, **gen)
+                            req.fut.set_result(text)
+                            if req.stream is not None:
+                                req.stream.finish(text)                 # (an engine whose generate took no streamer)
                         except Exception as ex:
-                            req.fut.set_exception(ex)
+                            self._fail(req, ex)
                     continue
                 # ---- one chunk of batched steps: never past the row that is closest to its max_new_tokens ----
                 k = min(self.chunk, min(r.req.max_new - len(r.toks) for r in rows.values()))
@@ -533,7 +677,7 @@ class ContinuousBatcher:
                     n_out, out = eng.read()
                 except Exception as ex:
                     for r in rows.values():
-                        r.req.fut.set_exception(ex)
+                        self._fail(r.req, ex)
                     free.extend(rows)
                     rows.clear()
                     continue
@@ -541,8 +685,10 @@ class ContinuousBatcher:
                 self.events.append(("run", k, len(rows)))
                 done = []
                 for slot, row in rows.items():
-                    row.toks.extend(out[slot][row.read:n_out[slot]])
+                    new = out[slot][row.read:n_out[slot]]
+                    row.toks.extend(new)
                     row.read = n_out[slot]
+                    self._emit(row, new)
                     if any(t in eng.eos for t in row.toks) or len(row.toks) >= row.req.max_new:
                         self._finish(row, row.toks[:row.req.max_new])
                         done.append(slot)
@@ -570,7 +716,8 @@ def _request_models():
     return _MODELS
 
 
-def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: Optional[float] = None, max_batch: int = 8):
+def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: Optional[float] = None, max_batch: int = 8,
+               stream_timeout_s: Optional[float] = 600.0):
     """FastAPI app with the reference's POST /chat/completions (server.py:171-290).  Import-time optional: needs fastapi + pydantic.
     batch_window_s: when set (any value), requests go through a batcher whose ONE worker thread owns the model: `ContinuousBatcher` (greedy
     requests join / leave the batched decode step between steps; sampled ones run solo on the same thread) where the model has the batched
@@ -616,36 +763,47 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: O
                 parts.append(f"<|im_end|>\n<|im_start|>assistant\n{m.content}<|im_end|>\n<|im_start|>user\n")
         return parts, system
 
+    model_lock = batcher.model_lock if isinstance(batcher, RequestBatcher) else threading.Lock()
+    app.state.model_lock = model_lock
+
+    def _solo(parts, n, system, temperature, top_p, streamer=None):
+        """A request the batcher does not take: under the model lock — never beside the worker thread's batch, never beside another solo
+        request."""
+        with model_lock, torch.inference_mode():
+            return generate_content(model, tokenizer, parts, max_new_tokens=n, system=system, temperature=temperature, top_p=top_p, streamer=streamer)
+
     async def chat_completions(request):
+        import asyncio
         try:
             if request.model != model_name:
                 raise ValueError(f"The endpoint is configured to use the model {model_name}, but the request model is {request.model}")
             parts, system = _prompt_of(request.messages)
             temperature = request.temperature if request.temperature is not None else 0.2
             top_p = request.top_p if request.top_p is not None else 0.9
-            if isinstance(batcher, ContinuousBatcher):
-                import asyncio
-                fut = batcher.submit(parts, request.max_tokens or 512, system, temperature=temperature, top_p=top_p)
-                text = await asyncio.get_running_loop().run_in_executor(None, fut.result)
-            elif batcher is not None and not temperature:
-                import asyncio
-                fut = batcher.submit(parts, request.max_tokens or 512, system)
-                text = await asyncio.get_running_loop().run_in_executor(None, fut.result)
-            elif batcher is not None:
-                with batcher.model_lock, torch.inference_mode():      # never beside the worker thread's batch
-                    text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
-                                            temperature=temperature, top_p=top_p)
-            else:
-                with torch.inference_mode():
-                    text = generate_content(model, tokenizer, parts, max_new_tokens=request.max_tokens or 512, system=system,
-                                            temperature=temperature, top_p=top_p)
+            n = request.max_tokens or 512
+            loop = asyncio.get_running_loop()
             if request.stream:
-                def chunks() -> Iterator[str]:
-                    for i, word in enumerate(re.findall(r"\S+\s*", text)):
-                        yield "data: " + json.dumps({"id": str(i), "object": "chat.completion.chunk", "created": time.time(), "model": request.model,
-                                                     "choices": [{"delta": {"content": word}}]}) + "\n\n"
-                    yield "data: [DONE]\n\n"
-                return StreamingResponse(chunks())
+                # server.py:241-270: the reply leaves as it is generated.  The tokens reach a `TextStream` from whoever runs the request (the
+                # continuous batcher's worker after every chunk of steps, else a thread of its own: the reference's Thread + TextIteratorStreamer)
+                stream = TextStream(tokenizer, timeout=stream_timeout_s)
+                if isinstance(batcher, ContinuousBatcher):
+                    batcher.submit(parts, n, system, stream=stream, temperature=temperature, top_p=top_p)
+                else:
+                    def run():
+                        try:
+                            stream.finish(_solo(parts, n, system, temperature, top_p, streamer=stream))
+                        except Exception as ex:                       # the consumer raises it
+                            stream.fail(ex)
+                    threading.Thread(target=run, daemon=True).start()
+                first = await loop.run_in_executor(None, lambda: next(stream, None))      # a failure before any text is still a 500 body
+                pieces = stream if first is None else itertools.chain([first], stream)
+                return StreamingResponse(sse_chunks(pieces, request.model), media_type="text/event-stream")
+            if isinstance(batcher, ContinuousBatcher):
+                text = await loop.run_in_executor(None, batcher.submit(parts, n, system, temperature=temperature, top_p=top_p).result)
+            elif batcher is not None and not temperature:
+                text = await loop.run_in_executor(None, batcher.submit(parts, n, system).result)
+            else:
+                text = _solo(parts, n, system, temperature, top_p)
             return {"id": uuid.uuid4().hex, "object": "chat.completion", "created": time.time(), "model": request.model,
                     "choices": [{"message": {"role": "assistant", "content": [{"type": "text", "text": text}]}}]}
         except Exception as e:                                       # server.py:292-297: errors come back as a 500 JSON body
