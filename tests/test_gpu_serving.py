@@ -153,3 +153,26 @@ def test_batched_serving_shares_the_weight_pass(served):
     assert len(admits) == 2 and admits[1][2] > admits[0][2]                                   # B was admitted after steps of A had run
     assert len(cb.thread_ids) == 1
     cb.close()
+
+
+def test_streamed_reply_equals_the_plain_one(served):
+    """`llm.generate(streamer=...)`: the tokens the host learns of every 16 graph replays reach a `TextStream` — same ids as the plain call, pieces
+    that add up to the reply; the endpoint's `stream=True` forwards them (server.py:241-270)."""
+    pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+    cfg, w, model, tok = served
+    parts = [_image(), "describe the image"]
+    n = 40
+    plain = serving.generate_content(model, tok, parts, max_new_tokens=n, eos_token_id=-1)
+    st = serving.TextStream(tok)
+    reply = serving.generate_content(model, tok, parts, max_new_tokens=n, eos_token_id=-1, streamer=st)
+    pieces = list(st)
+    assert reply == plain and len(st.token_ids) == n and "".join(pieces).strip() == plain
+    assert len([p for p in pieces if p]) > 4                              # word by word, not one lump
+    client = TestClient(serving.create_app(model, tok, model_name="NVILA-tiny"))
+    body = {"model": "NVILA-tiny", "max_tokens": 12, "temperature": 0.0, "stream": True, "messages": [{"role": "user", "content": "what is this ?"}]}
+    r = client.post("/chat/completions", json=body)
+    events = [e for e in r.text.split("\n\n") if e]
+    text = "".join(json.loads(e[6:])["choices"][0]["delta"]["content"] for e in events[:-1])
+    assert r.status_code == 200 and events[-1] == "data: [DONE]"
+    assert text.strip() == serving.generate_content(model, tok, "what is this ?", max_new_tokens=12)
