@@ -234,6 +234,17 @@ def chat_text(text: str, system: Optional[str] = None) -> str:
     return s + f"<|im_start|>user\n{text}<|im_end|>\n<|im_start|>assistant\n"
 
 
+def prompt_text(tokenizer, text: str, system: Optional[str] = None) -> str:
+    """The string the model is prompted with: the tokenizer's OWN chat template with the generation prompt appended, exactly what
+    `generate_content` builds (`tokenize_conversation(conversation, tokenizer, add_generation_prompt=True)`, llava_arch.py:921 ->
+    llava/utils/tokenizer.py:109-113) — Qwen2's template, for one, supplies a default system turn.  A tokenizer without a template (the
+    synthetic stand-ins) gets the bare Qwen2 chat form (`chat_text`)."""
+    if getattr(tokenizer, "chat_template", None) and hasattr(tokenizer, "apply_chat_template"):
+        turns = ([{"role": "system", "content": system}] if system else []) + [{"role": "user", "content": text}]
+        return tokenizer.apply_chat_template(turns, add_generation_prompt=True, tokenize=False)
+    return chat_text(text, system)
+
+
 def encode_with_images(tokenizer, text: str, image_token_id: int) -> torch.Tensor:
     """tokenizer_image_token (llava/mm_utils.py): tokenize the pieces between <image> tags, put the media id in between."""
     ids: List[int] = []
@@ -358,7 +369,7 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
     cfg = model.cfg
     dev = device or str(model.device)
     text, tiles, media_config = prepare_prompt(prompt, cfg)
-    ids = encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
+    ids = encode_with_images(tokenizer, prompt_text(tokenizer, text, system), cfg.image_token_id)[None].to(dev)
     media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
     gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
@@ -388,7 +399,7 @@ def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequen
     rows, tiles, blocks = [], [], []
     for prompt in prompts:
         text, t, mc = prepare_prompt(prompt, cfg)             # per request, like generate_content: one image -> its tiles
-        rows.append(encode_with_images(tokenizer, chat_text(text, system), cfg.image_token_id))
+        rows.append(encode_with_images(tokenizer, prompt_text(tokenizer, text, system), cfg.image_token_id))
         tiles.extend(t)
         blocks.extend(mc.get("image", {}).get("block_sizes", [None] * len(t)))
     eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
@@ -501,7 +512,7 @@ class HipBatchEngine:
         cfg = self.model.cfg
         dev = str(self.model.device)
         text, tiles, media_config = prepare_prompt(prompt, cfg)
-        ids = encode_with_images(self.tokenizer, chat_text(text, system), cfg.image_token_id)[None].to(dev)
+        ids = encode_with_images(self.tokenizer, prompt_text(self.tokenizer, text, system), cfg.image_token_id)[None].to(dev)
         media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
         e, _, _ = self.model._embed(ids, media, media_config)
         return e[0]
