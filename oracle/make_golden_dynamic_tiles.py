@@ -111,6 +111,9 @@ def main():
     st = ns["process_images"]([imgs[0], twin], proc, cfg, enable_dynamic_res=True, max_tiles=6)      # tiles of both pictures, concatenated (:533-534)
     out["stack_dyn_shape"] = np.asarray(st.shape, dtype=np.int64)
     out["stack_dyn_sum"] = np.float64(st.numpy().astype(np.float64).sum())
+    # the dataset path's prompt for TWO pictures in one message (mm_utils.py:408-424): each `<image>` becomes that picture's tiles
+    px2, prompt2 = ns["dynamic_process_images_and_prompt"]([imgs[0], imgs[2]], "A <image> B <image> C", data_args(proc, "dynamic"))
+    out["prompt2"], out["prompt2_shape"] = np.asarray(prompt2), np.asarray(px2.shape, dtype=np.int64)
     try:                                                              # pictures with different tile counts do not stack (:539-540)
         ns["process_images"]([imgs[0], imgs[2]], proc, cfg, enable_dynamic_res=True, max_tiles=6)
         raise AssertionError("expected the reference to refuse")
