@@ -30,6 +30,10 @@ Round 4: every remaining restated piece is held to the reference's OWN code, tak
   * the dynamic_s2 merge / tiler / image pre-processing, the video encoders' forward, the sampling chain: make_golden_s2*.py, make_golden_video.py,
     make_golden_sampling.py; full depth at NVILA-8B / Lite-3B size: make_golden_full_ref.py, make_golden_lite3b.py.
 
+Round 4, late: the input producers on the data side of the path are NOT restated here (they are product host code, `vila_amd/{serving,host,
+conversation,data}.py`) but pinned the same way — `process_image(s)` / `dynamic_preprocess`, `tokenize_conversation` / `preprocess_conversation` /
+`infer_stop_tokens`, `DataCollator`: make_golden_dynamic_tiles.py, make_golden_conversation.py, make_golden_collate_cases.py.
+
 All tensors fp32 unless noted.  `w` is a flat dict keyed by the reference's state_dict names
 (SURVEY.md Appendix C).
 """
