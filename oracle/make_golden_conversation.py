@@ -8,8 +8,9 @@ tokenizer call (llava/mm_utils.py:574-575), `IGNORE_INDEX = -100`, `SENTINEL_TOK
 `conversation_lib.default_conversation.sep_style = SeparatorStyle.AUTO` (llava/conversation.py:114-118,164: `conv_auto`, the default of every
 NVILA script).
 
-No tokenizer files exist offline, so the tokenizer is a byte-level BPE trained HERE on a fixed corpus, with Qwen2's chat template (default
-system turn, `<|im_start|>role\\n ... <|im_end|>\\n`), `<|im_end|>` as EOS and the media tokens added as special tokens the way
+No tokenizer files exist offline, so the tokenizer is a byte-level BPE trained HERE on a fixed corpus, with the reference's `qwen2` chat template (`--chat_template qwen2` of every NVILA
+script: llava/model/language_model/chat_templates/qwen2.jinja, installed the way language_model/builder.py:194-200 does; the fixture also
+keeps that template's own rendering of five conversations), `<|im_end|>` as EOS and the media tokens added as special tokens the way
 `build_llm_and_tokenizer` adds them (language_model/builder.py:190-211).  Its serialised form is stored in the fixture, so the test runs the
 HIP-side functions over the byte-identical tokenizer without re-training it.
 
@@ -30,10 +31,14 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference/llava/utils/tokenizer.py"
 OUT = os.path.join(ROOT, "tests", "golden", "conversation_ref.json")
 
-QWEN2_TEMPLATE = ("{% for message in messages %}{% if loop.first and messages[0]['role'] != 'system' %}"
-                  "{{ '<|im_start|>system\\nYou are a helpful assistant.<|im_end|>\\n' }}{% endif %}"
-                  "{{'<|im_start|>' + message['role'] + '\\n' + message['content'] + '<|im_end|>' + '\\n'}}{% endfor %}"
-                  "{% if add_generation_prompt %}{{ '<|im_start|>assistant\\n' }}{% endif %}")
+REF_TEMPLATE = "/root/reference/llava/model/language_model/chat_templates/qwen2.jinja"
+
+
+def reference_chat_template() -> str:
+    """`--chat_template qwen2` as `build_llm_and_tokenizer` installs it (language_model/builder.py:194-200): the file, minus indentation and newlines."""
+    return open(REF_TEMPLATE).read().replace("    ", "").replace("\n", "")
+
+
 CORPUS = ["the quick brown fox jumps over the lazy dog", "a red square sits on a blue table\nnext to a green circle", "what is in this picture ?",
           "describe the image in detail , please .", "system user assistant You are a helpful assistant.", "question answer question answer",
           "there are two cats and one dog in the video", "图片里有一个红色的方块", "hello world, hello again!  two  spaces"] * 4
@@ -48,8 +53,9 @@ CONVERSATIONS = [
 ]
 
 
-def build_tokenizer(serialised: str = None):
-    """Train (or re-load) the stand-in tokenizer.  -> PreTrainedTokenizerFast with chat template, EOS and media tokens."""
+def build_tokenizer(serialised: str = None, chat_template: str = None):
+    """Train (or re-load) the stand-in tokenizer.  -> PreTrainedTokenizerFast with EOS and media tokens; `chat_template` (a jinja string) is
+    installed when given — the generator passes the REFERENCE's, the tests install the HIP side's own restatement instead."""
     from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
     from transformers import PreTrainedTokenizerFast
     if serialised is None:
@@ -61,7 +67,8 @@ def build_tokenizer(serialised: str = None):
     else:
         tk = Tokenizer.from_str(serialised)
     tok = PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="<|im_end|>", pad_token="<|endoftext|>")
-    tok.chat_template = QWEN2_TEMPLATE
+    if chat_template is not None:
+        tok.chat_template = chat_template
     tok.add_tokens(["<image>", "<vila/video>"], special_tokens=True)            # builder.py:205-211: the media tokens are added tokens
     return tok
 
@@ -86,9 +93,15 @@ def reference_functions():
 
 def main():
     ns = reference_functions()
-    tok = build_tokenizer()
+    template = reference_chat_template()
+    tok = build_tokenizer(chat_template=template)
     serialised = tok.backend_tokenizer.to_str()
-    out = {"tokenizer": serialised, "chat_template": QWEN2_TEMPLATE, "conversations": CONVERSATIONS, "cases": []}
+    out = {"tokenizer": serialised, "chat_template_name": "qwen2", "conversations": CONVERSATIONS, "cases": []}
+    # the reference template's own rendering: plain turns, a conversation that opens with a system turn, a turn without content (left out)
+    out["turns"] = [[{"role": "user", "content": "hi"}], [{"role": "system", "content": ""}, {"role": "user", "content": " a\nb "}, {"role": "assistant", "content": "x"}],
+                    [{"role": "system", "content": "be brief"}, {"role": "user", "content": "q"}], [{"role": "user", "content": "q"}, {"role": "assistant", "content": None}],
+                    [{"role": "user", "content": "<image>\nq"}, {"role": "assistant", "content": "a"}, {"role": "user", "content": "q2"}, {"role": "assistant", "content": "a2"}]]
+    out["rendered"] = [[tok.apply_chat_template(t, add_generation_prompt=g, tokenize=False) for g in (False, True)] for t in out["turns"]]
     for conv in CONVERSATIONS:
         case = {}
         for key, kw in (("plain", {}), ("gen", {"add_generation_prompt": True}), ("nosys", {"no_system_prompt": True}),

@@ -23,9 +23,28 @@ def fx():
     return json.load(open(GOLDEN))
 
 
+def _tok(fx):
+    """The fixture's tokenizer with the HIP side's OWN `qwen2` template (the reference-executed ids were produced under the reference's file)."""
+    return C.prepare_tokenizer(build_tokenizer(fx["tokenizer"]), fx["chat_template_name"])
+
+
+def test_qwen2_chat_template_renders_like_the_reference_file(fx):
+    """`--chat_template qwen2` (language_model/builder.py:194-200): our restated template against the reference file's own rendering — default
+    system turn without a full stop, a leading system turn kept, a turn with `None` content left out, the generation prompt."""
+    tok = _tok(fx)
+    for turns, (plain, gen) in zip(fx["turns"], fx["rendered"]):
+        assert tok.apply_chat_template(turns, add_generation_prompt=False, tokenize=False) == plain
+        assert tok.apply_chat_template(turns, add_generation_prompt=True, tokenize=False) == gen
+    assert fx["rendered"][0][0].startswith("<|im_start|>system\nYou are a helpful assistant<|im_end|>\n<|im_start|>user\nhi")
+    with pytest.raises(ValueError, match="unknown chat template"):
+        C.prepare_tokenizer(build_tokenizer(fx["tokenizer"]), "vicuna_v9")
+    # the builder's other additions: stop tokens off the template, media tokens as added tokens with their ids
+    assert tok.stop_tokens == ["<|im_end|>"] and tok.stop_token_ids == [tok.eos_token_id]
+    assert tok.media_token_ids == {"image": tok.convert_tokens_to_ids("<image>"), "video": tok.convert_tokens_to_ids("<vila/video>")}
+
+
 def test_tokenize_conversation_every_switch_bit_exact(fx):
-    tok = build_tokenizer(fx["tokenizer"])
-    assert tok.chat_template == fx["chat_template"]
+    tok = _tok(fx)
     for conv, case in zip(fx["conversations"], fx["cases"]):
         for key, kw in (("plain", {}), ("gen", {"add_generation_prompt": True}), ("nosys", {"no_system_prompt": True}),
                         ("override", {"overrides": {"gpt": "answer"}})):
@@ -40,7 +59,7 @@ def test_tokenize_conversation_every_switch_bit_exact(fx):
 
 
 def test_preprocess_conversation_labels_bit_exact(fx):
-    tok = build_tokenizer(fx["tokenizer"])
+    tok = _tok(fx)
     for conv, case in zip(fx["conversations"], fx["cases"]):
         for key, kw in (("sft", {}), ("sft_nosys", {"no_system_prompt": True})):
             r = C.preprocess_conversation(copy.deepcopy(conv), tok, **kw)
@@ -55,7 +74,7 @@ def test_preprocess_conversation_labels_bit_exact(fx):
 
 
 def test_infer_stop_tokens(fx):
-    tok = build_tokenizer(fx["tokenizer"])
+    tok = _tok(fx)
     assert sorted(C.infer_stop_tokens(tok)) == fx["stop_tokens"] == ["<|im_end|>"]
 
 
@@ -104,12 +123,12 @@ def test_serving_prompt_ids_equal_the_reference_generate_content_prompt(fx):
     """`generate_content` tokenises ONE human turn with the generation prompt appended (llava_arch.py:843, 921): the serving shim's ids for
     the same text — through the tokenizer's own chat template, Qwen2's default system turn included — are the reference-executed ones."""
     from vila_amd import serving
-    tok = build_tokenizer(fx["tokenizer"])
+    tok = _tok(fx)
     image_id = tok.convert_tokens_to_ids("<image>")
     for text, want in zip(fx["prompts"], fx["prompt_ids"]):
         got = serving.encode_with_images(tok, serving.prompt_text(tok, text.strip()), image_id)      # prepare_prompt strips, like tokenizer.py:77-78
         assert got.tolist() == want, text
-    assert "You are a helpful assistant." in serving.prompt_text(tok, "hello")
+    assert "You are a helpful assistant<|im_end|>" in serving.prompt_text(tok, "hello")
     assert serving.prompt_text(tok, "hello", system="be brief").count("system") == 1 and "be brief" in serving.prompt_text(tok, "hello", system="be brief")
     # a tokenizer without a template gets the bare chat form
     tok.chat_template = None

@@ -77,9 +77,7 @@ def test_build_instance_under_every_recipe_and_through_the_collator():
     from vila_amd import serving
     cfx = json.load(open(os.path.join(GOLDEN, "conversation_ref.json")))
     dfx = np.load(os.path.join(GOLDEN, "dynamic_tiles.npz"))
-    tok = build_tokenizer(cfx["tokenizer"])
-    tok.media_tokens = {"image": "<image>", "video": "<vila/video>"}
-    tok.media_token_ids = {k: tok.convert_tokens_to_ids(v) for k, v in tok.media_tokens.items()}
+    tok = C.prepare_tokenizer(build_tokenizer(cfx["tokenizer"]), cfx["chat_template_name"])
     tok.model_max_length = 4096
     size = 448
     imgs = [synthetic_image(w, h, 200 + i) for i, (w, h) in enumerate([(640, 480), (300, 900), (448, 448)])]

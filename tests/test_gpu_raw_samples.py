@@ -20,9 +20,8 @@ def _tokenizer(cfg):
     pytest.importorskip("tokenizers")
     from oracle.make_golden_conversation import build_tokenizer
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "conversation_ref.json")))
-    tok = build_tokenizer(fx["tokenizer"])
-    tok.media_tokens = {"image": "<image>", "video": "<vila/video>"}
-    tok.media_token_ids = {k: tok.convert_tokens_to_ids(v) for k, v in tok.media_tokens.items()}
+    from vila_amd.conversation import prepare_tokenizer
+    tok = prepare_tokenizer(build_tokenizer(fx["tokenizer"]), fx["chat_template_name"])
     tok.model_max_length = 512
     nl = tok("\n").input_ids
     assert len(nl) == 1 and max(tok.media_token_ids.values()) + 2 < cfg.llm.vocab_size

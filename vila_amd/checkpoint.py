@@ -92,7 +92,8 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
            "mm_projector_cfg": pj_cfg, "mm_projector_type": cfg.mm_projector_type, "mm_vision_select_layer": v.select_layer,
            "mm_vision_select_feature": "cls_patch", "dynamic_s2": cfg.dynamic_s2, "s2_scales": ",".join(str(s) for s in cfg.s2_scales),
            "s2_resize_output_to_scale_idx": cfg.s2_resize_output_to_scale_idx, "image_aspect_ratio": cfg.image_aspect_ratio or None,
-           "min_tiles": cfg.min_tiles, "max_tiles": cfg.max_tiles, "video_max_tiles": cfg.video_max_tiles, "hidden_size": c.hidden_size,
+           "min_tiles": cfg.min_tiles, "max_tiles": cfg.max_tiles, "video_max_tiles": cfg.video_max_tiles, "chat_template": cfg.chat_template or None,
+           "hidden_size": c.hidden_size,
            "mm_hidden_size": cfg.mm_hidden_size, "image_token_id": cfg.image_token_id, "newline_token_id": cfg.newline_token_id,
            "_name_or_path": output_dir}
     with open(os.path.join(output_dir, "config.json"), "w") as f:
@@ -149,7 +150,8 @@ def config_from_pretrained(model_dir: str) -> VilaConfig:
                       dynamic_s2=bool(opt(top, "dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
                       s2_resize_output_to_scale_idx=opt(top, "s2_resize_output_to_scale_idx", -1),
                       image_aspect_ratio=str(opt(top, "image_aspect_ratio", "")), min_tiles=int(opt(top, "min_tiles", 1)),
-                      max_tiles=int(opt(top, "max_tiles", 12)), video_max_tiles=int(opt(top, "video_max_tiles", 1)), name=os.path.basename(model_dir.rstrip("/")))
+                      max_tiles=int(opt(top, "max_tiles", 12)), video_max_tiles=int(opt(top, "video_max_tiles", 1)),
+                      chat_template=str(opt(top, "chat_template", "")), name=os.path.basename(model_dir.rstrip("/")))
 
 
 def _rope_theta(l: dict) -> float:
@@ -189,10 +191,11 @@ def load_weights_into(model, model_dir: str, strict: bool = True) -> Dict[str, l
 MEDIA_TOKENS = {"image": "<image>", "video": "<vila/video>"}          # llava/constants.py:32-35
 
 
-def load_tokenizer(model_dir: str, model_max_length: Optional[int] = None):
+def load_tokenizer(model_dir: str, model_max_length: Optional[int] = None, chat_template: Optional[str] = None):
     """The tokenizer half of `build_llm_and_tokenizer` (language_model/builder.py:190-211): `AutoTokenizer.from_pretrained(<dir>/llm,
-    padding_side="right", use_fast=True, legacy=False)`, `model_max_length`, the media tokens added as special tokens and their ids recorded
-    in `media_token_ids`.  None when the folder holds no tokenizer files or transformers is absent (the model then keeps its stand-in)."""
+    padding_side="right", use_fast=True, legacy=False)`, `model_max_length`, the config's named chat template, the stop tokens read off it,
+    the media tokens added as special tokens and their ids recorded in `media_token_ids` (`conversation.prepare_tokenizer`).  None when the
+    folder holds no tokenizer files or transformers is absent (the model then keeps its stand-in)."""
     llm_dir = os.path.join(model_dir, "llm")
     if not any(os.path.exists(os.path.join(llm_dir, f)) for f in ("tokenizer.json", "tokenizer_config.json", "tokenizer.model", "vocab.json")):
         return None
@@ -200,15 +203,11 @@ def load_tokenizer(model_dir: str, model_max_length: Optional[int] = None):
         from transformers import AutoTokenizer
     except ImportError:
         return None
+    from .conversation import prepare_tokenizer
     tok = AutoTokenizer.from_pretrained(llm_dir, padding_side="right", use_fast=True, legacy=False)
     if model_max_length is not None:
         tok.model_max_length = model_max_length
-    tok.media_tokens = dict(MEDIA_TOKENS)
-    tok.media_token_ids = {}
-    for name, token in MEDIA_TOKENS.items():
-        tok.add_tokens([token], special_tokens=True)
-        tok.media_token_ids[name] = tok.convert_tokens_to_ids(token)
-    return tok
+    return prepare_tokenizer(tok, chat_template or None, MEDIA_TOKENS)
 
 
 def load_pretrained(model_dir: str, device="cuda", dtype=torch.bfloat16):
@@ -217,7 +216,7 @@ def load_pretrained(model_dir: str, device="cuda", dtype=torch.bfloat16):
     config.json)."""
     from .vlm import HipLlavaLlamaModel
     cfg = config_from_pretrained(model_dir)
-    tok = load_tokenizer(model_dir)
+    tok = load_tokenizer(model_dir, chat_template=cfg.chat_template or None)
     if tok is not None:
         cfg.image_token_id, cfg.video_token_id = int(tok.media_token_ids["image"]), int(tok.media_token_ids["video"])
         nl = tok("\n").input_ids

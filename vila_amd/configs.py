@@ -103,6 +103,7 @@ class VilaConfig:
     # processor's mean colour), "dynamic" (InternVL-style tiles + thumbnail: every NVILA-Lite script), "dynamic_s2" (every NVILA 9-tile script).
     # "" = not stated: "dynamic_s2" when the dynamic_s2 flag is on, else the processor's default (SigLIP: resize).
     image_aspect_ratio: str = ""
+    chat_template: str = ""          # `--chat_template qwen2` (language_model/builder.py:194-200): "" = the tokenizer's own template
 
     @property
     def mm_hidden_size(self) -> int:

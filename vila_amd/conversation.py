@@ -29,6 +29,36 @@ DUMMY_CONVERSATION = [{"from": "human", "value": "question"}, {"from": "gpt", "v
 
 _ROLE = {"human": "user", "gpt": "assistant"}
 
+# `--chat_template qwen2` of every NVILA script (scripts/NVILA/stage1_9tile.sh:16, scripts/NVILA-Lite/align.sh:20): the builder replaces the
+# tokenizer's template by llava/model/language_model/chat_templates/qwen2.jinja (language_model/builder.py:194-200).  Restated here — a default
+# system turn "You are a helpful assistant" (no full stop, unlike Qwen2's own) unless the conversation opens with a system turn, every turn as
+# `<|im_start|>role\ncontent<|im_end|>\n`, turns whose content is None left out — and pinned to the reference file's rendering of the same
+# conversations (tests/golden/conversation_ref.json: "rendered").
+CHAT_TEMPLATES = {
+    "qwen2": ("{%- macro turn(role, content) -%}{{ '<|im_start|>' ~ role ~ '\\n' ~ content ~ '<|im_end|>\\n' }}{%- endmacro -%}"
+              "{%- if messages[0]['role'] != 'system' -%}{{ turn('system', 'You are a helpful assistant') }}{%- endif -%}"
+              "{%- for m in messages -%}{%- if m['content'] is not none -%}{{ turn(m['role'], m['content']) }}{%- endif -%}{%- endfor -%}"
+              "{%- if add_generation_prompt -%}{{ '<|im_start|>assistant\\n' }}{%- endif -%}"),
+}
+
+
+def prepare_tokenizer(tokenizer, chat_template: Optional[str] = None, media_tokens: Optional[Dict[str, str]] = None):
+    """What `build_llm_and_tokenizer` does to the tokenizer it loaded (language_model/builder.py:194-211), in its order: the named chat template,
+    `stop_tokens` / `stop_token_ids` read off that template, the media tokens added as special tokens with their ids in `media_token_ids`."""
+    if chat_template is not None:
+        if chat_template not in CHAT_TEMPLATES:
+            raise ValueError(f"unknown chat template '{chat_template}' (known: {sorted(CHAT_TEMPLATES)})")
+        tokenizer.chat_template = CHAT_TEMPLATES[chat_template]
+    if getattr(tokenizer, "chat_template", None):
+        tokenizer.stop_tokens = infer_stop_tokens(tokenizer)
+        tokenizer.stop_token_ids = tokenizer.convert_tokens_to_ids(tokenizer.stop_tokens)
+    tokenizer.media_tokens = dict(media_tokens or {"image": "<image>", "video": "<vila/video>"})      # llava/constants.py:34-37
+    tokenizer.media_token_ids = {}
+    for name, token in tokenizer.media_tokens.items():
+        tokenizer.add_tokens([token], special_tokens=True)
+        tokenizer.media_token_ids[name] = tokenizer.convert_tokens_to_ids(token)
+    return tokenizer
+
 
 def tokenize_conversation(messages: Sequence[Dict[str, str]], tokenizer, add_generation_prompt: bool = False,
                           overrides: Optional[Dict[str, str]] = None, no_system_prompt: bool = False) -> torch.Tensor:

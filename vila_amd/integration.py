@@ -51,7 +51,7 @@ def vila_config_from_hf(llm_cfg, vision_cfg, top_cfg=None, projector=None) -> Vi
     kw = {}
     if top_cfg is not None:
         for src, dst in (("image_token_id", "image_token_id"), ("newline_token_id", "newline_token_id"), ("image_aspect_ratio", "image_aspect_ratio"),
-                         ("min_tiles", "min_tiles"), ("max_tiles", "max_tiles"), ("video_max_tiles", "video_max_tiles")):
+                         ("min_tiles", "min_tiles"), ("max_tiles", "max_tiles"), ("video_max_tiles", "video_max_tiles"), ("chat_template", "chat_template")):
             if _get(top_cfg, src) is not None:
                 kw[dst] = _get(top_cfg, src)
     return VilaConfig(vision=vis, llm=llm, mm_projector_type=projector_type_of(top_cfg, projector), dynamic_s2=bool(_get(top_cfg, "dynamic_s2", False)) if top_cfg is not None else False,

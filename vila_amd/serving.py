@@ -360,6 +360,17 @@ def sse_chunks(pieces, model_name: str, stop_str: str = "<|im_end|>") -> Iterato
     yield "data: [DONE]\n\n"
 
 
+def _eos_of(tokenizer, eos_token_id=None):
+    """The ids generation stops on: the caller's, else the tokenizer's `stop_token_ids` (what `default_generation_config` hands HF as
+    `eos_token_id`, llava_arch.py:961-962: the end-of-turn tokens `infer_stop_tokens` read off the chat template), else its EOS."""
+    if eos_token_id is not None:
+        return eos_token_id
+    stop = getattr(tokenizer, "stop_token_ids", None)
+    if stop:
+        return list(stop) if len(stop) > 1 else stop[0]
+    return getattr(tokenizer, "eos_token_id", None)
+
+
 def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_new_tokens: int = 128, system: Optional[str] = None,
                      eos_token_id=None, device: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 50,
                      seed: Optional[int] = None, streamer=None) -> str:
@@ -371,7 +382,7 @@ def generate_content(model, tokenizer, prompt: Union[str, Sequence[Any]], max_ne
     text, tiles, media_config = prepare_prompt(prompt, cfg)
     ids = encode_with_images(tokenizer, prompt_text(tokenizer, text, system), cfg.image_token_id)[None].to(dev)
     media = {"image": [t.to(device=dev, dtype=torch.bfloat16) for t in tiles]}
-    eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+    eos = _eos_of(tokenizer, eos_token_id)
     gen = dict(max_new_tokens=max_new_tokens, eos_token_id=eos)
     if temperature and temperature > 0:
         gen.update(do_sample=True, temperature=float(temperature), top_p=float(top_p), top_k=int(top_k), seed=seed)
@@ -402,7 +413,7 @@ def generate_content_batch(model, tokenizer, prompts: Sequence[Union[str, Sequen
         rows.append(encode_with_images(tokenizer, prompt_text(tokenizer, text, system), cfg.image_token_id))
         tiles.extend(t)
         blocks.extend(mc.get("image", {}).get("block_sizes", [None] * len(t)))
-    eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+    eos = _eos_of(tokenizer, eos_token_id)
     stop = set(eos) if isinstance(eos, (list, tuple)) else {eos}
     pad = pad_token_id if pad_token_id is not None else (getattr(tokenizer, "pad_token_id", None) or 0)
     L = max(int(r.numel()) for r in rows)
@@ -494,7 +505,7 @@ class HipBatchEngine:
     def __init__(self, model, tokenizer, n_slots: int = 8, max_ctx: int = 2048, max_new_tokens: int = 1024, eos_token_id=None):
         self.model, self.tokenizer = model, tokenizer
         self.n_slots, self.max_ctx, self.max_new_tokens = int(n_slots), int(max_ctx), int(max_new_tokens)
-        eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+        eos = _eos_of(tokenizer, eos_token_id)
         self.eos = set(eos) if isinstance(eos, (list, tuple)) else {eos}
         self.st = None
 
