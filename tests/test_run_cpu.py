@@ -1,0 +1,188 @@
+"""Host logic of an SFT run (vila_amd/run.py) against tests/golden/run_ref.json = the reference's own `VILADistributedSampler` and
+`get_checkpoint_path` (ast-extracted, executed) and transformers' own scheduler (oracle/make_golden_run.py).  Integer work: bit-exact; learning
+rates: to 1e-12 relative.  The loop itself runs over a recording stub of `SFTTrainer` (no kernels on CPU)."""
+import json
+import os
+
+import pytest
+import torch
+
+from vila_amd import run
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return json.load(open(os.path.join(GOLDEN, "run_ref.json")))
+
+
+def test_sampler_order_equals_the_reference_sampler_on_every_rank_and_epoch(fx):
+    assert len(fx["samplers"]) >= 8
+    for c in fx["samplers"]:
+        seen = []
+        for rank, rec in enumerate(c["ranks"]):
+            s = run.VILADistributedSampler(sum(c["lens"]), c["world"], rank, seed=c["seed"], batch_size=c["batch_size"], sample_len_list=c["lens"],
+                                           gradient_accumulation_steps=c["accumulation"])
+            assert len(s) == rec["len"], c
+            for epoch, want in enumerate(rec["order"]):
+                s.set_epoch(epoch)
+                assert list(s) == want, (c["lens"], c["world"], rank, epoch)
+            seen += rec["order"][0]
+        assert len(set(seen)) == len(seen)                               # the ranks' shares are disjoint
+        assert len(seen) % (c["world"] * c["batch_size"] * c["accumulation"]) == 0
+
+
+def test_sampler_refusals():
+    with pytest.raises(ValueError, match="Invalid rank 2"):
+        run.VILADistributedSampler(10, 2, 2)
+    with pytest.raises(NotImplementedError):
+        run.VILADistributedSampler(10, 2, 0, sp_degree=2)
+
+
+def test_learning_rate_of_every_update_equals_the_transformers_scheduler(fx):
+    kinds = set()
+    for c in fx["schedules"]:
+        n_warm = run.warmup_steps(c["total"], c["warmup_ratio"], c["warmup_steps"])
+        assert n_warm == c["n_warmup"]
+        for k, want in enumerate(c["lr"]):
+            got = fx["base_lr"] * run.lr_factor(c["kind"], k, n_warm, c["total"])
+            assert abs(got - want) <= 1e-12 * fx["base_lr"], (c["kind"], c["total"], k, got, want)
+        kinds.add(c["kind"])
+    assert kinds == {"cosine", "linear", "constant", "constant_with_warmup"}
+
+
+def test_get_checkpoint_path_equals_the_reference_rule(fx, tmp_path):
+    from oracle.make_golden_run import checkpoint_layouts
+    for name, (dirs, files) in checkpoint_layouts().items():
+        r = tmp_path / name
+        r.mkdir()
+        for d in dirs:
+            (r / d).mkdir()
+        for f in files:
+            (r / f).write_text("")
+        path, cont = run.get_checkpoint_path(str(r))
+        want = fx["checkpoints"][name]
+        assert (None if path is None else os.path.relpath(path, str(r))) == want["path"] and cont == want["continue"], name
+    assert run.get_checkpoint_path(str(tmp_path / "nope")) == (None, True)
+
+
+# ------------------------------------------------------------------------------------------------------------ the loop over a stub trainer
+class _Stub:
+    """Records what a run feeds the step; its 'weights' are a running checksum so a resumed run can be compared with an uninterrupted one."""
+    def __init__(self):
+        self.lr, self.calls, self.w = None, [], 0.0
+
+    def step(self, input_ids, images, labels, attention_mask, block_sizes=None, videos=None):
+        self.calls.append((self.lr, input_ids.flatten().tolist(), len(images), block_sizes, videos))
+        self.w = self.w * 0.5 + self.lr * float(input_ids.sum())
+        return float(len(self.calls))
+
+
+def _dataset(n):
+    return [{"input_ids": torch.tensor([i, i + 1000]), "labels": torch.tensor([-100, i]), "image": [torch.tensor([i])] if i % 3 == 0 else []} for i in range(n)]
+
+
+def _collate(insts):
+    ids = torch.stack([x["input_ids"] for x in insts])
+    return {"input_ids": ids, "labels": torch.stack([x["labels"] for x in insts]), "attention_mask": torch.ones_like(ids, dtype=torch.bool),
+            "media": {"image": [t for x in insts for t in x["image"]], "video": []}, "media_config": {"image": {"block_sizes": None}}}
+
+
+def _io():
+    def save(tr, folder):
+        json.dump({"w": tr.w}, open(os.path.join(folder, "stub.json"), "w"))
+    def load(tr, folder):
+        tr.w = json.load(open(os.path.join(folder, "stub.json")))["w"]
+    return save, load
+
+
+def _final(tr, folder):
+    json.dump({"w": tr.w}, open(os.path.join(folder, "config.json"), "w"))
+
+
+def test_run_feeds_the_step_sampler_batches_and_schedule_and_rotates_checkpoints(tmp_path):
+    ds = _dataset(45)
+    args = run.TrainArgs(output_dir=str(tmp_path / "r"), per_device_train_batch_size=2, num_train_epochs=2, save_steps=4, save_total_limit=2, seed=3,
+                         sample_lens=[30, 15])
+    save, load = _io()
+    tr = _Stub()
+    logs = []
+    st = run.train(tr, ds, _collate, args, rank=1, world_size=2, save_fn=save, load_fn=load, final_save_fn=_final, log=logs.append)
+    s = run.VILADistributedSampler(45, 2, 1, seed=3, batch_size=2, sample_len_list=[30, 15])
+    per_epoch, epochs, total = run.plan(len(s), args)
+    assert (per_epoch, epochs, total) == (len(s) // 2, 2, 2 * (len(s) // 2)) and st.global_step == total == len(tr.calls)
+    want = []
+    for e in range(2):
+        s.set_epoch(e)
+        o = list(s)
+        want += [o[i:i + 2] for i in range(0, len(o), 2)]
+    n_warm = run.warmup_steps(total, 0.03)
+    for k, (lr, ids, n_img, blocks, vids) in enumerate(tr.calls):
+        assert ids == [want[k][0], want[k][0] + 1000, want[k][1], want[k][1] + 1000]
+        assert n_img == sum(1 for i in want[k] if i % 3 == 0) and blocks is None and vids is None
+        assert lr == args.learning_rate * run.lr_factor("cosine", k, n_warm, total)
+    assert tr.calls[0][0] == 0.0 and logs == []                        # HF: the first update of a warmed-up run has rate 0; rank 1 does not log
+    assert [r["step"] for r in st.log_history] == list(range(1, total + 1)) and st.log_history[0]["learning_rate"] > 0
+    assert not os.path.exists(args.output_dir)                         # rank 1 writes nothing
+
+    tr0 = _Stub()
+    run.train(tr0, ds, _collate, args, rank=0, world_size=2, save_fn=save, load_fn=load, resume=False, final_save_fn=None)
+    kept = sorted(os.listdir(args.output_dir), key=lambda d: int(d.split("-")[1]))
+    assert kept == [f"checkpoint-{k}" for k in range(4, total + 1, 4)][-2:]               # save_total_limit = 2, no staging folder left behind
+    assert json.load(open(os.path.join(args.output_dir, kept[-1], "trainer_state.json")))["global_step"] == int(kept[-1].split("-")[1])
+
+
+def test_resumed_run_replays_neither_a_batch_nor_a_learning_rate(tmp_path):
+    ds = _dataset(40)
+    save, load = _io()
+    mk = lambda d, **kw: run.TrainArgs(output_dir=str(tmp_path / d), per_device_train_batch_size=4, num_train_epochs=3, save_steps=7, save_total_limit=None,
+                                       warmup_ratio=0.1, **kw)
+    whole = _Stub()
+    st = run.train(whole, ds, _collate, mk("a"), save_fn=save, load_fn=load, final_save_fn=_final)
+    assert st.global_step == 30 and json.load(open(tmp_path / "a" / "config.json"))["w"] == whole.w
+    # the same run killed after 17 updates (its last checkpoint is 14) ...
+    first = _Stub()
+    run.train(first, ds, _collate, mk("b", max_steps=17), save_fn=save, load_fn=load, final_save_fn=None)
+    assert sorted(os.listdir(tmp_path / "b")) == ["checkpoint-14", "checkpoint-7"]
+    # ... continues from update 14 in the middle of epoch 1 with the schedule of the 30-update run
+    second = _Stub()
+    st2 = run.train(second, ds, _collate, mk("b"), save_fn=save, load_fn=load, final_save_fn=_final)
+    assert st2.global_step == 30 and len(second.calls) == 16
+    assert [c[1] for c in second.calls] == [c[1] for c in whole.calls[14:]]
+    # (the killed run was planned for 17 updates, so ITS rates differ; the resumed run's are the uninterrupted run's)
+    assert [c[0] for c in second.calls] == [c[0] for c in whole.calls[14:]]
+    assert [r["step"] for r in st2.log_history] == list(range(1, 31))
+    # a finished run (the final model's config.json lies in the run folder) is not trained again (train.py:503-507)
+    third, said = _Stub(), []
+    st3 = run.train(third, ds, _collate, mk("b"), save_fn=save, load_fn=load, final_save_fn=_final, log=said.append)
+    assert third.calls == [] and st3.global_step == 30 and "Skipp training" in said[0]["message"]
+
+
+def test_accumulation_is_refused_with_the_way_out():
+    with pytest.raises(NotImplementedError, match="autograd seam"):
+        run.train(_Stub(), _dataset(8), _collate, run.TrainArgs(gradient_accumulation_steps=2), final_save_fn=None)
+
+
+def test_default_checkpoint_functions_round_trip_a_real_trainer_on_cpu(tmp_path):
+    """The default save / load of a run (weights in the reference's three folders + optimizer state) over a real `SFTTrainer` (CPU tensors, no
+    kernels): a trainer resumed from `checkpoint-<k>` holds the saved masters, moments, step counts and bf16 parameters."""
+    from vila_amd import configs
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import HipLlavaLlamaModel
+    torch.manual_seed(0)
+    tr = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    with torch.no_grad():
+        tr.flat.master.normal_(0, 0.02); tr.flat.params.copy_(tr.flat.master); tr.flat.m.normal_(0, 1e-3); tr.flat.v.uniform_(0, 1e-4)
+    tr.flat.step_count, tr.flat.bucket_steps = 5, {"mm_projector.": 5}
+    args = run.TrainArgs(output_dir=str(tmp_path / "r"))
+    st = run.TrainerState(global_step=5, epoch=0.5, max_steps=10)
+    run._checkpoint(tr, args, st, 0, run._save_checkpoint_default, None)
+    path, cont = run.get_checkpoint_path(args.output_dir)
+    assert path.endswith("checkpoint-5") and cont and sorted(os.listdir(path)) == ["config.json", "llm", "mm_projector", "optimizer", "trainer_state.json", "vision_tower"]
+    tr2 = SFTTrainer(HipLlavaLlamaModel(configs.tiny("mlp_downsample"), device="cpu"))
+    run._load_checkpoint_default(tr2, path)
+    for a, b in ((tr.flat.master, tr2.flat.master), (tr.flat.m, tr2.flat.m), (tr.flat.v, tr2.flat.v), (tr.flat.params, tr2.flat.params)):
+        assert torch.equal(a, b)
+    assert tr2.flat.step_count == 5 and tr2.flat.bucket_steps == {"mm_projector.": 5}
+    assert run.TrainerState.load(os.path.join(path, "trainer_state.json")).global_step == 5
