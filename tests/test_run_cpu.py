@@ -159,9 +159,23 @@ def test_resumed_run_replays_neither_a_batch_nor_a_learning_rate(tmp_path):
     assert third.calls == [] and st3.global_step == 30 and "Skipp training" in said[0]["message"]
 
 
-def test_accumulation_is_refused_with_the_way_out():
-    with pytest.raises(NotImplementedError, match="autograd seam"):
-        run.train(_Stub(), _dataset(8), _collate, run.TrainArgs(gradient_accumulation_steps=2), final_save_fn=None)
+def test_accumulation_groups_consecutive_batches_into_one_update(tmp_path):
+    class Acc(_Stub):
+        max_grad_norm = None
+        def step_accumulated(self, micro):
+            self.calls.append((self.lr, [m["input_ids"].flatten().tolist() for m in micro], self.max_grad_norm))
+            return 1.0
+    ds = _dataset(50)
+    args = run.TrainArgs(output_dir=str(tmp_path / "r"), per_device_train_batch_size=2, gradient_accumulation_steps=3, num_train_epochs=1, save_steps=0,
+                         max_grad_norm=5.0)
+    tr = Acc()
+    st = run.train(tr, ds, _collate, args, rank=0, world_size=2, final_save_fn=None)
+    s = run.VILADistributedSampler(50, 2, 0, seed=42, batch_size=2, gradient_accumulation_steps=3)
+    o = list(s)
+    assert len(o) == 24 and st.global_step == 4 == len(tr.calls)                      # 50 // (2 ranks x 2 x 3) = 4 updates of 3 micro-batches each
+    flat = [i for _, micro, _ in tr.calls for m in micro for i in m[::2]]
+    assert flat == o and all(len(micro) == 3 and clip == 5.0 for _, micro, clip in tr.calls)
+    assert tr.calls[0][0] == 0.0 and tr.calls[1][0] == 2e-5                           # ceil(0.03 x 4) = 1 warm-up update
 
 
 def test_default_checkpoint_functions_round_trip_a_real_trainer_on_cpu(tmp_path):

@@ -335,3 +335,112 @@ def test_reference_collated_batch_is_what_the_step_plans_on():
         keep[0] = False
         want += int(keep.sum())
     assert n_targets == want > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient accumulation: one update from several micro-batches (SFTTrainer.step_accumulated)
+# ---------------------------------------------------------------------------------------------------------------------
+def _accumulation_worker(rank, world, port, q, clip):
+    """Two ranks x three micro-batches.  Media appears only in SOME micro-batches of SOME ranks (rank 0: micro-batch 0; rank 1: none), and the
+    LAST micro-batch is text-only everywhere — the held sums must still reach the exchange and the update of the projector / tower buckets."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vila_amd import ops
+        from vila_amd.train import FlatParams, SFTTrainer, count_targets
+        torch.manual_seed(0)
+        m = _tiny_model()
+        ops.adamw_step = _adamw_reference
+        ops.add = lambda a, b, out=None: torch.add(a, b, out=out)          # TEST stand-ins for the HIP kernels on a CPU-only host
+        ops.sumsq = lambda x: (x.double() ** 2).sum().float().reshape(1)
+        tr = SFTTrainer(m, lr=1e-2, weight_decay=0.0, max_grad_norm=clip)
+        tr.flat.grads = tr.flat.grads.float()
+        cfg = m.cfg
+        full = _bucket_order(cfg)[1:] if cfg.llm.tie_word_embeddings else _bucket_order(cfg)
+        llm_only = full[:-len(tr.media_bucket_order())]
+        L, n_mb = 10, 3
+        mbs, seen = [], []
+        for i in range(n_mb):
+            g = torch.Generator().manual_seed(10 * rank + i)
+            ids = torch.randint(0, 900, (1, L), generator=g)
+            labels = ids.clone(); labels[:, : 2 + i + rank] = -100
+            has = rank == 0 and i == 0
+            if has:
+                ids[0, 0] = cfg.image_token_id
+                labels[0, 0] = -100
+            mbs.append({"input_ids": ids, "images": [torch.zeros(3, 4, 4)] if has else [], "labels": labels})
+
+        def grads_of(r, i, n_global, has):
+            g = torch.randn(tr.flat.numel, generator=torch.Generator().manual_seed(1000 + 10 * r + i)) / n_global
+            if not has:                                                    # a text-only backward leaves the media buckets at zero
+                for pre in tr.media_bucket_order():
+                    a, b = tr.flat.span(pre)
+                    g[a:b] = 0
+            return g
+
+        def fake_forward_backward(input_ids, imgs, lab, mask=None, num_items_in_batch=None, block_sizes=None):
+            i = len(seen)
+            seen.append((num_items_in_batch, tr._acc_mode, tr._bucket_step, tr._media_elsewhere))
+            tr._touched = []
+            tr.flat.grads.zero_()
+            gi = grads_of(rank, i, num_items_in_batch, len(imgs) > 0)
+            for pre in (full if len(imgs) else llm_only):
+                a, b = tr.flat.span(pre)
+                tr.flat.grads[a:b] = gi[a:b]
+                tr._ready(pre)
+            tr._announce_absent_media(len(imgs))
+            tr._finish_backward()
+            return torch.tensor(float(i + 1) / num_items_in_batch)
+        tr.forward_backward = fake_forward_backward
+        loss = tr.step_accumulated(mbs)
+        n_local = sum(count_targets(mb["input_ids"], mb["labels"], None, (cfg.image_token_id, cfg.video_token_id)) for mb in mbs)
+        # reference: one process, one step, gradient = the sum over ranks and micro-batches, one AdamW update per bucket (all of them: media was seen)
+        n_global = seen[0][0]
+        rf = FlatParams(_tiny_model_seeded(), with_optimizer_state=True)
+        # (summed in the trainer's order — micro-batches first, then ranks — so fp32 rounding cannot flip a near-zero gradient's AdamW direction)
+        per_rank = [(grads_of(r, 0, n_global, r == 0) + grads_of(r, 1, n_global, False)) + grads_of(r, 2, n_global, False) for r in range(world)]
+        gsum = per_rank[0] + per_rank[1] if world == 2 else per_rank[0]
+        in_buckets = torch.zeros_like(gsum)                                # the global norm runs over what the backward wrote: the announced buckets
+        for pre in full:
+            a, b = rf.span(pre)
+            in_buckets[a:b] = gsum[a:b]
+        scale = 1.0 if clip is None else min(1.0, clip / (float(in_buckets.double().norm()) + 1e-6))
+        assert clip is None or scale < 0.5
+        for pre in full:
+            a, b = rf.span(pre)
+            _adamw_reference(rf.master[a:b], rf.m[a:b], rf.v[a:b], gsum[a:b] * scale, rf.params[a:b], 1e-2, 0.9, 0.999, 1e-8, 0.0, 1)
+        ok = torch.allclose(tr.flat.master, rf.master, atol=1e-6, rtol=1e-5)
+        moved = float((rf.master - _tiny_model_seeded_flat()).abs().max()) > 1e-4
+        import hashlib
+        digest = hashlib.sha256(tr.flat.master.numpy().tobytes()).hexdigest()
+        q.put((rank, n_local, [s[0] for s in seen], [s[1] for s in seen], [s[3] for s in seen], float(loss), bool(ok and moved), digest,
+               dict(tr.flat.bucket_steps), tr._acc_mode, tr._bucket_step))
+    finally:
+        dist.destroy_process_group()
+
+
+def _tiny_model_seeded_flat():
+    from vila_amd.train import FlatParams
+    return FlatParams(_tiny_model_seeded(), with_optimizer_state=True).master
+
+
+@pytest.mark.parametrize("clip", [None, 0.05])
+def test_accumulated_update_gloo_world2_equals_one_step_on_the_summed_gradients(clip):
+    """`--gradient_accumulation_steps 3` on two ranks: ONE global target count for all six micro-batches (HF counts the whole update's targets,
+    transformer_normalize_monkey_patch.py:236-249), no exchange before the last micro-batch, and the masters of both ranks equal what a single
+    process computes from the summed gradients — with per-bucket AdamW under the last backward (clip None) and with global-norm clipping."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (0 if clip is None else 1)
+    procs = [ctx.Process(target=_accumulation_worker, args=(r, 2, port, q, clip)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    (_, n0, counts0, modes0, else0, l0, ok0, d0, steps0, mode_after, bs_after), (_, n1, counts1, modes1, else1, l1, ok1, d1, steps1, _, _) = res
+    assert n0 != n1 and counts0 == counts1 == [n0 + n1] * 3
+    assert modes0 == modes1 == ["hold", "hold", "add"] and else0 == else1 == [False, False, True]
+    assert abs(l0 - (1 + 2 + 3) / (n0 + n1)) < 1e-6 and ok0 and ok1 and d0 == d1
+    assert steps0 == steps1 and set(steps0.values()) == {1} and "mm_projector." in steps0
+    assert mode_after is None and bs_after is False

@@ -137,6 +137,7 @@ class TrainArgs:
     num_train_epochs: float = 1.0
     max_steps: int = -1
     learning_rate: float = 2e-5
+    max_grad_norm: Optional[float] = 1.0        # HF's default; the NVILA stage-2 scripts pass 5.0
     warmup_ratio: float = 0.03
     warmup_steps: int = 0
     lr_scheduler_type: str = "cosine"
@@ -207,13 +208,14 @@ def train(trainer, dataset, collator: Callable[[Sequence[Any]], Dict[str, Any]],
           resume: bool = True, save_fn: Callable = _save_checkpoint_default, load_fn: Callable = _load_checkpoint_default,
           final_save_fn: Optional[Callable] = _save_final_default, log: Optional[Callable[[Dict[str, Any]], None]] = None, barrier: Optional[Callable[[], None]] = None) -> TrainerState:
     """Run `args.num_train_epochs` of SFT over `dataset` on this rank.  `trainer` is an `SFTTrainer` (anything with `.lr` and
-    `.step(input_ids, images, labels, attention_mask, block_sizes=, videos=) -> loss`); the gradient exchange across ranks happens inside its step.
+    `.step(input_ids, images, labels, attention_mask, block_sizes=, videos=) -> loss`, and `.step_accumulated(list of those keyword dicts)` when
+    `gradient_accumulation_steps > 1`); the gradient exchange across ranks happens inside its step.
     Only rank 0 writes checkpoints (every rank holds the same weights and optimizer state after a step); `barrier` keeps the others from running
     ahead of the rename.  A run whose folder already holds the final model is not trained again (llava/train/train.py:503-507); at the end the model is
     written into the run folder itself (train.py's `trainer.save_model(output_dir)`), which is what marks it finished."""
-    if args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("the native step updates once per call; accumulate micro-batches through the autograd seam "
-                                  "(HipLlavaLlamaModel.enable_autograd) or raise per_device_train_batch_size")
+    acc = max(1, int(args.gradient_accumulation_steps))
+    if hasattr(trainer, "max_grad_norm"):                              # HF clips the global gradient norm by default (max_grad_norm = 1.0)
+        trainer.max_grad_norm = args.max_grad_norm if (args.max_grad_norm is not None and args.max_grad_norm > 0) else None
     seed = args.data_seed if args.data_seed is not None else args.seed
     sampler = VILADistributedSampler(dataset, world_size, rank, seed=seed, batch_size=args.per_device_train_batch_size,
                                      sample_len_list=args.sample_lens, gradient_accumulation_steps=args.gradient_accumulation_steps)
@@ -239,11 +241,9 @@ def train(trainer, dataset, collator: Callable[[Sequence[Any]], Dict[str, Any]],
         for b in range(skip if epoch == first_epoch else 0, per_epoch):
             if state.global_step >= total:
                 break
-            batch = collator([dataset[i] for i in order[b * bs:(b + 1) * bs]])
             trainer.lr = args.learning_rate * lr_factor(args.lr_scheduler_type, state.global_step, n_warm, total)
-            media, mcfg = batch.get("media") or {}, batch.get("media_config") or {}
-            loss = trainer.step(batch["input_ids"], list(media.get("image", [])), batch["labels"], batch.get("attention_mask"),
-                                block_sizes=(mcfg.get("image") or {}).get("block_sizes"), videos=list(media.get("video", [])) or None)
+            micro = [_step_kwargs(collator([dataset[i] for i in order[k * bs:(k + 1) * bs]])) for k in range(b * acc, (b + 1) * acc)]
+            loss = trainer.step(**micro[0]) if acc == 1 else trainer.step_accumulated(micro)
             state.global_step += 1
             state.epoch = epoch + (b + 1) / per_epoch
             if args.logging_steps and state.global_step % args.logging_steps == 0:
@@ -263,6 +263,14 @@ def train(trainer, dataset, collator: Callable[[Sequence[Any]], Dict[str, Any]],
         if barrier is not None:
             barrier()
     return state
+
+
+def _step_kwargs(batch: Dict[str, Any]) -> Dict[str, Any]:
+    """The collator's batch (llava/data/collate.py:139-159) -> the keyword arguments of `SFTTrainer.step`."""
+    media, mcfg = batch.get("media") or {}, batch.get("media_config") or {}
+    return {"input_ids": batch["input_ids"], "images": list(media.get("image", [])), "labels": batch["labels"],
+            "attention_mask": batch.get("attention_mask"), "block_sizes": (mcfg.get("image") or {}).get("block_sizes"),
+            "videos": list(media.get("video", [])) or None}
 
 
 def _checkpoint(trainer, args: TrainArgs, state: TrainerState, rank: int, save_fn: Callable, barrier) -> None:

@@ -259,6 +259,10 @@ class SFTTrainer:
         self.ws_side = torch.empty(128 << 20, device=dev, dtype=torch.uint8) if (on_gpu and self.side is not None) else None   # the side stream's own slabs
         self._bucket_step = False          # set per step: apply AdamW bucket by bucket (no global clipping)
         self._touched: List[str] = []      # bucket prefixes whose gradients this step produced, in the order they became final
+        # gradient accumulation (`step_accumulated`): the sum of the earlier micro-batches' gradients and what `_ready` does with a bucket —
+        # None: a plain step; "hold": not the last micro-batch (no exchange, no update); "add": the last one (bucket += held sum, then as usual)
+        self._acc: Optional[torch.Tensor] = None
+        self._acc_mode: Optional[str] = None
 
     def _attn_bwd(self, *a, **kw) -> None:
         """Flash-attention backward.  dQ and dK / dV share no output and both under-fill the chip (208 blocks at 4 x 769 tokens, 4-13 % of the
@@ -278,6 +282,9 @@ class SFTTrainer:
     def _ready(self, prefix: str) -> None:
         """Gradients under `prefix` are final once the compute stream and the wgrad stream reach this point: hand the bucket to the
         optimizer stream (exchange, then AdamW on that slice) and carry on with the layers below."""
+        if self._acc_mode == "hold":                 # an earlier micro-batch of an accumulated update: its gradients only join the held sum
+            self._touched.append(prefix)
+            return
         if self.opt is None:
             # no optimizer stream: the exchange is ordered behind the compute stream, so the wgrad stream (the weight-gradient GEMMs and
             # bias column sums of this bucket are still in flight there) has to be joined first, or the all-reduce would read / overwrite
@@ -285,6 +292,7 @@ class SFTTrainer:
             if self.side is not None:
                 torch.cuda.current_stream().wait_event(self.side.record_event())
             self._touched.append(prefix)
+            self._add_held(prefix)
             self.reducer.ready(prefix)
             return
         main = torch.cuda.current_stream()
@@ -293,11 +301,19 @@ class SFTTrainer:
             self.opt.wait_event(self.side.record_event())
         self._touched.append(prefix)
         with torch.cuda.stream(self.opt):
+            self._add_held(prefix)
             h = self.reducer.ready(prefix)
             if self._bucket_step:
                 if h is not None:
                     h.wait()                                        # the optimizer stream waits for this bucket's all-reduce only
                 self._adamw_bucket(prefix, 1.0)
+
+    def _add_held(self, prefix: str) -> None:
+        """Last micro-batch of an accumulated update: this bucket's gradient becomes (sum of the earlier micro-batches) + (this one), on the
+        stream the exchange and the update of the bucket are ordered on."""
+        if self._acc_mode == "add":
+            a, b = self.flat.span(prefix)
+            ops.add(self._acc[a:b], self.flat.grads[a:b], out=self.flat.grads[a:b])
 
     def _adamw_bucket(self, prefix: str, grad_scale: float) -> None:
         """AdamW on the slice of one gradient bucket.  Semantics = torch.optim.AdamW with grad = None for what a step did not touch:
@@ -945,6 +961,46 @@ class SFTTrainer:
         finally:
             self._bucket_step = False
         return loss
+
+
+    def step_accumulated(self, micro_batches) -> float:
+        """ONE optimizer update from several micro-batches (`--gradient_accumulation_steps` of the NVILA scripts; HF `Trainer` counts the
+        targets of ALL micro-batches of the update, on all ranks, into `num_items_in_batch` — so every micro-batch's loss is its sum CE over
+        that one global count and the gradients simply add up, transformer_normalize_monkey_patch.py:236-249).  Each element of
+        `micro_batches` is the keyword dict of `step` (`input_ids`, `images`, `labels`, `attention_mask`, `block_sizes`, `videos`).  The earlier
+        micro-batches' gradients are held in one flat bf16 buffer; the exchange across ranks and the update happen once, bucket by bucket,
+        under the LAST micro-batch's backward (DDP's `no_sync` for the others).  Returns the update's (local) loss = sum over the micro-batches."""
+        mbs = [dict(mb) for mb in micro_batches]
+        if len(mbs) == 1:
+            return self.step(**mbs[0])
+        tok = (self.cfg.image_token_id, self.cfg.video_token_id)
+        n_local = sum(count_targets(mb["input_ids"], mb["labels"], mb.get("attention_mask"), tok) for mb in mbs)
+        media = [len(mb.get("images") or []) + len(mb.get("videos") or []) > 0 for mb in mbs]
+        n_global = self._global_counts(n_local, any(media))
+        any_media = any(media) or self._media_elsewhere                    # on some rank, in some micro-batch of this update
+        if self._acc is None:
+            self._acc = torch.zeros_like(self.flat.grads)
+        fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
+        losses = []
+        try:
+            for i, mb in enumerate(mbs):
+                last = i == len(mbs) - 1
+                self._acc_mode = "add" if last else "hold"
+                self._bucket_step = last and self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
+                # the media buckets hold gradient as soon as ANY micro-batch anywhere had media: the last micro-batch announces them even when
+                # it is text-only itself (held sum + zeros), so every rank exchanges and updates the same buckets
+                self._media_elsewhere = last and any_media and not media[i]
+                losses.append(fb(mb["input_ids"], list(mb.get("images") or []), mb["labels"], mb.get("attention_mask"), n_global,
+                                 mb.get("block_sizes"), **({"videos": mb["videos"]} if mb.get("videos") else {})))
+                if not last:                         # `_finish_backward` joined the wgrad stream: the micro-batch's gradients are final here
+                    if i == 0:
+                        self._acc.copy_(self.flat.grads)
+                    else:
+                        ops.add(self._acc, self.flat.grads, out=self._acc)
+            self.optimizer_step()
+        finally:
+            self._bucket_step, self._acc_mode = False, None
+        return float(sum(float(l) for l in losses))
 
 
 def count_targets(input_ids, labels, attention_mask, image_token_id) -> int:
