@@ -6,6 +6,10 @@
                scripts/NVILA-Lite/sft.sh:41-44) stepped over a dummy optimizer: the learning rate of every update
   checkpoints  `get_checkpoint_path` (llava/train/utils.py:59-79) executed over five run-folder layouts
 
+  datasets     the front of the run: `_remove_media_tokens` (llava/data/dataset_impl/utils.py:10-13), `parse_mixture` (llava/data/builder.py:58-62)
+               and `LLaVADataset` (dataset_impl/llava.py:16-74: the global-batch padding arithmetic of `__init__`, `process` on six records) —
+               ast-extracted and executed over stand-in `Image` / `BaseDataset` objects that only record what they are given
+
     python oracle/make_golden_run.py        # writes tests/golden/run_ref.json; needs /root/reference
 """
 from __future__ import annotations
@@ -70,6 +74,68 @@ def checkpoint_layouts():
     }
 
 
+MEDIA_TEXTS = ["<image>\nwhat is this?", "what is <image> this?", "look\n<image>", "<video>\n<image>\ndescribe", "no media here ", "a<image>\nb\n<image>c",
+               "  <image>  ", "<image><image>\n\n<image>x"]
+MIXTURES = {"sft_all": ["llava_a", "mix_b*2"], "mix_b": ["docvqa", "ai2d"], "stage3": ["sft_all", "extra"]}
+MIXTURE_CASES = ["llava_a", "b+a", "sft_all", "stage3+zeta*3", "mix_b+llava_a"]
+PAD_CASES = [(10, 4), (12, 4), (3, 8), (3, 7), (1, 16), (5, 16), (100, 64), (7, None), (64, 64), (9, 2)]
+RECORDS = [
+    {"image": "a.png", "conversations": [{"from": "human", "value": "<image>\nwhat is in the picture?"}, {"from": "gpt", "value": "a cat"}]},
+    {"image": ["a.png", "sub/b.png"], "conversations": [{"from": "human", "value": "compare <image> and <image>"}, {"from": "gpt", "value": "same"}]},
+    {"images": ["c.png"], "image": "a.png", "conversations": [{"from": "human", "value": "two keys\n<image>"}, {"from": "gpt", "value": "ok <image>"}]},
+    {"conversations": [{"from": "human", "value": "text only"}, {"from": "gpt", "value": "yes"}, {"from": "human", "value": "more"}, {"from": "gpt", "value": "no"}]},
+    {"image": ["1.png", "2.png", "3.png"], "conversations": [{"from": "human", "value": "<image><image><image>many"}, {"from": "gpt", "value": "three"}]},
+    {"image": "a.png", "conversations": [{"from": "gpt", "value": "wrong first speaker"}]},
+]
+
+
+def dataset_section():
+    import copy
+    import types
+    from itertools import chain
+    ns = {}
+    exec(compile(_extract(f"{REF}/data/dataset_impl/utils.py", "_remove_media_tokens", ast.FunctionDef), "utils.py", "exec"), ns)
+    strip = ns["_remove_media_tokens"]
+    ns2 = {"List": list, "chain": chain, "MIXTURES": MIXTURES}
+    exec(compile("from typing import List\n" + _extract(f"{REF}/data/builder.py", "parse_mixture", ast.FunctionDef), "builder.py", "exec"), ns2)
+
+    class Media:                                                          # stands in for llava.media.Image / Video: remembers its path
+        def __init__(self, path):
+            self.path = path
+
+    class Base:                                                           # stands in for BaseDataset.__init__ (base.py:75-94)
+        def __init__(self, data_args=None, **kw):
+            self.data_args = data_args
+    drawn = []
+    fake_random = types.SimpleNamespace(sample=lambda pop, k: (drawn.append((len(pop), k)), list(pop)[:k])[1])
+    holder = {}
+    ns3 = {"BaseDataset": Base, "Optional": Optional, "Dict": dict, "Any": object, "List": list, "copy": copy, "os": os, "random": fake_random,
+           "Image": Media, "Video": Media, "make_list": lambda x: x if isinstance(x, (list, tuple)) else [x], "_remove_media_tokens": strip,
+           "local_load_or_hf_load": lambda path: list(holder["instances"])}
+    exec(compile("from typing import Any, Dict, List, Optional\n" + _extract(f"{REF}/data/dataset_impl/llava.py", "LLaVADataset", ast.ClassDef), "llava.py", "exec"), ns3)
+    D = ns3["LLaVADataset"]
+    pads = []
+    for n, gbs in PAD_CASES:
+        holder["instances"] = [{"k": i} for i in range(n)]
+        drawn.clear()
+        d = D("x.json", "m", data_args=types.SimpleNamespace(image_aspect_ratio="dynamic", max_num_images=None), global_batch_size=gbs)
+        pads.append({"n": n, "global_batch_size": gbs, "len": len(d.instances), "drawn": list(drawn)})
+    procs = []
+    for max_images in (None, 2):
+        holder["instances"] = RECORDS
+        d = D("x.json", "media/root", data_args=types.SimpleNamespace(image_aspect_ratio="resize", max_num_images=max_images))
+        for r in RECORDS:
+            try:
+                msgs = d.process(copy.deepcopy(r))
+                rec = {"messages": [{"from": m["from"], "value": [v.path if isinstance(v, Media) else v for v in m["value"]] if isinstance(m["value"], list) else m["value"]}
+                                    for m in msgs]}
+            except ValueError as e:
+                rec = {"error": str(e)}
+            procs.append({"max_num_images": max_images, **rec})
+    return {"strip": [[t, strip(t)] for t in MEDIA_TEXTS], "mixtures": MIXTURES, "parse": [[m, ns2["parse_mixture"](m)] for m in MIXTURE_CASES],
+            "pad": pads, "records": RECORDS, "process": procs}
+
+
 def main():
     S = load_sampler()
     samplers = []
@@ -114,7 +180,8 @@ def main():
     ckpt["missing_folder"] = {"path": None if path is None else path, "continue": bool(cont)}
 
     import transformers
-    json.dump({"transformers": transformers.__version__, "base_lr": 2e-5, "samplers": samplers, "schedules": schedules, "checkpoints": ckpt},
+    json.dump({"transformers": transformers.__version__, "base_lr": 2e-5, "samplers": samplers, "schedules": schedules, "checkpoints": ckpt,
+               "datasets": dataset_section()},
               open(OUT, "w"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(samplers), "sampler cases,", len(schedules), "schedules,", ckpt)
 

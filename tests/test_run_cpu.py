@@ -200,3 +200,94 @@ def test_default_checkpoint_functions_round_trip_a_real_trainer_on_cpu(tmp_path)
         assert torch.equal(a, b)
     assert tr2.flat.step_count == 5 and tr2.flat.bucket_steps == {"mm_projector.": 5}
     assert run.TrainerState.load(os.path.join(path, "trainer_state.json")).global_step == 5
+
+
+# ------------------------------------------------------------------------------------------------------------ datasets on disk -> instances
+def test_media_token_stripping_mixture_parsing_and_global_batch_padding_equal_the_reference(fx):
+    from vila_amd import data
+    d = fx["datasets"]
+    assert len(d["strip"]) >= 8 and all(data.remove_media_tokens(t) == want for t, want in d["strip"])
+    assert all(data.parse_mixture(m, d["mixtures"]) == want for m, want in d["parse"])
+    for c in d["pad"]:
+        times, extra = data.pad_to_global_batch(c["n"], c["global_batch_size"])
+        assert c["n"] * times + extra == c["len"], c
+        assert ([[c["n"] * times, extra]] if extra else []) == c["drawn"], c             # what the reference asked `random.sample` for
+
+
+def _write_media(root, records):
+    from PIL import Image
+    sizes = {}
+    for r in records:
+        for key in ("image", "images"):
+            for p in ([r[key]] if isinstance(r.get(key), str) else r.get(key, [])):
+                if p not in sizes:
+                    sizes[p] = (8 + 2 * len(sizes), 6 + len(sizes))                       # every file has its own size: the picture names its path
+                    os.makedirs(os.path.dirname(os.path.join(root, p)) or root, exist_ok=True)
+                    Image.new("RGB", sizes[p], (10 * len(sizes), 0, 0)).save(os.path.join(root, p))
+    return sizes
+
+
+def test_llava_dataset_process_equals_the_reference_class_on_every_record(fx, tmp_path):
+    from vila_amd import data
+    d = fx["datasets"]
+    root = str(tmp_path / "media")
+    os.makedirs(root)
+    sizes = _write_media(root, d["records"])
+    by_size = {v: k for k, v in sizes.items()}
+    jpath = str(tmp_path / "set.json")
+    json.dump(d["records"], open(jpath, "w"))
+    for k, want in enumerate(d["process"]):
+        ds = data.LLaVADataset(jpath, root, cfg=None, tokenizer=None, max_num_images=want["max_num_images"], resample_on_failure=False)
+        rec = d["records"][k % len(d["records"])]
+        if "error" in want:
+            with pytest.raises(ValueError) as e:
+                ds.process(rec)
+            assert str(e.value) == want["error"]
+            continue
+        got = ds.process(rec)
+        assert rec == d["records"][k % len(d["records"])]                                # the record itself is left alone (deepcopy)
+        flat = [{"from": m["from"], "value": [("media/root/" + by_size[v.size]) if not isinstance(v, str) else v for v in m["value"]]
+                 if isinstance(m["value"], list) else m["value"]} for m in got]
+        assert flat == want["messages"], (k, flat, want["messages"])
+
+
+def test_mixture_on_disk_to_batches_through_the_run(tmp_path):
+    """json files + pictures -> build_dataset -> sampler (balanced by `sample_lens`) -> DataCollator -> the step's keyword arguments: the whole
+    input side of `run.train` over the stand-in tokenizer of the conversation fixture."""
+    pytest.importorskip("tokenizers")
+    from oracle.make_golden_conversation import build_tokenizer
+    from vila_amd import configs, data
+    from vila_amd.conversation import prepare_tokenizer
+    cfx = json.load(open(os.path.join(GOLDEN, "conversation_ref.json")))
+    tok = prepare_tokenizer(build_tokenizer(cfx["tokenizer"]), cfx["chat_template_name"])
+    tok.model_max_length = 256
+    cfg = configs.tiny("mlp_downsample")
+    cfg.image_token_id, cfg.video_token_id = tok.media_token_ids["image"], tok.media_token_ids["video"]
+    cfg.image_aspect_ratio = "resize"
+    root = str(tmp_path / "m")
+    os.makedirs(root)
+    recs_a = [{"image": f"a{i}.png", "conversations": [{"from": "human", "value": "<image>\nwhat is this ?"}, {"from": "gpt", "value": f"a red square {i}"}]} for i in range(5)]
+    recs_b = [{"conversations": [{"from": "human", "value": "hello"}, {"from": "gpt", "value": "hello again!"}]} for _ in range(3)]
+    _write_media(root, recs_a)
+    json.dump(recs_a, open(tmp_path / "a.json", "w")); json.dump(recs_b, open(tmp_path / "b.json", "w"))
+    registry = {"pics": {"_target_": "llava.data.LLaVADataset", "data_path": str(tmp_path / "a.json"), "media_dir": root},
+                "chat": {"_target_": "llava.data.LLaVADataset", "data_path": str(tmp_path / "b.json"), "media_dir": None}}
+    ds = data.build_dataset("pics+chat*2", registry, cfg, tok, global_batch_size=4, seed=0)
+    assert ds.sample_lens == [8, 8] and len(ds) == 16                    # sorted names: chat*2 (3 -> 4 padded, twice), pics (5 -> 8 padded)
+    with pytest.raises(ValueError, match="'nope' is not found"):
+        data.build_dataset("nope", registry, cfg, tok)
+    seen = []
+
+    class Rec:
+        lr = None
+        def step(self, **kw):
+            seen.append(kw)
+            return 0.5
+    args = run.TrainArgs(output_dir=str(tmp_path / "out"), per_device_train_batch_size=2, num_train_epochs=1, save_steps=0, sample_lens=ds.sample_lens)
+    st = run.train(Rec(), ds, data.DataCollator(tok), args, rank=0, world_size=2, final_save_fn=None)
+    assert st.global_step == 4 and len(seen) == 4
+    n_img = sum(len(kw["images"]) for kw in seen)
+    assert n_img == 4 and all(kw["input_ids"].shape[0] == 2 and kw["attention_mask"].dtype == torch.bool for kw in seen)     # rank 0's half of each dataset
+    for kw in seen:
+        assert int((kw["input_ids"] == cfg.image_token_id).sum()) == len(kw["images"]) and all(t.shape == (3, 56, 56) for t in kw["images"])
+        assert int((kw["labels"] != -100).sum()) > 0 and kw["videos"] is None

@@ -12,7 +12,7 @@ by the fixtures of the pieces `build_instance` is made of (conversation_ref.json
 from __future__ import annotations
 
 import logging
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -130,3 +130,145 @@ class DataCollator:
                                            "original_image_sizes": [s for r in rows for s in r["sizes"]]}, "video": {}},
                 "labels": labels, "attention_mask": attention_mask,
                 "gt_selection_maps": torch.stack(maps, dim=0) if maps and maps[0] is not None else None}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# datasets on disk -> instances (the front of `run.train`): the LLaVA-format json every NVILA SFT mixture is made of
+# ----------------------------------------------------------------------------------------------------------------------
+def remove_media_tokens(text: str) -> str:
+    """llava/data/dataset_impl/utils.py:10-13: the json's own `<image>` / `<video>` markers go; the media are re-attached in front."""
+    for token in ("<image>", "<video>"):
+        text = text.replace(token + "\n", "").replace("\n" + token, "").replace(token, "")
+    return text.strip()
+
+
+def pad_to_global_batch(n: int, global_batch_size: Optional[int]) -> Tuple[int, int]:
+    """How `LLaVADataset.__init__` (dataset_impl/llava.py:30-38) grows a dataset of n samples so that it fills whole global batches:
+    -> (times the instance list is repeated first, samples then drawn at random from the repeated list and appended)."""
+    if global_batch_size is None:
+        return 1, 0
+    times = 1
+    residual = global_batch_size - n % global_batch_size
+    if residual != global_batch_size:
+        if global_batch_size // n >= 2:
+            times = global_batch_size // n
+            residual = global_batch_size - (n * times) % global_batch_size
+        return times, residual
+    return 1, 0
+
+
+class LLaVADataset:
+    """`llava.data.LLaVADataset` (dataset_impl/llava.py:16-74): a json list of `{"conversations": [...], "image" | "images" | "video": path(s)}`
+    records under `media_dir`.  `process` re-attaches the pictures in front of the first (human) message; `__getitem__` is
+    `BaseDataset.__getitem__` = `build_instance` (with its resample-on-failure rule, base.py:183-188).  Video records are refused: frame
+    sampling from video files is outside this library's path (the serving shim's `load_video_frames` shows the rule)."""
+
+    def __init__(self, data_path: str, media_dir: Optional[str], cfg, tokenizer, global_batch_size: Optional[int] = None,
+                 no_system_prompt: bool = False, max_num_images: Optional[int] = None, resample_on_failure: bool = True, seed: Optional[int] = None):
+        import json
+        import random
+        self.data_path, self.media_dir, self.cfg, self.tokenizer = data_path, media_dir or "", cfg, tokenizer
+        self.no_system_prompt, self.max_num_images, self.resample_on_failure = no_system_prompt, max_num_images, resample_on_failure
+        with open(data_path) as fh:
+            self.instances = [json.loads(l) for l in fh if l.strip()] if data_path.endswith(".jsonl") else json.load(fh)
+        self._rng = random.Random(seed)                                   # (the reference draws from the global `random` state)
+        times, extra = pad_to_global_batch(len(self.instances), global_batch_size)
+        self.instances = self.instances * times
+        self.instances.extend([self.instances[i] for i in self._rng.sample(range(len(self.instances)), extra)])
+
+    def __len__(self) -> int:
+        return len(self.instances)
+
+    def process(self, instance: Dict[str, Any]) -> List[Dict[str, Any]]:
+        import copy
+        import os
+        from PIL import Image
+        messages = copy.deepcopy(instance["conversations"])
+        if "video" in instance:
+            raise NotImplementedError("video records: decode the frames upstream and pass them as pictures")
+        medias = []
+        for key in ("image", "images"):
+            if key in instance:
+                paths = instance[key] if isinstance(instance[key], (list, tuple)) else [instance[key]]
+                medias.extend(os.path.join(self.media_dir, p) for p in paths)
+                if self.max_num_images is not None:
+                    medias = medias[: min(self.max_num_images, len(medias))]
+        for m in messages:
+            m["value"] = remove_media_tokens(m["value"])
+        if messages[0]["from"] != "human":
+            raise ValueError(f"First message is not from human: {messages}")
+        messages[0]["value"] = [Image.open(p).convert("RGB") for p in medias] + [messages[0]["value"]]
+        return messages
+
+    def __getitem__(self, index: int) -> Dict[str, Any]:
+        try:
+            return build_instance(self.process(self.instances[index]), self.cfg, self.tokenizer, no_system_prompt=self.no_system_prompt)
+        except Exception as e:
+            if not self.resample_on_failure:
+                raise
+            _log.exception("Error processing instance '%s': '%s'. Resampling.", self.instances[index], e)
+            return self[self._rng.randint(0, len(self.instances) - 1)]
+
+
+class RepeatedDataset:
+    """`name*3` in a mixture (llava/data/builder.py:65-76)."""
+    def __init__(self, dataset, times: int):
+        self.dataset, self.times = dataset, times
+
+    def __len__(self) -> int:
+        return len(self.dataset) * self.times
+
+    def __getitem__(self, index: int):
+        return self.dataset[index % len(self.dataset)]
+
+
+class ConcatDataset:
+    """The mixture as one index space; `sample_lens` is what `VILADistributedSampler` needs to balance the datasets over the ranks."""
+    def __init__(self, datasets: Sequence[Any]):
+        self.datasets = list(datasets)
+        self.sample_lens = [len(d) for d in self.datasets]
+
+    def __len__(self) -> int:
+        return sum(self.sample_lens)
+
+    def __getitem__(self, index: int):
+        if index < 0 or index >= len(self):
+            raise IndexError(index)
+        for d, n in zip(self.datasets, self.sample_lens):
+            if index < n:
+                return d[index]
+            index -= n
+
+
+def parse_mixture(mixture: str, mixtures: Optional[Dict[str, List[str]]] = None) -> List[str]:
+    """`a+b+c`, names of registered mixtures expanded until none is left, sorted (llava/data/builder.py:58-62)."""
+    mixtures = mixtures or {}
+    names = mixture.split("+") if "+" in mixture else [mixture]
+    while any(n in mixtures for n in names):
+        names = [x for n in names for x in mixtures.get(n, [n])]
+    return sorted(names)
+
+
+def build_dataset(mixture: str, registry: Dict[str, Dict[str, Any]], cfg, tokenizer, global_batch_size: Optional[int] = None,
+                  mixtures: Optional[Dict[str, List[str]]] = None, seed: Optional[int] = None) -> ConcatDataset:
+    """`build_dataset` of llava/data/builder.py:85-151 for registries of LLaVA-format datasets: every name of the mixture (`name*times` repeats
+    it) is instantiated from its registry entry `{"_target_": "llava.data.LLaVADataset", "data_path": ..., "media_dir": ...}` with the global
+    batch size the run uses, and the datasets are concatenated in the mixture's (sorted) order."""
+    out = []
+    for name in parse_mixture(mixture, mixtures):
+        times = 1
+        if "@" in name:
+            raise NotImplementedError("subset slicing by a filter index (`name@subset`)")
+        if "*" in name:
+            name, t = name.split("*")
+            times = int(t)
+        if name not in registry:
+            raise ValueError(f"Dataset '{name}' is not found in the registries.")
+        ent = dict(registry[name])
+        target = ent.pop("_target_", "llava.data.LLaVADataset")
+        if target.rsplit(".", 1)[-1] != "LLaVADataset":
+            raise NotImplementedError(f"dataset class '{target}'")
+        known = {k: ent[k] for k in ("data_path", "media_dir", "no_system_prompt", "max_num_images", "resample_on_failure") if k in ent}
+        d = LLaVADataset(cfg=cfg, tokenizer=tokenizer, global_batch_size=global_batch_size, seed=seed, **known)
+        out.append(RepeatedDataset(d, times) if times > 1 else d)
+    return ConcatDataset(out)
