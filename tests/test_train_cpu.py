@@ -444,3 +444,81 @@ def test_accumulated_update_gloo_world2_equals_one_step_on_the_summed_gradients(
     assert abs(l0 - (1 + 2 + 3) / (n0 + n1)) < 1e-6 and ok0 and ok1 and d0 == d1
     assert steps0 == steps1 and set(steps0.values()) == {1} and "mm_projector." in steps0
     assert mode_after is None and bs_after is False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a whole data-parallel RUN on two gloo ranks: sampler shares, schedule, accumulated updates, clipping, checkpoints by rank 0 only
+# ---------------------------------------------------------------------------------------------------------------------
+def _dp_run_worker(rank, world, port, q, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from vila_amd import ops, run
+        from vila_amd.train import SFTTrainer
+        torch.manual_seed(0)
+        m = _tiny_model()
+        ops.adamw_step = _adamw_reference
+        ops.add = lambda a, b, out=None: torch.add(a, b, out=out)
+        ops.sumsq = lambda x: (x.double() ** 2).sum().float().reshape(1)
+        tr = SFTTrainer(m, lr=0.0, weight_decay=0.0)
+        tr.flat.grads = tr.flat.grads.float()
+        cfg = m.cfg
+        order = _bucket_order(cfg)[1:] if cfg.llm.tie_word_embeddings else _bucket_order(cfg)
+        llm_only = order[:-len(tr.media_bucket_order())]
+        fed = []
+
+        def fake_forward_backward(input_ids, imgs, lab, mask=None, num_items_in_batch=None, block_sizes=None):
+            fed.append((input_ids[:, 1].tolist(), num_items_in_batch, tr.lr, tr.max_grad_norm))
+            tr._touched = []
+            tr.flat.grads.zero_()
+            g = torch.randn(tr.flat.numel, generator=torch.Generator().manual_seed(int(input_ids[:, 1].sum()))) / num_items_in_batch
+            for pre in llm_only:
+                a, b = tr.flat.span(pre)
+                tr.flat.grads[a:b] = g[a:b]
+                tr._ready(pre)
+            tr._announce_absent_media(0)
+            tr._finish_backward()
+            return torch.tensor(1.0 / num_items_in_batch)
+        tr.forward_backward = fake_forward_backward
+        data = [{"input_ids": torch.tensor([7, i, 9, 11]), "labels": torch.tensor([-100, -100, 9 + i % 2, 11])} for i in range(41)]
+        coll = lambda insts: {"input_ids": torch.stack([x["input_ids"] for x in insts]), "labels": torch.stack([x["labels"] for x in insts]),
+                              "attention_mask": None, "media": {"image": [], "video": []}}
+        args = run.TrainArgs(output_dir=out_dir, per_device_train_batch_size=2, gradient_accumulation_steps=2, num_train_epochs=2, learning_rate=1e-2,
+                             warmup_ratio=0.25, save_steps=3, save_total_limit=1, max_grad_norm=0.5, seed=5)
+        save = lambda t, folder: json.dump({"rank": rank, "step": t.flat.step_count}, open(os.path.join(folder, "who.json"), "w"))
+        st = run.train(tr, data, coll, args, rank=rank, world_size=world, save_fn=save, load_fn=None, final_save_fn=None, barrier=dist.barrier)
+        import hashlib
+        digest = hashlib.sha256(tr.flat.master.numpy().tobytes()).hexdigest()
+        q.put((rank, st.global_step, [f[0] for f in fed], [f[1] for f in fed], [f[2] for f in fed], {f[3] for f in fed}, digest, tr.flat.step_count))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_run_gloo_world2_shares_schedule_accumulation_and_rank0_checkpoints(tmp_path):
+    """`run.train` on two ranks over the real `SFTTrainer` (kernels stubbed): 41 samples -> 40 kept = 5 updates per epoch of 2 micro-batches x 2
+    samples x 2 ranks; the ranks' samples are disjoint within an epoch, every micro-batch of an update sees the update's GLOBAL target count and
+    learning rate, both ranks end with bit-identical masters, and only rank 0 wrote (and rotated) the checkpoints."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    out = str(tmp_path / "run")
+    procs = [ctx.Process(target=_dp_run_worker, args=(r, 2, port, q, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    (_, steps0, fed0, n0, lr0, clip0, d0, sc0), (_, steps1, fed1, n1, lr1, clip1, d1, sc1) = res
+    assert steps0 == steps1 == 10 == sc0 == sc1 and len(fed0) == len(fed1) == 20
+    e0 = [i for b in fed0[:10] for i in b], [i for b in fed1[:10] for i in b]
+    assert len(set(e0[0]) | set(e0[1])) == 40 and not set(e0[0]) & set(e0[1])                 # epoch 0: 40 distinct samples, 20 per rank
+    assert sorted(e0[0] + e0[1]) == sorted([i for b in fed0[10:] for i in b] + [i for b in fed1[10:] for i in b])   # epoch 1: the same 40, reshuffled
+    assert fed0[:10] != fed0[10:]
+    assert n0 == n1 == [16] * 20                                                               # 2 targets x 2 samples x 2 micro-batches x 2 ranks
+    from vila_amd import run
+    want_lr = [1e-2 * run.lr_factor("cosine", k // 2, run.warmup_steps(10, 0.25), 10) for k in range(20)]
+    assert lr0 == lr1 == want_lr and lr0[0] == 0.0 and clip0 == clip1 == {0.5}
+    assert d0 == d1
+    import json
+    assert sorted(os.listdir(out)) == ["checkpoint-9"] and json.load(open(os.path.join(out, "checkpoint-9", "who.json"))) == {"rank": 0, "step": 9}
