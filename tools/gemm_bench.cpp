@@ -218,6 +218,16 @@ int main(int argc, char** argv) {
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
         g_cold = 0;
     }
+    if (!strcmp(what, "prering")) {    // round 5, first thing: the 128x128 ring with 3 / 4 stages (force_tile 9 / 10, written without a GPU) vs the current choices, cold weights
+        g_cold = 1;
+        std::vector<Case> pc = {
+            {"LLM qkv  S=769 cold", 769, 4608, 3584, 0, 0, 0}, {"LLM o+res S=769 cold", 769, 3584, 3584, 0, 0, 1},
+            {"ViT qkv  M=1024 cold", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res cold", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc1 cold", 1024, 4304, 1152, 0, 0, 0},
+            {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
+        };
+        for (auto& c : pc) run_case(c, {300, 307, 308, 309, 310, 300, 307, 308, 309, 310}, ws, ws_bytes);
+        g_cold = 0;
+    }
     if (!strcmp(what, "grp")) {        // tile order: row-tile-fastest strips (400) vs columns grouped by 4 / 2 / 8 (8 x 4 patches per XCD)
         for (int i : {5, 6, 7, 8, 9, 0, 2, 4}) run_case(bwd[i], {400, 404, 402, 408, 400, 404}, ws, ws_bytes);
         for (int i : {2, 3, 5, 6}) run_case(fwd[i], {400, 404, 400, 404}, ws, ws_bytes);

@@ -209,8 +209,14 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
     VILA_FAIL(-1, "gemm_ring: unsupported epilogue %d", a.epi);
 }
 
-// variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU)
+// variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU);
+// 12 / 16 = 128x128 tile with 3 / 4 stages (96 / 128 KB of LDS, one block per CU, two / three K-tiles in flight).  12 and 16 were ADDED
+// WITHOUT A GPU at the end of round 4 and are reachable only through vila_gemm_force_tile(9 / 10) / VILA_RING_BIG (off by default): the
+// S = 769 q/k/v/o launches are one round of 504 / 392 128x64 blocks that pull 677 MB through L2 for 39 MB of operands (24 KB per block and
+// K-tile); a 128x128 tile halves that traffic per flop, and what the 2-stage variant lacked at one block per CU was loads in flight.
 int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {
+    if (variant == 16) return launch_ring_epi<4, 4>(a, s);
+    if (variant == 12) return launch_ring_epi<3, 4>(a, s);
     if (variant == 8) return launch_ring_epi<2, 4>(a, s);
     if (variant == 4) return launch_ring_epi<4, 2>(a, s);
     return launch_ring_epi<3, 2>(a, s);
