@@ -118,3 +118,27 @@ def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
         assert rel_l2(ops.gemm(a, w, bias=bias, epi=2), torch.nn.functional.gelu(ref + bias.float())) < 5e-3
     finally:
         lib.vila_gemm_force_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(289, 4608, 3584), (64, 3584, 3584), (160, 4608, 3584), (300, 264, 1096), (1, 24, 1024), (511, 520, 2056)])
+def test_gemm_ring_k_sliced_for_short_prompts(M, N, K):
+    """gemm_ring_splitk.hip (`vila_gemm_force_tile(11)` + a workspace): fp32 slabs per K-slice + reduce with bias / residual, also in place on
+    the residual stream, against the fp32 reference and against the un-sliced default choice."""
+    from gpu_util import randn_bf16, rel_l2
+    from vila_amd import _lib, ops
+    lib = _lib.load()
+    a = randn_bf16(M, K, seed=51)
+    w = randn_bf16(N, K, seed=52, scale=K ** -0.5)
+    bias, res = randn_bf16(N, seed=53), randn_bf16(M, N, seed=54)
+    ws = torch.empty(4 * M * N, device="cuda", dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    plain = ops.gemm(a, w, bias=bias, residual=res)
+    lib.vila_gemm_force_tile(11)
+    try:
+        out = ops.gemm(a, w, bias=bias, residual=res, ws=ws)
+        x = res.clone()
+        ops.gemm(a, w, bias=bias, residual=x, out=x, ws=ws)
+    finally:
+        lib.vila_gemm_force_tile(0)
+    assert rel_l2(out, ref) < 4e-3 and rel_l2(out, plain.float()) < 4e-3, (rel_l2(out, ref), rel_l2(out, plain.float()))
+    assert torch.equal(x, out)

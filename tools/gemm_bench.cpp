@@ -226,6 +226,13 @@ int main(int argc, char** argv) {
             {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
         };
         for (auto& c : pc) run_case(c, {300, 307, 308, 309, 310, 300, 307, 308, 309, 310}, ws, ws_bytes);
+        // short prompts: the K-sliced 128x64 ring (force_tile 11, gemm_ring_splitk.hip) vs the automatic choice and the plain ring
+        std::vector<Case> sc = {
+            {"LLM qkv M=64 cold", 64, 4608, 3584, 0, 0, 0}, {"LLM qkv M=160 cold", 160, 4608, 3584, 0, 0, 0}, {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0},
+            {"LLM o+res M=64 cold", 64, 3584, 3584, 0, 0, 1}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
+            {"Lite qkv M=154 cold", 154, 2560, 2048, 0, 0, 0}, {"Lite o+res M=154 cold", 154, 2048, 2048, 0, 0, 1},
+        };
+        for (auto& c : sc) run_case(c, {300, 307, 311, 300, 307, 311}, ws, ws_bytes);
         g_cold = 0;
     }
     if (!strcmp(what, "grp")) {        // tile order: row-tile-fastest strips (400) vs columns grouped by 4 / 2 / 8 (8 x 4 patches per XCD)

@@ -1,9 +1,10 @@
 #!/bin/bash
 # FIRST GPU call of round 5: everything that was written at the end of round 4 WITHOUT a GPU (0.6 GPU-minutes were left) gets its first run.
 #   gpurun --timeout 1500 -- bash tools/r05_first_call.sh          results under gpurun_out/r05_first/
-# 1. the gated tests (tests/test_gpu_run.py: accumulated update, resumed run, the 3- / 4-stage 128x128 ring) — apart from the suite
+# 1. the gated tests (tests/test_gpu_run.py: accumulated update, resumed run, the 3- / 4-stage 128x128 ring, the K-sliced ring) — apart from the suite
 # 2. tools/gemm_bench prering: the new ring variants (force_tile 9 / 10) vs the current choices on the prefill / tower shapes, cold weights
 # 3. TTFT A/B of the dispatch switch VILA_RING_BIG = 0 / 12 / 16 on the default bench line (no SFT, no sustained loop, no CPU leg)
+# 3b. VILA_RING_SPLITK = 0 / 1 on the short-prompt lines (gemm_ring_splitk.hip)
 # 4. the suite itself (the round-4 late commits after the last full run: chat template, prepare_tokenizer, stop_token_ids)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_first; mkdir -p "$O"
@@ -14,5 +15,14 @@ for v in 0 12 16; do
   VILA_RING_BIG=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_big_$v.json" 2> "$O/ring_big_$v.err"
   python -c "
 import json; d=json.loads(open('$O/ring_big_$v.json').read().strip().splitlines()[-1]); print('VILA_RING_BIG=$v: ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_big_$v.err"
+done
+# 3b. the K-sliced ring on SHORT prompts (VILA_RING_SPLITK = 0 / 1): configs[1]'s 32-token prompt (S = 289) and the Lite-3B line
+for v in 0 1; do
+  VILA_RING_SPLITK=$v timeout 300 python bench.py --prompt-tokens 32 --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_splitk_$v.json" 2> "$O/ring_splitk_$v.err"
+  VILA_RING_SPLITK=$v timeout 300 python bench.py --config nvila_lite_3b --prompt-tokens 32 --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_splitk_lite_$v.json" 2> "$O/ring_splitk_lite_$v.err"
+  python -c "
+import json
+for f in ('$O/ring_splitk_$v.json', '$O/ring_splitk_lite_$v.json'):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print('VILA_RING_SPLITK=$v', d['config'].get('workload'), ': ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_splitk_$v.err"
 done
 timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -25 > "$O/pytest.log"; tail -3 "$O/pytest.log"

@@ -211,10 +211,18 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
 bool gemm_ring_supported(const GemmArgs& a);
 int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
-static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring, 9 / 10 = 128x128 DMA ring with 3 / 4 stages
+int gemm_ring_splitk_slices(const GemmArgs& a);      // gemm_ring_splitk.hip: K-sliced 128x64 ring for short prompts (unmeasured, opt-in)
+int launch_gemm_ring_splitk(const GemmArgs& a, int splits, hipStream_t s);
+static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring, 9 / 10 = 128x128 DMA ring with 3 / 4 stages, 11 = K-sliced 128x64 ring (needs a workspace)
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 // VILA_RING_BIG = 12 / 16: one-round grids of the 128x128 ring (65..256 tiles: the S = 769 q/k/v/o projections, the tower's qkv / fc1 at one
 // image) take the 3- / 4-stage 128x128 variant instead of the 128x64 ring.  Unset / 0 = off (the default until measured, gemm_ring.hip).
+// VILA_RING_SPLITK = 1: q/k/v/o-sized GEMMs of SHORT prompts (M < 512, a workspace given) take the K-sliced ring (gemm_ring_splitk.hip).
+static int ring_splitk_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_RING_SPLITK"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static int ring_big() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VILA_RING_BIG"); v = e ? atoi(e) : 0; if (v != 12 && v != 16) v = 0; }
@@ -257,6 +265,12 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);
     }
     if (sel == 5) sel = 0;
+    if constexpr (EPI == EPI_NONE && !OUT_F32) {
+        if ((sel == 11 || (sel == 0 && ring_splitk_env() && a.M < 512)) && gemm_ring_supported(a)) {
+            const int sp = gemm_ring_splitk_slices(a);
+            if (sp >= 2) return launch_gemm_ring_splitk(a, sp, s);
+        }
+    }
     // everything below the gemm256 threshold: the LDS-DMA ring kernels (gemm_ring.hip) instead of the one-tile-ahead register staging
     if (EPI != EPI_GATEUP && !OUT_F32 && gemm_ring_supported(a)) {
         const int64_t tiles_ring = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64);
@@ -271,7 +285,7 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (sel == 6) return launch_gemm_ring(a, 4, s);
         if (sel == 8 || sel == 0) return launch_gemm_ring(a, 8, s);
     }
-    if (sel >= 6 && sel <= 10) sel = 0;
+    if (sel >= 6 && sel <= 11) sel = 0;
     if (sel == 0) {
         const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
         if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;
