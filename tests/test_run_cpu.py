@@ -159,6 +159,11 @@ def test_resumed_run_replays_neither_a_batch_nor_a_learning_rate(tmp_path):
     assert third.calls == [] and st3.global_step == 30 and "Skipp training" in said[0]["message"]
 
 
+def test_a_mixture_below_one_global_batch_is_refused():
+    with pytest.raises(ValueError, match="does not fill one global batch"):
+        run.train(_Stub(), _dataset(7), _collate, run.TrainArgs(per_device_train_batch_size=4), world_size=2, final_save_fn=None)
+
+
 def test_accumulation_groups_consecutive_batches_into_one_update(tmp_path):
     class Acc(_Stub):
         max_grad_norm = None

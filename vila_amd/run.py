@@ -220,6 +220,9 @@ def train(trainer, dataset, collator: Callable[[Sequence[Any]], Dict[str, Any]],
     sampler = VILADistributedSampler(dataset, world_size, rank, seed=seed, batch_size=args.per_device_train_batch_size,
                                      sample_len_list=args.sample_lens, gradient_accumulation_steps=args.gradient_accumulation_steps)
     bs = args.per_device_train_batch_size
+    if len(sampler) < bs * acc:
+        raise ValueError(f"the mixture ({len(dataset)} samples) does not fill one global batch of {bs} x {acc} x {world_size} samples: "
+                         "pad the datasets to the global batch size (data.build_dataset(global_batch_size=...))")
     per_epoch, epochs, total = plan(len(sampler), args)
     n_warm = warmup_steps(total, args.warmup_ratio, args.warmup_steps)
     state = TrainerState(max_steps=total)
