@@ -10,6 +10,10 @@
                and `LLaVADataset` (dataset_impl/llava.py:16-74: the global-batch padding arithmetic of `__init__`, `process` on six records) —
                ast-extracted and executed over stand-in `Image` / `BaseDataset` objects that only record what they are given
 
+  decay        the two statements of `LLaVATrainer.create_optimizer` that choose the weight-decay group (llava/train/llava_trainer.py:494-495),
+               taken out of the method with `ast` and executed over the reference's own modules (reference SigLIP + projector, HF Qwen2) held
+               under the names the VLM gives them: the names that decay
+
     python oracle/make_golden_run.py        # writes tests/golden/run_ref.json; needs /root/reference
 """
 from __future__ import annotations
@@ -23,6 +27,7 @@ import random
 import re
 import sys
 import tempfile
+import types
 from typing import Optional
 
 import torch
@@ -136,6 +141,50 @@ def dataset_section():
             "pad": pads, "records": RECORDS, "process": procs}
 
 
+def decay_section():
+    """-> {"decay": [...names...], "all": [...names...]} for the tiny `mlp_downsample` and `mlp_downsample_3x3_fix` configurations."""
+    # llava_trainer.py:32-33 imports both names from transformers.trainer (4.46); the installed 5.x keeps them in their home modules only
+    from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS
+    from transformers.trainer_pt_utils import get_parameter_names
+    sys.path.insert(0, ROOT)
+    from oracle import make_golden as G
+    from vila_amd import configs, synthetic
+    src = open(f"{REF}/train/llava_trainer.py").read()
+    fn = next(n for c in ast.parse(src).body if isinstance(c, ast.ClassDef) and c.name == "LLaVATrainer" for n in c.body
+              if isinstance(n, ast.FunctionDef) and n.name == "create_optimizer")
+    stmts = [ast.get_source_segment(src, n) for n in ast.walk(fn) if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "decay_parameters"]
+    assert len(stmts) == 2, stmts
+    out = {}
+    for kind in ("mlp_downsample", "mlp_downsample_3x3_fix"):
+        cfg = configs.tiny(kind)
+        w = synthetic.make_weights(cfg, 0)
+        ms, bp = G.ref_siglip(), G.ref_projector()
+        v = cfg.vision
+        vc = ms.SiglipVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size, num_hidden_layers=v.num_hidden_layers,
+                                   num_attention_heads=v.num_attention_heads, image_size=v.image_size, patch_size=v.patch_size, num_channels=v.num_channels)
+        vc._attn_implementation = "eager"
+        llm, _ = G.build_hf_llm(cfg, w)
+
+        class Tower(torch.nn.Module):                                     # VisionTower holds the HF model as `.vision_tower` (vision_encoder.py)
+            def __init__(self):
+                super().__init__()
+                self.vision_tower = ms.SiglipVisionModel(vc)
+
+        class VLM(torch.nn.Module):                                       # LlavaMetaModel's three attributes (llava_arch.py:73-75)
+            def __init__(self):
+                super().__init__()
+                self.llm, self.vision_tower = llm, Tower()
+                self.mm_projector = bp.MultimodalProjector(bp.MultimodalProjectorConfig(cfg.mm_projector_type),
+                                                           types.SimpleNamespace(mm_hidden_size=cfg.mm_hidden_size, hidden_size=cfg.llm.hidden_size))
+        opt_model = VLM()
+        ns = {"get_parameter_names": get_parameter_names, "ALL_LAYERNORM_LAYERS": ALL_LAYERNORM_LAYERS, "opt_model": opt_model}
+        for st in stmts:
+            exec(st, ns)
+        out[kind] = {"decay": sorted(ns["decay_parameters"]), "all": sorted(n for n, _ in opt_model.named_parameters()),
+                     "layernorm_layers": [c.__name__ for c in ALL_LAYERNORM_LAYERS]}
+    return out
+
+
 def main():
     S = load_sampler()
     samplers = []
@@ -181,7 +230,7 @@ def main():
 
     import transformers
     json.dump({"transformers": transformers.__version__, "base_lr": 2e-5, "samplers": samplers, "schedules": schedules, "checkpoints": ckpt,
-               "datasets": dataset_section()},
+               "datasets": dataset_section(), "decay": decay_section()},
               open(OUT, "w"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(samplers), "sampler cases,", len(schedules), "schedules,", ckpt)
 

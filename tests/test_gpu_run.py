@@ -103,7 +103,7 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
 def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
     """The 128x128 LDS-DMA ring with 3 / 4 stages (gemm_ring.hip variants 12 / 16, `vila_gemm_force_tile(9 / 10)`): same epilogues, same
     tolerances as every other tile shape (tests/test_gpu_ops.py::test_gemm_every_tile_shape)."""
-    from gpu_util import randn_bf16, rel_l2
+    from tests.gpu_util import randn_bf16, rel_l2
     from vila_amd import _lib, ops
     lib = _lib.load()
     a = randn_bf16(M, K, seed=41)
@@ -124,7 +124,7 @@ def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
 def test_gemm_ring_k_sliced_for_short_prompts(M, N, K):
     """gemm_ring_splitk.hip (`vila_gemm_force_tile(11)` + a workspace): fp32 slabs per K-slice + reduce with bias / residual, also in place on
     the residual stream, against the fp32 reference and against the un-sliced default choice."""
-    from gpu_util import randn_bf16, rel_l2
+    from tests.gpu_util import randn_bf16, rel_l2
     from vila_amd import _lib, ops
     lib = _lib.load()
     a = randn_bf16(M, K, seed=51)

@@ -296,3 +296,75 @@ def test_mixture_on_disk_to_batches_through_the_run(tmp_path):
     for kw in seen:
         assert int((kw["input_ids"] == cfg.image_token_id).sum()) == len(kw["images"]) and all(t.shape == (3, 56, 56) for t in kw["images"])
         assert int((kw["labels"] != -100).sum()) > 0 and kw["videos"] is None
+
+
+# ------------------------------------------------------------------------------------------------------------ the optimizer's weight-decay groups
+@pytest.mark.parametrize("kind", ["mlp_downsample", "mlp_downsample_3x3_fix"])
+def test_weight_decay_groups_equal_the_reference_create_optimizer_rule(fx, kind):
+    """`FlatParams.decays` against the names the reference's own two statements (llava_trainer.py:494-495, executed over the reference SigLIP /
+    projector + HF Qwen2) put into the decaying group: biases and LayerNorm weights out, Qwen2's RMSNorm weights IN (they are not nn.LayerNorm)."""
+    from vila_amd import configs
+    from vila_amd.train import FlatParams
+    from vila_amd.vlm import HipLlavaLlamaModel
+    ref = fx["decay"][kind]
+    assert ref["layernorm_layers"] == ["LayerNorm"]
+    flat = FlatParams(HipLlavaLlamaModel(configs.tiny(kind), device="cpu"), with_optimizer_state=False)
+    ours = set(flat.index)
+    theirs = {n for n in ref["all"] if ".vision_model.head." not in n}            # the pooling head VILA never builds (vision_use_head = false)
+    assert ours - {"llm.lm_head.weight"} == theirs - {"llm.lm_head.weight"}        # (a tied head appears once in named_parameters)
+    decay = set(ref["decay"])
+    for n in ours & theirs:
+        assert flat.decays(n) == (n in decay), n
+    assert sum(flat.decays(n) for n in ours) >= 40 and any(not flat.decays(n) and "bias" not in n for n in ours)
+    # the runs a bucket is cut into cover it exactly, in order, with alternating flags
+    for pre in ("llm.model.layers.0.", "mm_projector.", "vision_tower.vision_tower.vision_model.encoder.layers.1."):
+        a, b = flat.span(pre)
+        runs = flat.decay_runs(pre)
+        assert runs[0][0] == a and runs[-1][1] == b and all(r[1] == s[0] and r[2] != s[2] for r, s in zip(runs, runs[1:]))
+        for n, (o, k, _) in flat.index.items():
+            if n.startswith(pre):
+                assert any(ra <= o and o + k <= rb and d == flat.decays(n) for ra, rb, d in runs), n
+
+
+def test_adamw_with_weight_decay_equals_torch_adamw_with_the_reference_groups():
+    """One update of every bucket through `SFTTrainer._adamw_bucket` (kernel stubbed by its torch restatement) == torch.optim.AdamW over two
+    parameter groups built by the reference rule; with `decay_groups=False` everything decays (the pre-round-4 behaviour, kept as a switch)."""
+    from tests import test_train_cpu as TC
+    from vila_amd import ops
+    from vila_amd.train import SFTTrainer
+    orig = ops.adamw_step
+    ops.adamw_step = TC._adamw_reference
+    try:
+        torch.manual_seed(0)
+        tr = SFTTrainer(TC._tiny_model(), lr=1e-2, weight_decay=0.1)
+        tr.flat.grads = torch.randn(tr.flat.numel, generator=torch.Generator().manual_seed(3))
+        names = [n for n in tr.flat.index]
+        ps = {n: torch.nn.Parameter(tr.flat.master[o:o + k].clone()) for n, (o, k, _) in tr.flat.index.items()}
+        for n, (o, k, _) in tr.flat.index.items():
+            ps[n].grad = tr.flat.grads[o:o + k].clone()
+        opt = torch.optim.AdamW([{"params": [ps[n] for n in names if tr.flat.decays(n)], "weight_decay": 0.1},
+                                 {"params": [ps[n] for n in names if not tr.flat.decays(n)], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+        opt.step()
+        order = TC._bucket_order(tr.cfg)
+        for pre in (order[1:] if tr.cfg.llm.tie_word_embeddings else order):
+            tr._adamw_bucket(pre, 1.0)
+        touched = [n for n in names if any(n.startswith(p) for p in order)]
+        assert len(touched) > 60
+        for n in touched:
+            o, k, _ = tr.flat.index[n]
+            assert torch.allclose(tr.flat.master[o:o + k], ps[n].detach(), atol=1e-7, rtol=1e-6), n
+        n_bias = next(n for n in touched if n.endswith("q_proj.bias"))
+        o, k, _ = tr.flat.index[n_bias]
+        before = torch.nn.Parameter(tr.flat.master[o:o + k].clone())
+        tr2 = SFTTrainer(TC._tiny_model_seeded(), lr=1e-2, weight_decay=0.1, decay_groups=False)
+        tr2.flat.grads = tr.flat.grads.clone()
+        tr2._adamw_bucket("llm.model.layers.0.", 1.0)
+        o2, k2, _ = tr2.flat.index["llm.model.layers.0.self_attn.q_proj.bias"]
+        tr3 = SFTTrainer(TC._tiny_model_seeded(), lr=1e-2, weight_decay=0.1)
+        tr3.flat.grads = tr.flat.grads.clone()
+        tr3._adamw_bucket("llm.model.layers.0.", 1.0)
+        assert not torch.equal(tr2.flat.master[o2:o2 + k2], tr3.flat.master[o2:o2 + k2])       # the bias decays only without the groups
+        ow, kw, _ = tr2.flat.index["llm.model.layers.0.mlp.down_proj.weight"]
+        assert torch.equal(tr2.flat.master[ow:ow + kw], tr3.flat.master[ow:ow + kw])
+    finally:
+        ops.adamw_step = orig

@@ -197,9 +197,10 @@ def _dp_step_worker(rank, world, port, q):
         from vila_amd.train import FlatParams
         rf = FlatParams(ref_m, with_optimizer_state=True)
         gsum = sum(torch.randn(rf.numel, generator=torch.Generator().manual_seed(200 + r)) * (1.0 / want_global) for r in range(world))
-        for pre in order:
-            a, b = rf.span(pre)
-            _adamw_reference(rf.master[a:b], rf.m[a:b], rf.v[a:b], gsum[a:b], rf.params[a:b], 1e-2, 0.9, 0.999, 1e-8, 0.01, 1)
+        for n, (o, k, shape) in rf.index.items():            # tensor by tensor, decay by the reference's group rule (biases / LayerNorm weights: none)
+            if any(n.startswith(pre) for pre in order):
+                _adamw_reference(rf.master[o:o + k], rf.m[o:o + k], rf.v[o:o + k], gsum[o:o + k], rf.params[o:o + k], 1e-2, 0.9, 0.999, 1e-8,
+                                 0.01 if _decays_like_the_reference(n, shape) else 0.0, 1)
         same_as_ref = torch.allclose(tr.flat.master, rf.master, atol=1e-6, rtol=1e-5)
         import hashlib
         digest = hashlib.sha256(tr.flat.master.numpy().tobytes()).hexdigest()     # (a tensor in the queue would need the sender to stay alive)
@@ -211,6 +212,18 @@ def _dp_step_worker(rank, world, port, q):
 def _tiny_model_seeded():
     torch.manual_seed(0)
     return _tiny_model()
+
+
+def _decays_like_the_reference(name, shape):
+    """llava_trainer.py:494-495 for this model family, restated independently of FlatParams.decays: no "bias" in the name, and not a parameter of
+    an nn.LayerNorm (tower: layer_norm1 / layer_norm2 / post_layernorm; projector: the 1-D `layers.N.weight`); Qwen2's RMSNorm weights decay."""
+    if "bias" in name:
+        return False
+    if "layer_norm" in name or "post_layernorm" in name:
+        return False
+    if name.startswith("mm_projector.") and len(shape) == 1:
+        return False
+    return True
 
 
 def test_dp_step_gloo_world2_global_count_loss_scaling_and_identical_masters():

@@ -132,6 +132,26 @@ class FlatParams:
     def named_grads(self) -> Dict[str, torch.Tensor]:
         return {n: self.grad(n) for n in self.index}
 
+    def decays(self, name: str) -> bool:
+        """Whether AdamW's weight decay applies to this tensor under the reference's parameter groups (`LLaVATrainer.create_optimizer`,
+        llava/train/llava_trainer.py:494-495, 537-553: `get_parameter_names(model, ALL_LAYERNORM_LAYERS)` minus every name containing
+        "bias").  `ALL_LAYERNORM_LAYERS` is `[nn.LayerNorm]` for this model family — Qwen2's RMSNorm is not in it, so the decoder's norm
+        weights DO decay; the LayerNorms are the tower's and the projector's, whose weights are the only 1-D non-bias tensors outside the LLM."""
+        if "bias" in name:
+            return False
+        return not (len(self.index[name][2]) == 1 and not name.startswith("llm."))
+
+    def decay_runs(self, prefix: str) -> List[Tuple[int, int, bool]]:
+        """The slice of one gradient bucket cut into maximal runs of adjacent tensors with the same decay flag: [(start, end, decays)]."""
+        ent = sorted((o, o + (k + 7) // 8 * 8, self.decays(n)) for n, (o, k, _) in self.index.items() if n.startswith(prefix))
+        runs: List[Tuple[int, int, bool]] = []
+        for a, b, d in ent:
+            if runs and runs[-1][2] == d and runs[-1][1] == a:
+                runs[-1] = (runs[-1][0], b, d)
+            else:
+                runs.append((a, b, d))
+        return runs
+
 
 class GradReducer:
     """Bucketed SUM all-reduce of slices of the flat gradient buffer, one bucket per layer, issued as soon as the layer's
@@ -229,7 +249,7 @@ def linear_bwd(x2: torch.Tensor, w: torch.Tensor, dy2: torch.Tensor, gw: torch.T
 # ----------------------------------------------------------------------------------------------------------------------
 class SFTTrainer:
     def __init__(self, model, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 max_grad_norm: Optional[float] = None, optimizer_state: bool = True, group=None):
+                 max_grad_norm: Optional[float] = None, optimizer_state: bool = True, group=None, decay_groups: bool = True):
         self.model = model
         self.cfg = model.cfg
         self.flat = FlatParams(model, with_optimizer_state=optimizer_state)
@@ -237,6 +257,8 @@ class SFTTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.group = group
+        self.decay_groups = decay_groups   # weight decay skips biases and LayerNorm weights like the reference's optimizer groups (False: decays all)
+        self._decay_runs: Dict[str, List[Tuple[int, int, bool]]] = {}
         dev = model.device
         on_gpu = torch.device(dev).type == "cuda"
         # side: weight-gradient GEMMs of the decoder layers (concurrent with the dgrad chain on the compute stream)
@@ -323,8 +345,17 @@ class SFTTrainer:
         a, b = f.span(prefix)
         step = f.bucket_steps.get(prefix, getattr(f, "bucket_step_floor", 0)) + 1
         f.bucket_steps[prefix] = step
-        ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.wd, step, grad_scale, lean=self.lean_adamw)
+        if self.wd == 0.0 or not self.decay_groups:          # every NVILA script trains with --weight_decay 0.: one launch per bucket
+            ops.adamw_step(f.master[a:b], f.m[a:b], f.v[a:b], f.grads[a:b], f.params[a:b], self.lr, self.betas[0], self.betas[1],
+                           self.eps, self.wd, step, grad_scale, lean=self.lean_adamw)
+            return
+        # weight decay > 0: the reference's two parameter groups (biases and LayerNorm weights do not decay) = one launch per run of
+        # adjacent tensors with the same flag
+        if prefix not in self._decay_runs:
+            self._decay_runs[prefix] = f.decay_runs(prefix)
+        for ra, rb, dec in self._decay_runs[prefix]:
+            ops.adamw_step(f.master[ra:rb], f.m[ra:rb], f.v[ra:rb], f.grads[ra:rb], f.params[ra:rb], self.lr, self.betas[0], self.betas[1],
+                           self.eps, self.wd if dec else 0.0, step, grad_scale, lean=self.lean_adamw)
 
     # ------------------------------------------------------------------ ViT ------------------------------------------------
     def _vit_fwd(self, pixels: torch.Tensor):
