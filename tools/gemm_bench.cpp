@@ -57,7 +57,8 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
         if (sched == 9 && (c.a_cm || c.b_cm)) continue;
         // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
         // pseudo schedules 256 / 192: default kernels with that tile height forced (0 elsewhere = automatic)
-        const bool tilef = sched >= 300 && sched < 320;          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
+        const bool tilef = sched >= 300 && sched < 320;          // (9 / 10 / 11 / 12..15: the variants added unmeasured at the end of round 4)
+        //          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
         const bool grpf = sched >= 400 && sched < 420;            // pseudo schedules 400 + g: default kernels with vila_gemm_force_group(g) (0 = row-tile-fastest order)
         vila_gemm_force_group(grpf ? sched - 400 : -1);
         const bool bmf = sched == 256 || sched == 192;
@@ -225,7 +226,7 @@ int main(int argc, char** argv) {
             {"ViT qkv  M=1024 cold", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res cold", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc1 cold", 1024, 4304, 1152, 0, 0, 0},
             {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
         };
-        for (auto& c : pc) run_case(c, {300, 307, 308, 309, 310, 300, 307, 308, 309, 310}, ws, ws_bytes);
+        for (auto& c : pc) run_case(c, {300, 307, 312, 308, 315, 309, 313, 310, 314, 300, 307, 312, 308, 315, 309, 313, 310, 314}, ws, ws_bytes);   // 312..315 = the PIPE fragment schedule on 307 / 309 / 310 / 308
         // short prompts: the K-sliced 128x64 ring (force_tile 11, gemm_ring_splitk.hip) vs the automatic choice and the plain ring
         std::vector<Case> sc = {
             {"LLM qkv M=64 cold", 64, 4608, 3584, 0, 0, 0}, {"LLM qkv M=160 cold", 160, 4608, 3584, 0, 0, 0}, {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0},

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1500 -- bash tools/r05_first_call.sh          results under gpurun_out/r05_first/
 # 1. the gated tests (tests/test_gpu_run.py: accumulated update, resumed run, the 3- / 4-stage 128x128 ring, the K-sliced ring) — apart from the suite
 # 2. tools/gemm_bench prering: the new ring variants (force_tile 9 / 10) vs the current choices on the prefill / tower shapes, cold weights
-# 3. TTFT A/B of the dispatch switch VILA_RING_BIG = 0 / 12 / 16 on the default bench line (no SFT, no sustained loop, no CPU leg)
+# 3. TTFT A/B of VILA_RING_PIPE = 1 (the ring kernels' fragment schedule) and of the dispatch switch VILA_RING_BIG = 0 / 12 / 16 on the default bench line (no SFT, no sustained loop, no CPU leg)
 # 3b. VILA_RING_SPLITK = 0 / 1 on the short-prompt lines (gemm_ring_splitk.hip)
 # 4. the suite itself (the round-4 late commits after the last full run: chat template, prepare_tokenizer, stop_token_ids)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -11,6 +11,9 @@ O=$GRAFT_REPO_ROOT/gpurun_out/r05_first; mkdir -p "$O"
 VILA_TEST_UNVERIFIED=1 timeout 600 python -m pytest tests/test_gpu_run.py -m gpu -q -s 2>&1 | tail -40 > "$O/pytest_unverified.log"; tail -5 "$O/pytest_unverified.log"
 [ -x tools/gemm_bench ] || hipcc -O2 -std=c++17 tools/gemm_bench.cpp -o tools/gemm_bench -Iinclude -Lvila_amd/lib -lvila_hip -Wl,-rpath,'$ORIGIN/../vila_amd/lib'
 timeout 300 tools/gemm_bench prering > "$O/gemm_bench_prering.log" 2>&1; tail -72 "$O/gemm_bench_prering.log"
+VILA_RING_PIPE=1 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_pipe.json" 2> "$O/ring_pipe.err"
+python -c "
+import json; d=json.loads(open('$O/ring_pipe.json').read().strip().splitlines()[-1]); print('VILA_RING_PIPE=1: ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_pipe.err"
 for v in 0 12 16; do
   VILA_RING_BIG=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_big_$v.json" 2> "$O/ring_big_$v.err"
   python -c "

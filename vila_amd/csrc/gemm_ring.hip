@@ -14,6 +14,7 @@
 //   involution as gemm.hip / gemm256.hip) is applied on the per-lane SOURCE address and on the fragment reads.
 //   K tail: chunks of the last K-tile beyond K are DMA'd from a zero chunk.  M / N tails: row clamping + masked stores.
 // Epilogues: bias, GELU (tanh / erf), residual, bf16 out.
+#include <stdlib.h>
 #include "kernels.h"
 
 #define RG_BM 128
@@ -28,7 +29,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_ring_zero_chunk[4];   // 
 // tile 64 x 64: 16 ds_read_b128 per 32 MFMAs).  RG_STAGES x stage bytes <= 72 KB keeps two blocks per CU, so a second wave per
 // SIMD overlaps one block's LDS reads with the other's MFMAs:  <NF=2, 3 stages> for grids of about one round (two K-tiles in
 // flight per block), <NF=4, 2 stages> for the mid-size GEMMs of the SFT step's ViT (M = 4096, N, K in 1152..4304).
-template <int EPI, int RG_STAGES, int NF>
+// PIPE (added at the end of round 4 from the ISA alone, OFF by default until measured — VILA_RING_PIPE=1 / vila_gemm_force_tile(12..15)): left to
+// itself the compiler issues the 12 fragment reads of a K-tile in FOUR groups, each followed by `s_waitcnt lgkmcnt(0)` and 4 MFMAs (it schedules
+// for the smallest register footprint: 82 VGPRs where 256 are free at two waves per SIMD), so every K-tile exposes the LDS round trip four times.
+// PIPE reads the ks = 0 operands first, then the ks = 1 operands, and pins "all reads, then the MFMAs" with sched_group_barrier: the counted
+// lgkmcnt waits the compiler inserts then retire the reads progressively and the ks = 1 reads land under the ks = 0 MFMAs.  Scheduling hints only:
+// the arithmetic and its order are unchanged (bit-identical results).
+template <int EPI, int RG_STAGES, int NF, bool PIPE = false>
 __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 72 * 1024) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 32 * NF;
@@ -118,6 +125,15 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
         const char* cA = smem + (t % RG_STAGES) * STAGE_BYTES + wr * 64 * 128;
         const char* cB = smem + (t % RG_STAGES) * STAGE_BYTES + A_BYTES + wc * (16 * NF) * 128;
         bf16x8 af[4][2], bfr[NF][2];
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
@@ -126,12 +142,19 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+        if constexpr (PIPE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);      // DS reads: the ks = 0 operands
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);      // DS reads: the ks = 1 operands
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);      // MFMAs of ks = 0 (the ks = 1 reads land under them)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);      // MFMAs of ks = 1
+        }
     }
     __syncthreads();   // all LDS reads of the last tile done before the ring is reused as staging
 
@@ -180,16 +203,16 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
     }
 }
 
-template <int EPI, int STAGES, int NF>
+template <int EPI, int STAGES, int NF, bool PIPE = false>
 static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = cdiv(a.M, RG_BM), tiles_n = cdiv(a.N, 32 * NF);
     const size_t lds = (size_t)STAGES * (RG_BM + 32 * NF) * RG_BK * 2;    // >= 4 waves x 32 x (16 NF + 4) x 4 B of staging
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, STAGES, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, STAGES, NF, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, STAGES, NF>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, STAGES, NF, PIPE>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m);
     VILA_LAUNCH_CHECK();
     return 0;
 }
@@ -199,12 +222,12 @@ bool gemm_ring_supported(const GemmArgs& a) {
            (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
-template <int STAGES, int NF>
+template <int STAGES, int NF, bool PIPE = false>
 static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
-        case EPI_NONE: return launch_ring_t<EPI_NONE, STAGES, NF>(a, s);
-        case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, STAGES, NF>(a, s);
-        case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, STAGES, NF>(a, s);
+        case EPI_NONE: return launch_ring_t<EPI_NONE, STAGES, NF, PIPE>(a, s);
+        case EPI_GELU_TANH: return launch_ring_t<EPI_GELU_TANH, STAGES, NF, PIPE>(a, s);
+        case EPI_GELU_ERF: return launch_ring_t<EPI_GELU_ERF, STAGES, NF, PIPE>(a, s);
     }
     VILA_FAIL(-1, "gemm_ring: unsupported epilogue %d", a.epi);
 }
@@ -214,7 +237,21 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
 // WITHOUT A GPU at the end of round 4 and are reachable only through vila_gemm_force_tile(9 / 10) / VILA_RING_BIG (off by default): the
 // S = 769 q/k/v/o launches are one round of 504 / 392 128x64 blocks that pull 677 MB through L2 for 39 MB of operands (24 KB per block and
 // K-tile); a 128x128 tile halves that traffic per flop, and what the 2-stage variant lacked at one block per CU was loads in flight.
+// variant + 100 (or VILA_RING_PIPE=1 in the environment) = the same tile with the PIPE fragment schedule.
+static int ring_pipe_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {
+    if (variant >= 100 || ring_pipe_env()) {
+        variant %= 100;
+        if (variant == 16) return launch_ring_epi<4, 4, true>(a, s);
+        if (variant == 12) return launch_ring_epi<3, 4, true>(a, s);
+        if (variant == 8) return launch_ring_epi<2, 4, true>(a, s);
+        if (variant == 4) return launch_ring_epi<4, 2, true>(a, s);
+        return launch_ring_epi<3, 2, true>(a, s);
+    }
     if (variant == 16) return launch_ring_epi<4, 4>(a, s);
     if (variant == 12) return launch_ring_epi<3, 4>(a, s);
     if (variant == 8) return launch_ring_epi<2, 4>(a, s);
