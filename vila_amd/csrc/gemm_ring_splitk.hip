@@ -12,6 +12,7 @@
 //
 // The kernel is the 3-stage 128x64 ring of gemm_ring.hip with (a) its K-tile range [t0, t1) taken from blockIdx.y and (b) an epilogue that
 // stores the raw fp32 accumulators.  Tile / LDS layout, swizzle, counted waits: see gemm_ring.hip.
+#include <stdlib.h>
 #include "kernels.h"
 
 #define RS_BM 128
@@ -24,6 +25,8 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __attribute__((aligned(16))) unsigned int g_rsk_zero_chunk[4];   // K-tail source (zero-initialised)
 
+// PIPE: the fragment schedule of gemm_ring.hip's PIPE variants (all reads of a K-tile ahead of its MFMAs); chosen by VILA_RING_PIPE=1.
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void gemm_ring_splitk_kernel(GemmArgs p, int tiles_m, int per, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = 2;
@@ -111,19 +114,24 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_splitk_kernel(GemmArgs p, in
         const char* cB = smem + ((t - t0) % RS_STAGES) * STAGE_BYTES + A_BYTES + wc * (16 * NF) * 128;
         bf16x8 af[4][2], bfr[NF][2];
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
+            for (int j = 0; j < NF; ++j) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
+            for (int i = 0; i < 4; ++i) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+        if constexpr (PIPE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);
+        }
     }
     __syncthreads();
 
@@ -199,12 +207,15 @@ int launch_gemm_ring_splitk(const GemmArgs& a, int splits, hipStream_t s) {
                  (size_t)splits * a.M * a.N * 4 <= a.ws_bytes, "gemm_ring split-K: %d K tiles / %d slices / workspace %zu B do not fit", kt, splits, a.ws_bytes);
     const int tiles_m = cdiv(a.M, RS_BM), tiles_n = cdiv(a.N, RS_BN);
     const size_t lds = (size_t)RS_STAGES * (RS_BM + RS_BN) * RS_BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static int pipe = -1;
+    if (pipe < 0) {
+        const char* e = getenv("VILA_RING_PIPE");
+        pipe = (e && e[0] == '1') ? 1 : 0;
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(gemm_ring_splitk_kernel, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
+    if (pipe) hipLaunchKernelGGL(gemm_ring_splitk_kernel<true>, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
+    else hipLaunchKernelGGL(gemm_ring_splitk_kernel<false>, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
     VILA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
