@@ -147,3 +147,40 @@ def test_gemm_ring_k_sliced_for_short_prompts(M, N, K):
         lib.vila_gemm_force_tile(0)
     assert rel_l2(out, ref) < 4e-3 and rel_l2(out, plain.float()) < 4e-3, (rel_l2(out, ref), rel_l2(out, plain.float()))
     assert torch.equal(x, out)
+
+
+def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
+    """`stage_x_ge` (gemv_common.h; `vila_gemv_force_gain_early(1)`): the RMSNorm gain arrives by LDS-DMA ahead of x instead of one dependent
+    load per chunk after the reduction.  Same values, same arithmetic: the normalising GEMVs (plain, gate/up), the decode QKV kernel and a whole
+    decode run at NVILA-8B widths must reproduce the plain staging BIT FOR BIT, eager and through a re-captured graph."""
+    from tests.gpu_util import randn_bf16
+    from vila_amd import _lib, ops
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+
+    def gemvs():
+        out = []
+        for N, K in ((3584, 3584), (1000, 512), (64, 1096), (6, 64), (152, 8192)):
+            x, w, w2 = randn_bf16(K, seed=27), randn_bf16(N, K, seed=28, scale=K ** -0.5), randn_bf16(N, K, seed=33, scale=K ** -0.5)
+            g = randn_bf16(K, seed=31, scale=0.1) + 1
+            out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, out_f32=True))
+            out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, w2=w2))
+        return out
+    cfg = configs.reduced_8b(layers_v=2, layers_l=3, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    model = build_model(cfg, seed=11)
+    e = (torch.randn(1, 300, cfg.llm.hidden_size, generator=torch.Generator().manual_seed(11)) * 0.5).to(torch.bfloat16).cuda()
+    runs = {}
+    try:
+        for on in (0, 1):
+            lib.vila_gemv_force_gain_early(on)
+            model.llm._invalidate()
+            ids, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=10, return_logits=True, use_graph=False, eos_token_id=-1)
+            free = model.llm.generate(inputs_embeds=e, max_new_tokens=10, use_graph=True, eos_token_id=-1)
+            runs[on] = (gemvs(), ids, lg, free)
+    finally:
+        lib.vila_gemv_force_gain_early(-1)
+        model.llm._invalidate()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][3], runs[1][3])

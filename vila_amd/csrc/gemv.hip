@@ -101,7 +101,7 @@ __device__ __forceinline__ void wave_rows_dot(const bf16_t* const (&wrow)[R], co
 // ------------------------------------------------------------------------------------------------
 // U = 16-B loads in flight per row and lane: 7 covers a whole K = 3584 row in ONE round trip (the short K=hidden GEMVs are
 // latency-bound), 4 is enough for the long rows (K = 18944) where many iterations pipeline anyway.
-template <int MODE, int U>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials
+template <int MODE, int U, bool GE = false>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials; GE: gemv_common.h stage_x_ge
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     } else if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) {
         stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);   // x comes from the kernel just waited for: sc1 loads
     } else {
-        stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+        if constexpr (GE) stage_x_ge(p.x, p.norm_w, p.eps, p.K, sx, scratch, (bf16_t*)((char*)scratch + 16));   // (the launcher adds K bf16 of LDS)
+        else stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     }
     if (early) {
         float acc[R];
@@ -219,6 +220,15 @@ static inline int balanced_grid(int n_groups, int bpc = 0) {
     return want <= 256 ? want : cdiv(want, 256) * 256;
 }
 
+static int g_gain_early = -1;             // -1 = VILA_GEMV_GAIN_EARLY from the environment (default 0), 0 / 1 = forced (vila_gemv_force_gain_early)
+extern "C" void vila_gemv_force_gain_early(int on) { g_gain_early = on; }
+static int gemv_gain_early() {            // the GE staging for the normalising GEMVs (unmeasured, see gemv_common.h stage_x_ge)
+    if (g_gain_early >= 0) return g_gain_early;
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_GEMV_GAIN_EARLY"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
@@ -230,7 +240,9 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     if (a.mode == 1) {
         VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr && (uintptr_t)a.x % 16 == 0, "gemv: gate/up mode needs W2, bf16 y, aligned x");
         b.chain.done_blocks = (uint32_t)grid;
-        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (gemv_gain_early() && a.norm_w != nullptr && a.K <= 8192 && a.chain.ctr == nullptr)
+            hipLaunchKernelGGL((gemv_kernel<1, 4, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b, n_groups);
+        else hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else if (a.mode == 2) {
         VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
         lds += (size_t)a.n_splits * (a.K / 128) * 4;
@@ -242,7 +254,9 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
         b.chain.done_blocks = (uint32_t)grid;
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (gemv_gain_early() && a.norm_w != nullptr && short_k && a.chain.ctr == nullptr)
+            hipLaunchKernelGGL((gemv_kernel<0, 7, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b, n_groups);
+        else if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
         else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     }
     VILA_LAUNCH_CHECK();
@@ -255,7 +269,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
 // Group = 2 rows per wave: q/k heads -> the rotate-half pair {d, d+hd/2} of one head, v heads -> 2 consecutive rows.  cos/sin of the token's position come from the per-token table written by
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
-template <int U>
+template <int U, bool GE = false>
 __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); epi_fetch(g); }
     chain_wait(p.chain);
     if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+    else if constexpr (GE) stage_x_ge(p.x, p.norm_w, p.eps, p.K, sx, scratch, (bf16_t*)((char*)scratch + 16));
     else stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
         float acc[2] = {0.f, 0.f};
@@ -341,7 +356,9 @@ int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out) {
     const int grid = balanced_grid(n_groups, a.max_bpc);
     QkvDecodeArgs b = a;
     b.chain.done_blocks = (uint32_t)grid;
-    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
+    if (a.K <= 3584 && gemv_gain_early() && a.norm_w != nullptr && a.chain.ctr == nullptr)
+        hipLaunchKernelGGL((qkv_decode_kernel<7, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b);
+    else if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
     else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(grid), dim3(256), lds, s, b);
     VILA_LAUNCH_CHECK();
     if (grid_out != nullptr) *grid_out = grid;
