@@ -38,6 +38,10 @@ void vila_gemm_force_fuse_norm(int on);
  * chunk after the reduction (gemv_common.h stage_x_ge; added unmeasured at the end of round 4): -1 = VILA_GEMV_GAIN_EARLY from the environment
  * (default 0), 0 = off, 1 = on.  A captured decode graph keeps the kernels it was captured with. */
 void vila_gemv_force_gain_early(int on);
+/* decode o_proj GEMV with the split-KV attention merge in its prologue: request every slice's statistics / partial outputs up front instead of one
+ * dependent load per slice (gemv.hip stage_x_attn_batched; added unmeasured at the end of round 4): -1 = VILA_GEMV_MERGE_BATCH from the
+ * environment (default 0), 0 = off, 1 = on */
+void vila_gemv_force_merge_batch(int on);
 #ifdef __cplusplus
 }
 #endif

@@ -152,7 +152,9 @@ def test_gemm_ring_k_sliced_for_short_prompts(M, N, K):
 def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
     """`stage_x_ge` (gemv_common.h; `vila_gemv_force_gain_early(1)`): the RMSNorm gain arrives by LDS-DMA ahead of x instead of one dependent
     load per chunk after the reduction.  Same values, same arithmetic: the normalising GEMVs (plain, gate/up), the decode QKV kernel and a whole
-    decode run at NVILA-8B widths must reproduce the plain staging BIT FOR BIT, eager and through a re-captured graph."""
+    decode run at NVILA-8B widths must reproduce the plain staging BIT FOR BIT, eager and through a re-captured graph.  The same run flips
+    `vila_gemv_force_merge_batch`: the split-KV attention merge in the o_proj GEMV's prologue with every slice's loads requested up front (two
+    active 256-key slices at the 300-token prompt used here; same combine order)."""
     from tests.gpu_util import randn_bf16
     from vila_amd import _lib, ops
     from vila_amd.vlm import build_model
@@ -174,12 +176,14 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
     try:
         for on in (0, 1):
             lib.vila_gemv_force_gain_early(on)
+            lib.vila_gemv_force_merge_batch(on)                  # the o_proj GEMV's attention merge with its loads batched (stage_x_attn_batched)
             model.llm._invalidate()
             ids, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=10, return_logits=True, use_graph=False, eos_token_id=-1)
             free = model.llm.generate(inputs_embeds=e, max_new_tokens=10, use_graph=True, eos_token_id=-1)
             runs[on] = (gemvs(), ids, lg, free)
     finally:
         lib.vila_gemv_force_gain_early(-1)
+        lib.vila_gemv_force_merge_batch(-1)
         model.llm._invalidate()
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)

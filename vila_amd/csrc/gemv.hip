@@ -59,6 +59,60 @@ __device__ __forceinline__ void stage_x_attn(const float* __restrict__ part_o, c
     __syncthreads();
 }
 
+// The same merge with its loads BATCHED ("MB": added at the end of round 4 from the ISA alone, OFF by default until measured —
+// VILA_GEMV_MERGE_BATCH=1 / vila_gemv_force_merge_batch).  stage_x_attn's `for s` loops have a run-time trip count, so the compiler emits one
+// `global_load -> s_waitcnt vmcnt(0)` per iteration: with 4 active 256-key slices that is ~8 dependent round trips for the statistics and
+// 3.5 x 4 = 14 for the partial outputs, in front of an o_proj that streams its 25.7 MB in 3.7 us (the kernel takes 9.8 us).  Here every slice's
+// word is requested up front (slots past n_active re-read slot 0 and are not used): one round trip for the statistics, one per 256-chunk pass
+// for the outputs.  Same values combined in the same order (max, sum over s = 0.., fmaf over s = 0..): bit-identical results.
+// For up to MERGE_MAXS slices (256-key slices of a cache of <= 2048 positions); the caller falls back to stage_x_attn beyond that.
+#define MERGE_MAXS 8
+__device__ __forceinline__ void stage_x_attn_batched(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active,
+                                                     int nq, bf16_t* sx, float* wsm /* [n_active*nq] */) {
+    typedef __attribute__((ext_vector_type(2))) float mb_f32x2;
+    const int tid = threadIdx.x;
+    for (int h = tid; h < nq; h += 256) {
+        float m[MERGE_MAXS], l[MERGE_MAXS];
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) {
+            const int ss = s < n_active ? s : 0;
+            const mb_f32x2 ml = *(const mb_f32x2*)(part_ml + ((int64_t)ss * nq + h) * 2);
+            m[s] = ml[0]; l[s] = ml[1];
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) M = fmaxf(M, m[s]);
+        float L = 0.f;
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) L += __expf(m[s] - M) * l[s];
+        const float invL = 1.f / L;
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) wsm[s * nq + h] = __expf(m[s] - M) * invL;
+    }
+    __syncthreads();
+    const int n4 = nq * 32;   // float4 chunks
+    for (int i = tid; i < n4; i += 256) {
+        const int h = i >> 5;
+        f32x4 pv[MERGE_MAXS];
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) {
+            const int ss = s < n_active ? s : 0;
+            pv[s] = *(const f32x4*)(part_o + ((int64_t)ss * nq) * 128 + i * 4);
+        }
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < MERGE_MAXS; ++s) {
+            if (s < n_active) {
+                const float w = wsm[s * nq + h];
+                o[0] = fmaf(w, pv[s][0], o[0]); o[1] = fmaf(w, pv[s][1], o[1]); o[2] = fmaf(w, pv[s][2], o[2]); o[3] = fmaf(w, pv[s][3], o[3]);
+            }
+        }
+        u32x2 r; r[0] = pack2bf(o[0], o[1]); r[1] = pack2bf(o[2], o[3]);
+        *(u32x2*)(sx + i * 4) = r;
+    }
+    __syncthreads();
+}
+
 // ---- weight streaming -----------------------------------------------------------------------------
 template <int R, int U> struct Batch { u32x4 v[U][R]; };
 
@@ -175,7 +229,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     if constexpr (MODE == 2) {
         const int ks = p.split_keys > 0 ? p.split_keys : DEC_KS;
         const int n_active = (*p.pos_ptr + ks) / ks;             // ceil((pos+1)/ks)
-        stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+        if constexpr (GE) {                                       // (MODE 2: GE = the batched merge)
+            if (n_active <= MERGE_MAXS) stage_x_attn_batched(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+            else stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+        } else {
+            stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
+        }
     } else if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) {
         stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);   // x comes from the kernel just waited for: sc1 loads
     } else {
@@ -229,6 +288,15 @@ static int gemv_gain_early() {            // the GE staging for the normalising 
     return v;
 }
 
+static int g_merge_batch = -1;            // -1 = VILA_GEMV_MERGE_BATCH from the environment (default 0), 0 / 1 = forced
+extern "C" void vila_gemv_force_merge_batch(int on) { g_merge_batch = on; }
+static int gemv_merge_batch() {           // the batched attention merge in the o_proj GEMV's prologue (unmeasured, see stage_x_attn_batched)
+    if (g_merge_batch >= 0) return g_merge_batch;
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_GEMV_MERGE_BATCH"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
@@ -249,7 +317,8 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
         const int cap = a.grid_cap > 0 ? a.grid_cap : 256;           // the merge prologue is paid per block: default ~1 block per CU
         if (grid > cap) grid = cap;
         b.chain.done_blocks = (uint32_t)grid;
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (short_k && gemv_merge_batch() && a.chain.ctr == nullptr) hipLaunchKernelGGL((gemv_kernel<2, 7, true>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        else if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
         else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
