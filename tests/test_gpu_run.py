@@ -188,3 +188,30 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][3], runs[1][3])
+
+
+@pytest.mark.parametrize("n_prompt", [16, 560])
+def test_w4_o_proj_batched_merge_equals_the_plain_merge_bit_for_bit(n_prompt):
+    """`gemv_w4_kernel<5>` (`vila_gemv_force_merge_batch(1)`): the W4 o_proj kernel's attention merge with every slice's loads requested up
+    front, at two and four active 256-key slices, against MODE 4 on the same W4 model: identical logits, eager and replayed."""
+    from tests.test_gpu_w4 import _w4_model
+    from vila_amd import _lib
+    cfg = configs.reduced_8b(layers_v=2, layers_l=2, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    _, model = _w4_model(cfg, 5, (-9, -8, -7))
+    px = synthetic.make_pixels(cfg, 1, 5).to(torch.bfloat16)
+    ids = synthetic.make_prompt(cfg, n_prompt, 1, 5)[None]
+    e, _, _ = model._embed(ids, {"image": [px[0].cuda()]})
+    lib = _lib.load()
+    runs = {}
+    try:
+        for on in (0, 1):
+            lib.vila_gemv_force_merge_batch(on)
+            model.llm._drop_decode_session()
+            _, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=6, return_logits=True, use_graph=False, eos_token_id=-1)
+            free = model.llm.generate(inputs_embeds=e, max_new_tokens=6, use_graph=True, eos_token_id=-1)
+            runs[on] = (lg, free)
+    finally:
+        lib.vila_gemv_force_merge_batch(-1)
+        model.llm._drop_decode_session()
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])

@@ -297,6 +297,8 @@ static int gemv_merge_batch() {           // the batched attention merge in the 
     return v;
 }
 
+int gemv_merge_batch_enabled() { return gemv_merge_batch(); }      // for gemv_w4.hip (the W4 o_proj kernel's MODE 5)
+
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");

@@ -22,6 +22,9 @@
 
 #define W4_MAX_WAVES 16
 
+int gemv_merge_batch_enabled();            // gemv.hip: VILA_GEMV_MERGE_BATCH / vila_gemv_force_merge_batch
+static int w4_merge_batch() { return gemv_merge_batch_enabled(); }
+
 // stage x (optionally RMS-normalised, HF rounding order) as bf16 into LDS + the per-group sums of the staged values; any blockDim
 // that is a multiple of 64.  Chunk c = 8 consecutive elements; 16 consecutive chunks (= 16 consecutive lanes) form a group.
 __device__ __forceinline__ void stage_x_w4(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, float eps, int K,
@@ -137,7 +140,65 @@ __device__ __forceinline__ void stage_x_attn_w4(const float* __restrict__ part_o
     __syncthreads();
 }
 
-// MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
+// stage_x_attn_w4 with its loads BATCHED (gemv.hip stage_x_attn_batched has the story: the run-time `for s` loops compile to one dependent
+// round trip per slice and pass).  Added unmeasured at the end of round 4; MODE 5 of the kernel, chosen by VILA_GEMV_MERGE_BATCH=1 /
+// vila_gemv_force_merge_batch(1).  Same values, same combine order: bit-identical.  Up to W4_MERGE_MAXS slices, else the plain function.
+#define W4_MERGE_MAXS 8
+__device__ __forceinline__ void stage_x_attn_w4_batched(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active, int nq,
+                                                        bf16_t* sx, float* xg, float* wsm /* [n_active * nq] */) {
+    typedef __attribute__((ext_vector_type(2))) float mb_f32x2;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int h = tid; h < nq; h += nt) {
+        float m[W4_MERGE_MAXS], l[W4_MERGE_MAXS];
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
+            const int ss = s < n_active ? s : 0;
+            const mb_f32x2 ml = *(const mb_f32x2*)(part_ml + ((int64_t)ss * nq + h) * 2);
+            m[s] = ml[0]; l[s] = ml[1];
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) M = fmaxf(M, m[s]);
+        float L = 0.f;
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) L += __expf(m[s] - M) * l[s];
+        const float invL = 1.f / L;
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) wsm[s * nq + h] = __expf(m[s] - M) * invL;
+    }
+    __syncthreads();
+    const int nch = nq * 16;
+    for (int c = tid; c < nch; c += nt) {
+        const int h = c >> 4;
+        f32x4 p0[W4_MERGE_MAXS], p1[W4_MERGE_MAXS];
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
+            const int ss = s < n_active ? s : 0;
+            const float* src = part_o + ((int64_t)ss * nq) * 128 + c * 8;
+            p0[s] = *(const f32x4*)src; p1[s] = *(const f32x4*)(src + 4);
+        }
+        float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
+            if (s < n_active) {
+                const float w = wsm[s * nq + h];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[k] = fmaf(w, p0[s][k], e[k]); e[4 + k] = fmaf(w, p1[s][k], e[4 + k]); }
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = pack2bf(e[2 * k], e[2 * k + 1]); e[2 * k] = lo_bf(o[k]); e[2 * k + 1] = hi_bf(o[k]); }
+        *(u32x4*)(sx + c * 8) = o;
+        float a = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
+        if ((c & 15) == 0) xg[h] = a;
+    }
+    __syncthreads();
+}
+
+// MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials (5: with the batched merge) ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
 // (q/k rows interleaved so RoPE partners i, i + hd/2 are neighbours).  UB = groups (KB) per wave and item; PIPE = the next
 // item's weights are issued before the current item is consumed (persistent blocks walking several tiles).
 template <int MODE, int UB, bool PIPE>
@@ -173,7 +234,7 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     auto epi_fetch = [&](int tile_) {
         if (tid >= 16) return;
         const int pr = tile_ * 16 + tid;
-        if (MODE == 0 || MODE == 4) {
+        if (MODE == 0 || MODE == 4 || MODE == 5) {
             if (pr < p.N) {
                 e0 = p.bias != nullptr ? bf2f(p.bias[pr]) : 0.f;
                 e1 = p.residual != nullptr ? bf2f(p.residual[pr]) : 0.f;
@@ -201,6 +262,10 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     if constexpr (MODE == 4) {
         const int n_active = (*p.pos_ptr + p.split_keys) / p.split_keys;     // ceil((pos + 1) / split_keys)
         stage_x_attn_w4(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
+    } else if constexpr (MODE == 5) {
+        const int n_active = (*p.pos_ptr + p.split_keys) / p.split_keys;
+        if (n_active <= W4_MERGE_MAXS) stage_x_attn_w4_batched(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
+        else stage_x_attn_w4(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
     } else {
         stage_x_w4(p.x, p.norm_w, p.eps, K, sx, xg, scratch);
     }
@@ -238,7 +303,7 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
                 float v = 0.f, vp = 0.f;                        // own row and the partner row (n ^ 1)
                 for (int i = 0; i < W; ++i) { v += rd[i * 16 + tid]; vp += rd[i * 16 + (tid ^ 1)]; }
                 const int pr = tile * 16 + tid;                 // packed row
-                if (MODE == 0 || MODE == 4) {
+                if (MODE == 0 || MODE == 4 || MODE == 5) {
                     if (pr < p.N) {
                         v += e0;
                         if (p.residual != nullptr) v = bfround(v) + e1;
@@ -319,6 +384,7 @@ int launch_gemv_w4(const GemvW4Args& a, hipStream_t s) {
 #define W4_LAUNCH(MODE, UB_, PIPE_) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles)
     if (a.mode == 1) { if (pipe) W4_LAUNCH(1, 7, true); else W4_LAUNCH(1, 7, false); }
     else if (a.mode == 3) W4_LAUNCH(3, 7, false);
+    else if (a.mode == 4 && w4_merge_batch()) { if (pipe) W4_LAUNCH(5, 7, true); else W4_LAUNCH(5, 7, false); }
     else if (a.mode == 4) { if (pipe) W4_LAUNCH(4, 7, true); else W4_LAUNCH(4, 7, false); }
     else if (deep) W4_LAUNCH(0, 10, false);
     else if (pipe) W4_LAUNCH(0, 7, true);
