@@ -42,6 +42,11 @@ void vila_gemv_force_gain_early(int on);
  * dependent load per slice (gemv.hip stage_x_attn_batched; added unmeasured at the end of round 4): -1 = VILA_GEMV_MERGE_BATCH from the
  * environment (default 0), 0 = off, 1 = on */
 void vila_gemv_force_merge_batch(int on);
+/* decode attention over 256-key slices: request the wave's first K / V chunk before q is staged (gemv.hip attn_decode_head_ek; added unmeasured
+ * at the end of round 4): -1 = VILA_DECODE_ATTN_EARLY_KV from the environment (default 0), 0 = off, 1 = on.
+ * VILA_DECODE_LAT=1 in the environment switches all three decode-latency variants (gain early, merge batch, early K/V) on at once; the
+ * individual variables and these hooks win over it. */
+void vila_decode_force_early_kv(int on);
 #ifdef __cplusplus
 }
 #endif

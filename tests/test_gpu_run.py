@@ -177,6 +177,7 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
         for on in (0, 1):
             lib.vila_gemv_force_gain_early(on)
             lib.vila_gemv_force_merge_batch(on)                  # the o_proj GEMV's attention merge with its loads batched (stage_x_attn_batched)
+            lib.vila_decode_force_early_kv(on)                   # the decode attention's first K / V chunk requested ahead of q (attn_decode_head_ek)
             model.llm._invalidate()
             ids, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=10, return_logits=True, use_graph=False, eos_token_id=-1)
             free = model.llm.generate(inputs_embeds=e, max_new_tokens=10, use_graph=True, eos_token_id=-1)
@@ -184,6 +185,7 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
     finally:
         lib.vila_gemv_force_gain_early(-1)
         lib.vila_gemv_force_merge_batch(-1)
+        lib.vila_decode_force_early_kv(-1)
         model.llm._invalidate()
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)

@@ -23,6 +23,11 @@ for v in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do
 import json; d=json.loads(open('$O/decode_ge$1_mb$2.json').read().strip().splitlines()[-1]); print('GAIN_EARLY=$1 MERGE_BATCH=$2: decode', d['value'], 'tok/s  ms/step', d['ms_per_step'], ' dominant-kernel frac', d['roofline']['frac'])" || tail -3 "$O/decode_ge$1_mb$2.err"
 done
 for v in 0 1 0 1; do
+  VILA_DECODE_LAT=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/decode_lat$v.json" 2> "$O/decode_lat$v.err"
+  python -c "
+import json; d=json.loads(open('$O/decode_lat$v.json').read().strip().splitlines()[-1]); print('VILA_DECODE_LAT=$v (gain early + merge batch + early K/V): decode', d['value'], 'tok/s  ms/step', d['ms_per_step'], ' dominant-kernel frac', d['roofline']['frac'])" || tail -3 "$O/decode_lat$v.err"
+done
+for v in 0 1 0 1; do
   VILA_GEMV_MERGE_BATCH=$v timeout 300 python bench.py --w4 --no-sft --no-sustain --no-cpu-baseline > "$O/w4_mb$v.json" 2> "$O/w4_mb$v.err"
   python -c "
 import json; d=json.loads(open('$O/w4_mb$v.json').read().strip().splitlines()[-1]); print('W4 decode, MERGE_BATCH=$v:', d['value'], 'tok/s  ms/step', d['ms_per_step'])" || tail -3 "$O/w4_mb$v.err"

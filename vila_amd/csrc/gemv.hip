@@ -279,12 +279,28 @@ static inline int balanced_grid(int n_groups, int bpc = 0) {
     return want <= 256 ? want : cdiv(want, 256) * 256;
 }
 
+// VILA_DECODE_LAT=1: master switch for the decode-latency variants written at the end of round 4 (stage_x_ge, stage_x_attn_batched,
+// attn_decode_head<.., EK>); each also has its own variable / force hook, which wins over the master.
+static int decode_lat_switch(const char* name) {
+    const char* e = getenv(name);
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] - '0';
+    const char* m = getenv("VILA_DECODE_LAT");
+    return (m && m[0] == '1') ? 1 : 0;
+}
+static int g_attn_early_kv = -1;
+extern "C" void vila_decode_force_early_kv(int on) { g_attn_early_kv = on; }
+static int attn_early_kv() {
+    if (g_attn_early_kv >= 0) return g_attn_early_kv;
+    static int v = -1;
+    if (v < 0) v = decode_lat_switch("VILA_DECODE_ATTN_EARLY_KV");
+    return v;
+}
 static int g_gain_early = -1;             // -1 = VILA_GEMV_GAIN_EARLY from the environment (default 0), 0 / 1 = forced (vila_gemv_force_gain_early)
 extern "C" void vila_gemv_force_gain_early(int on) { g_gain_early = on; }
 static int gemv_gain_early() {            // the GE staging for the normalising GEMVs (unmeasured, see gemv_common.h stage_x_ge)
     if (g_gain_early >= 0) return g_gain_early;
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_GEMV_GAIN_EARLY"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) v = decode_lat_switch("VILA_GEMV_GAIN_EARLY");
     return v;
 }
 
@@ -293,7 +309,7 @@ extern "C" void vila_gemv_force_merge_batch(int on) { g_merge_batch = on; }
 static int gemv_merge_batch() {           // the batched attention merge in the o_proj GEMV's prologue (unmeasured, see stage_x_attn_batched)
     if (g_merge_batch >= 0) return g_merge_batch;
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_GEMV_MERGE_BATCH"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) v = decode_lat_switch("VILA_GEMV_MERGE_BATCH");
     return v;
 }
 
@@ -665,6 +681,119 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     }
 }
 
+// attn_decode_head<true> with EARLY KEYS ("EK", added at the end of round 4 from the ISA alone, OFF by default until measured —
+// VILA_DECODE_ATTN_EARLY_KV=1 or the master switch VILA_DECODE_LAT=1): the kernel's start is three dependent round trips — the position, then
+// q (load -> wait -> LDS -> barrier), then the wave's first K / V chunk.  q and the chunk do not depend on each other: here the chunk is
+// requested BEFORE q is staged, so the two travel together.  Same loads, same arithmetic: bit-identical results.  A copy of the kernel, not a
+// template flag: re-ordering the declarations inside the shared body changed the DEFAULT instantiations' code (checked in the ISA).
+__global__ __launch_bounds__(1024) void attn_decode_head_ek(AttnDecodeArgs p) {
+    constexpr bool SPLIT = true;
+    __shared__ float sq[128];
+    __shared__ float so[16][128];
+    __shared__ float sml[16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, kvh = h / (p.nq / p.nkv);
+    const int key_lo = SPLIT ? blockIdx.y * 256 : 0;
+    const int row = blockIdx.z;                                  // batched decode: sequence = cache slot (0 for the batch-1 step)
+    p.q += row * p.q_row_stride; p.kcache += row * p.slot_stride; p.vcache += row * p.slot_stride;
+    if (!SPLIT) p.o += row * p.o_row_stride;
+    const int nkeys_all = p.pos_ptr[row] + 1;
+    if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
+    const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
+    const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
+    const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
+    const int kq = lane >> 2, qd = lane & 3;        // scores: key within the chunk, d quarter
+    const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup, d chunk
+    u32x4 kc[4], vc[4], kn_[4], vn_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
+    auto load_chunk = [&](int k0, u32x4 (&kk)[4], u32x4 (&vv)[4]) {
+        const int key = k0 + kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kk[j] = (key < nkeys) ? *(const u32x4*)(kb + (int64_t)key * 128 + qd * 32 + j * 8) : (u32x4){0u, 0u, 0u, 0u};
+            const int vk = k0 + sg * 4 + j;
+            vv[j] = (vk < nkeys) ? *(const u32x4*)(vb + (int64_t)vk * 128 + dc * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    int k0 = key_lo + wave * 16;
+    if (k0 < nkeys) load_chunk(k0, kc, vc);           // EK: the wave's first K / V chunk is requested BEFORE q is staged
+    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
+    __syncthreads();
+    float qr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+
+    for (; k0 < nkeys; k0 += 256) {
+        const int kn = k0 + 256;
+        if (kn < nkeys) load_chunk(kn, kn_, vn_);            // prefetch the wave's next chunk under this chunk's math
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a = fmaf(lo_bf(kc[j][e]), qr[j * 8 + 2 * e], a);
+                a = fmaf(hi_bf(kc[j][e]), qr[j * 8 + 2 * e + 1], a);
+            }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        const float s = (k0 + kq < nkeys) ? a : -INFINITY;
+        float cm = s;
+        cm = fmaxf(cm, __shfl_xor(cm, 4, 64)); cm = fmaxf(cm, __shfl_xor(cm, 8, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float m_new = fmaxf(m, cm);
+        const float alpha = __expf(m - m_new);
+        const float pr = __expf(s - m_new);
+        float ps = pr;
+        ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pj = __shfl(pr, (sg * 4 + j) * 4, 64);   // probability of key k0 + sg*4 + j (held by lanes 4*key .. 4*key+3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] = fmaf(pj, lo_bf(vc[j][e]), o[2 * e]);
+                o[2 * e + 1] = fmaf(pj, hi_bf(vc[j][e]), o[2 * e + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kc[j] = kn_[j]; vc[j] = vn_[j]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) so[wave][dc * 8 + e] = o[e];
+    }
+    if (lane == 0) { sml[wave][0] = m; sml[wave][1] = l; }
+    __syncthreads();
+    if (tid < 128) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) M = fmaxf(M, sml[w][0]);
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float wgt = __expf(sml[w][0] - M);
+            L += wgt * sml[w][1];
+            acc += wgt * so[w][tid];
+        }
+        if (SPLIT) {
+            const int64_t slot = (int64_t)blockIdx.y * p.nq + h;
+            p.part_o[slot * 128 + tid] = acc;
+            if (tid == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
+        } else {
+            p.o[h * 128 + tid] = f2bf(acc / L);
+        }
+    }
+}
+
 // batched decode: one block per (query head, sequence) over the sequence's whole context (caches up to 2048 positions)
 int launch_attn_decode_rows(const AttnDecodeArgs& a0, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s) {
     AttnDecodeArgs a = a0;
@@ -682,7 +811,8 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
     if (a.split256) {                                            // partials per 256-key slice; merged by the o_proj GEMV (mode 2, split_keys 256)
         VILA_REQUIRE(a.max_ctx <= 2048 && a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: 256-key slices need max_ctx <= 2048");
-        hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
+        if (attn_early_kv()) hipLaunchKernelGGL(attn_decode_head_ek, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
         if (grid_out != nullptr) *grid_out = a.nq * cdiv(a.max_ctx, 256);
         return 0;
