@@ -47,6 +47,9 @@ void vila_gemv_force_merge_batch(int on);
  * VILA_DECODE_LAT=1 in the environment switches all three decode-latency variants (gain early, merge batch, early K/V) on at once; the
  * individual variables and these hooks win over it. */
 void vila_decode_force_early_kv(int on);
+/* the long no-norm GEMV (down_proj): x requested first, the first weight batch behind it (gemv.hip gemv_xfirst_kernel; added unmeasured at the end
+ * of round 4; also under VILA_DECODE_LAT): -1 = VILA_GEMV_X_FIRST from the environment (default 0), 0 = off, 1 = on */
+void vila_gemv_force_x_first(int on);
 #ifdef __cplusplus
 }
 #endif

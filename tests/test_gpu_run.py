@@ -167,6 +167,10 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
             g = randn_bf16(K, seed=31, scale=0.1) + 1
             out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, out_f32=True))
             out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, w2=w2))
+        for N, K in ((3584, 18944), (70, 18944), (6, 4104)):                       # long rows without a norm: gemv_xfirst_kernel when switched on
+            x, w = randn_bf16(K, seed=41), randn_bf16(N, K, seed=42, scale=K ** -0.5)
+            out.append(ops.gemv(x, w, bias=randn_bf16(N, seed=43), residual=randn_bf16(N, seed=44)))
+            out.append(ops.gemv(x, w, out_f32=True))
         return out
     cfg = configs.reduced_8b(layers_v=2, layers_l=3, vocab=32000)
     cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
@@ -178,6 +182,7 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
             lib.vila_gemv_force_gain_early(on)
             lib.vila_gemv_force_merge_batch(on)                  # the o_proj GEMV's attention merge with its loads batched (stage_x_attn_batched)
             lib.vila_decode_force_early_kv(on)                   # the decode attention's first K / V chunk requested ahead of q (attn_decode_head_ek)
+            lib.vila_gemv_force_x_first(on)                      # down_proj: x requested first, the first weight batch behind it (gemv_xfirst_kernel)
             model.llm._invalidate()
             ids, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=10, return_logits=True, use_graph=False, eos_token_id=-1)
             free = model.llm.generate(inputs_embeds=e, max_new_tokens=10, use_graph=True, eos_token_id=-1)
@@ -186,6 +191,7 @@ def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
         lib.vila_gemv_force_gain_early(-1)
         lib.vila_gemv_force_merge_batch(-1)
         lib.vila_decode_force_early_kv(-1)
+        lib.vila_gemv_force_x_first(-1)
         model.llm._invalidate()
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)

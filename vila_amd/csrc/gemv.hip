@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     // stores both as ONE write-through 4-byte word (gemv_common.h store_bf16_pair).
     const bool coh_out = p.chain.ctr != nullptr && p.chain.done_idx >= 0;
     float e_bias = 0.f, e_res = 0.f;
+    // GE variants keep the epilogue's operands AS LOADED and convert them in `finish`: converting at the request makes the compiler wait for them
+    // there — and, loads retiring in order, for the whole weight prefetch issued in front of them — before the staging loads can even be issued
+    bf16_t eb_raw = 0, er_raw = 0;
     auto finish = [&](int gg, float (&acc)[R]) {
         const int n = gg * 2;
         bf16_t o = 0;
@@ -190,6 +193,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             o = f2bf(bfround(silu_f(gv)) * uv);
         } else {
             float v = lane == 0 ? acc[0] : acc[1];
+            if constexpr (GE) {        // (the empty asm pins the conversion HERE: left free, the compiler folds it back into the request)
+                uint32_t bb = eb_raw, rb = er_raw;
+                asm volatile("" : "+v"(bb), "+v"(rb));
+                e_bias = bf2f((bf16_t)bb); e_res = bf2f((bf16_t)rb);
+            }
             v += e_bias;
             if (lane < 2 && n + lane < p.N && p.y_f32 != nullptr) p.y_f32[n + lane] = v;
             if (p.residual != nullptr) v = bfround(v) + e_res;
@@ -208,10 +216,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     auto epi_fetch = [&](int gg) {
         if constexpr (MODE != 1) {
             const int nn = gg * 2 + lane;
+            if constexpr (GE) {
+                eb_raw = 0; er_raw = 0;
+                if (lane < 2 && nn < p.N) {
+                    if (p.bias != nullptr) eb_raw = p.bias[nn];
+                    if (p.residual != nullptr && p.y != nullptr) er_raw = p.residual[nn];
+                }
+            } else {
             e_bias = 0.f; e_res = 0.f;
             if (lane < 2 && nn < p.N) {
                 if (p.bias != nullptr) e_bias = bf2f(p.bias[nn]);
                 if (p.residual != nullptr && p.y != nullptr) e_res = bf2f(p.residual[nn]);
+            }
             }
         }
     };
@@ -262,6 +278,85 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     chain_done(p.chain);
 }
 
+// The long-row GEMV (down_proj: K = 18944, no norm) with x REQUESTED FIRST ("XF", added at the end of round 4 from the ISA alone, OFF by
+// default until measured — VILA_GEMV_X_FIRST=1 or the master switch VILA_DECODE_LAT=1).  gemv_kernel stages such an x in three passes of
+// `4 loads -> wait -> 4 LDS writes` and only then starts its weight stream (queuing the weight prefetch IN FRONT of the staging measured 13 %
+// slower: loads retire in order, so every staging wait then also waits for the weights).  Here all of a thread's x chunks (<= XF_MAXC = 10)
+// are requested at once, the first weight batch is requested BEHIND them, and the wait for x leaves the weights in flight: one round trip
+// for x instead of three, with the HBM latency of the first weights under it.  MODE 0, R = 2, U = 4, no norm, no chain; same loads, same
+// accumulation order as gemv_kernel<0, 4>: bit-identical results.
+#define XF_MAXC 10
+__global__ __launch_bounds__(256) void gemv_xfirst_kernel(GemvArgs p, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sx = (bf16_t*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = p.K >> 3;
+    constexpr int R = 2, U = 4;
+    const int stride = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wave;
+    u32x4 xr[XF_MAXC];
+#pragma unroll
+    for (int i = 0; i < XF_MAXC; ++i) {
+        const int c = tid + 256 * i;
+        xr[i] = (c < nch) ? *(const u32x4*)(p.x + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    const bf16_t* rows[R];
+    auto rows_of = [&](int gg) {
+        const int n = gg * 2;
+        const int n1 = (n + 1 < p.N) ? n + 1 : n;
+        rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
+    };
+    bf16_t eb_raw = 0, er_raw = 0;            // as loaded; converted in `finish` (see gemv_kernel: a conversion here would drain the prefetch)
+    auto epi_fetch = [&](int gg) {
+        const int nn = gg * 2 + lane;
+        eb_raw = 0; er_raw = 0;
+        if (lane < 2 && nn < p.N) {
+            if (p.bias != nullptr) eb_raw = p.bias[nn];
+            if (p.residual != nullptr && p.y != nullptr) er_raw = p.residual[nn];
+        }
+    };
+    auto finish = [&](int gg, float (&acc)[R]) {
+        const int n = gg * 2;
+        uint32_t bb = eb_raw, rb = er_raw;
+        asm volatile("" : "+v"(bb), "+v"(rb));        // pins the conversion here: left free, the compiler folds it back into the request
+        const float e_bias = bf2f((bf16_t)bb), e_res = bf2f((bf16_t)rb);
+        float v = lane == 0 ? acc[0] : acc[1];
+        v += e_bias;
+        if (lane < 2 && n + lane < p.N && p.y_f32 != nullptr) p.y_f32[n + lane] = v;
+        if (p.residual != nullptr) v = bfround(v) + e_res;
+        const bf16_t o = f2bf(v);
+        if (p.y == nullptr) return;
+        if (lane < 2 && n + lane < p.N) p.y[n + lane] = o;
+    };
+    Batch<R, U> b0;
+    const bool has = g < n_groups;
+    // UNCONDITIONAL (a wave without a group fetches the last group's rows and drops them): behind a branch the compiler cannot count the loads
+    // issued after x and falls back to vmcnt(0) for the LDS writes below, i.e. waits for the weights as well
+    rows_of(has ? g : n_groups - 1);
+    load_batch<R, U>(rows, 0, lane, nch, b0);
+    if (has) epi_fetch(g);
+#pragma unroll
+    for (int i = 0; i < XF_MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) *(u32x4*)(sx + c * 8) = xr[i];
+    }
+    __syncthreads();
+    if (has) {
+        float acc[R] = {0.f, 0.f};
+        fma_batch<R, U>(b0, sx, 0, lane, nch, acc);
+        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 64 * U);
+        finish(g, acc);
+        g += stride;
+    }
+    for (; g < n_groups; g += stride) {
+        rows_of(g);
+        epi_fetch(g);
+        float acc[R] = {0.f, 0.f};
+        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 0);
+        finish(g, acc);
+    }
+}
+
 // Grid sizing for the HBM-bound GEMVs: a multiple of the 256 CUs (the dispatcher deals blocks round-robin, so 448 blocks
 // would leave 64 CUs with half the work of the others) and at most 4 blocks (16 waves) per CU = everything resident at once;
 // waves then walk the row groups with a grid stride.
@@ -293,6 +388,14 @@ static int attn_early_kv() {
     if (g_attn_early_kv >= 0) return g_attn_early_kv;
     static int v = -1;
     if (v < 0) v = decode_lat_switch("VILA_DECODE_ATTN_EARLY_KV");
+    return v;
+}
+static int g_x_first = -1;
+extern "C" void vila_gemv_force_x_first(int on) { g_x_first = on; }
+static int gemv_x_first() {               // gemv_xfirst_kernel for the long no-norm rows (unmeasured)
+    if (g_x_first >= 0) return g_x_first;
+    static int v = -1;
+    if (v < 0) v = decode_lat_switch("VILA_GEMV_X_FIRST");
     return v;
 }
 static int g_gain_early = -1;             // -1 = VILA_GEMV_GAIN_EARLY from the environment (default 0), 0 / 1 = forced (vila_gemv_force_gain_early)
@@ -344,6 +447,8 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
         if (gemv_gain_early() && a.norm_w != nullptr && short_k && a.chain.ctr == nullptr)
             hipLaunchKernelGGL((gemv_kernel<0, 7, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b, n_groups);
         else if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        else if (gemv_x_first() && a.norm_w == nullptr && a.chain.ctr == nullptr && (a.K >> 3) <= 256 * XF_MAXC)
+            hipLaunchKernelGGL(gemv_xfirst_kernel, dim3(grid), dim3(256), lds, s, b, n_groups);
         else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     }
     VILA_LAUNCH_CHECK();
@@ -381,12 +486,18 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     // epilogue operands (position, the pair's biases, its RoPE row) are requested before the dot product, not after the reduction
     int e_pos = 0;
     float e_b0 = 0.f, e_b1 = 0.f, e_c = 1.f, e_s = 0.f;
+    bf16_t b0_raw = 0, b1_raw = 0;
     auto epi_fetch = [&](int gg) {
         if (lane >= 2) return;
         const int head = gg / gph, gi = gg % gph;
         e_pos = *p.pos_ptr;
+        if constexpr (GE) {                 // as loaded; converted in `finish` (gemv_kernel has the story)
+            b0_raw = p.bqkv != nullptr ? p.bqkv[rows_i[0]] : (bf16_t)0;
+            b1_raw = p.bqkv != nullptr ? p.bqkv[rows_i[1]] : (bf16_t)0;
+        } else {
         e_b0 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[0]]) : 0.f;
         e_b1 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[1]]) : 0.f;
+        }
         if (head < p.nq + p.nkv) { e_c = p.rope_cs[gi]; e_s = p.rope_cs[half + gi]; }
     };
     auto finish = [&](int gg, float (&acc)[2]) {
@@ -394,6 +505,11 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         const int head = gg / gph;
         const bool is_v = head >= p.nq + p.nkv;
         const int pos = e_pos;
+        if constexpr (GE) {
+            uint32_t r0 = b0_raw, r1 = b1_raw;
+            asm volatile("" : "+v"(r0), "+v"(r1));
+            e_b0 = bf2f((bf16_t)r0); e_b1 = bf2f((bf16_t)r1);
+        }
         const float lo = bfround(acc[0] + e_b0);
         const float hi = bfround(acc[1] + e_b1);
         float out = lane ? hi : lo;
