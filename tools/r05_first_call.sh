@@ -4,7 +4,7 @@
 # 1. the gated tests (tests/test_gpu_run.py: accumulated update, resumed run, the 3- / 4-stage 128x128 ring, the K-sliced ring) — apart from the suite
 # 2. tools/gemm_bench prering: the new ring variants (force_tile 9 / 10) vs the current choices on the prefill / tower shapes, cold weights
 # 3. TTFT A/B of VILA_RING_PIPE = 1 (the ring kernels' fragment schedule) and of the dispatch switch VILA_RING_BIG = 0 / 12 / 16 on the default bench line (no SFT, no sustained loop, no CPU leg)
-# 3a. decode A/B of VILA_GEMV_GAIN_EARLY x VILA_GEMV_MERGE_BATCH (gemv_common.h stage_x_ge, gemv.hip stage_x_attn_batched)
+# 3a. decode: each latency variant alone (gain early, merge batch, early K/V, x first), then VILA_DECODE_LAT = 0 / 1 twice; W4 with the batched merge
 # 3b. VILA_RING_SPLITK = 0 / 1 on the short-prompt lines (gemm_ring_splitk.hip)
 # 4. the suite itself (the round-4 late commits after the last full run: chat template, prepare_tokenizer, stop_token_ids)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -16,11 +16,10 @@ VILA_RING_PIPE=1 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-base
 python -c "
 import json; d=json.loads(open('$O/ring_pipe.json').read().strip().splitlines()[-1]); print('VILA_RING_PIPE=1: ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_pipe.err"
 # decode: the RMSNorm gain by LDS-DMA ahead of x (stage_x_ge) — three runs each, the headline metric
-for v in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do
-  set -- $v
-  VILA_GEMV_GAIN_EARLY=$1 VILA_GEMV_MERGE_BATCH=$2 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/decode_ge$1_mb$2.json" 2> "$O/decode_ge$1_mb$2.err"
+for v in VILA_GEMV_GAIN_EARLY VILA_GEMV_MERGE_BATCH VILA_DECODE_ATTN_EARLY_KV VILA_GEMV_X_FIRST; do
+  env $v=1 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/decode_$v.json" 2> "$O/decode_$v.err"
   python -c "
-import json; d=json.loads(open('$O/decode_ge$1_mb$2.json').read().strip().splitlines()[-1]); print('GAIN_EARLY=$1 MERGE_BATCH=$2: decode', d['value'], 'tok/s  ms/step', d['ms_per_step'], ' dominant-kernel frac', d['roofline']['frac'])" || tail -3 "$O/decode_ge$1_mb$2.err"
+import json; d=json.loads(open('$O/decode_$v.json').read().strip().splitlines()[-1]); print('$v=1 alone: decode', d['value'], 'tok/s  ms/step', d['ms_per_step'], ' dominant-kernel frac', d['roofline']['frac'])" || tail -3 "$O/decode_$v.err"
 done
 for v in 0 1 0 1; do
   VILA_DECODE_LAT=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/decode_lat$v.json" 2> "$O/decode_lat$v.err"
