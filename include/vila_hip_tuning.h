@@ -50,6 +50,9 @@ void vila_decode_force_early_kv(int on);
 /* the long no-norm GEMV (down_proj): x requested first, the first weight batch behind it (gemv.hip gemv_xfirst_kernel; added unmeasured at the end
  * of round 4; also under VILA_DECODE_LAT): -1 = VILA_GEMV_X_FIRST from the environment (default 0), 0 = off, 1 = on */
 void vila_gemv_force_x_first(int on);
+/* W4 GEMVs: keep the epilogue's bf16 operands as loaded and convert them in the epilogue (gemv_w4.hip LAT variants; added unmeasured at the end of
+ * round 4; also under VILA_DECODE_LAT): -1 = VILA_GEMV_W4_LAT from the environment (default 0), 0 = off, 1 = on */
+void vila_gemv_w4_force_lat(int on);
 #ifdef __cplusplus
 }
 #endif

@@ -215,11 +215,15 @@ def test_w4_o_proj_batched_merge_equals_the_plain_merge_bit_for_bit(n_prompt):
     try:
         for on in (0, 1):
             lib.vila_gemv_force_merge_batch(on)
+            lib.vila_gemv_w4_force_lat(on)                       # the W4 GEMVs' LAT variants (epilogue operands converted in the epilogue)
+            lib.vila_decode_force_early_kv(on)
             model.llm._drop_decode_session()
             _, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=6, return_logits=True, use_graph=False, eos_token_id=-1)
             free = model.llm.generate(inputs_embeds=e, max_new_tokens=6, use_graph=True, eos_token_id=-1)
             runs[on] = (lg, free)
     finally:
         lib.vila_gemv_force_merge_batch(-1)
+        lib.vila_gemv_w4_force_lat(-1)
+        lib.vila_decode_force_early_kv(-1)
         model.llm._drop_decode_session()
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])

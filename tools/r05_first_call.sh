@@ -27,9 +27,9 @@ for v in 0 1 0 1; do
 import json; d=json.loads(open('$O/decode_lat$v.json').read().strip().splitlines()[-1]); print('VILA_DECODE_LAT=$v (gain early + merge batch + early K/V): decode', d['value'], 'tok/s  ms/step', d['ms_per_step'], ' dominant-kernel frac', d['roofline']['frac'])" || tail -3 "$O/decode_lat$v.err"
 done
 for v in 0 1 0 1; do
-  VILA_GEMV_MERGE_BATCH=$v timeout 300 python bench.py --w4 --no-sft --no-sustain --no-cpu-baseline > "$O/w4_mb$v.json" 2> "$O/w4_mb$v.err"
+  VILA_DECODE_LAT=$v timeout 300 python bench.py --w4 --no-sft --no-sustain --no-cpu-baseline > "$O/w4_mb$v.json" 2> "$O/w4_mb$v.err"
   python -c "
-import json; d=json.loads(open('$O/w4_mb$v.json').read().strip().splitlines()[-1]); print('W4 decode, MERGE_BATCH=$v:', d['value'], 'tok/s  ms/step', d['ms_per_step'])" || tail -3 "$O/w4_mb$v.err"
+import json; d=json.loads(open('$O/w4_mb$v.json').read().strip().splitlines()[-1]); print('W4 decode, VILA_DECODE_LAT=$v (batched merge + LAT epilogues + early K/V):', d['value'], 'tok/s  ms/step', d['ms_per_step'])" || tail -3 "$O/w4_mb$v.err"
 done
 for v in 0 12 16; do
   VILA_RING_BIG=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_big_$v.json" 2> "$O/ring_big_$v.err"

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "vila_gemv_force_merge_batch": (None, [c_int]),
     "vila_decode_force_early_kv": (None, [c_int]),
     "vila_gemv_force_x_first": (None, [c_int]),
+    "vila_gemv_w4_force_lat": (None, [c_int]),
     "vila_llm_decode_chain_error": (c_int, [c_void_p, c_void_p]),
     "vila_gemm_bf16_t": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -417,6 +417,14 @@ static int gemv_merge_batch() {           // the batched attention merge in the 
 }
 
 int gemv_merge_batch_enabled() { return gemv_merge_batch(); }      // for gemv_w4.hip (the W4 o_proj kernel's MODE 5)
+static int g_w4_lat = -1;
+extern "C" void vila_gemv_w4_force_lat(int on) { g_w4_lat = on; }
+int gemv_w4_lat_enabled() {               // gemv_w4.hip: the LAT variants of the W4 GEMVs (epilogue operands kept as loaded)
+    if (g_w4_lat >= 0) return g_w4_lat;
+    static int v = -1;
+    if (v < 0) v = decode_lat_switch("VILA_GEMV_W4_LAT");
+    return v;
+}
 
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);

@@ -24,6 +24,8 @@
 
 int gemv_merge_batch_enabled();            // gemv.hip: VILA_GEMV_MERGE_BATCH / vila_gemv_force_merge_batch
 static int w4_merge_batch() { return gemv_merge_batch_enabled(); }
+int gemv_w4_lat_enabled();                 // gemv.hip: VILA_GEMV_W4_LAT / VILA_DECODE_LAT / vila_gemv_w4_force_lat
+static int w4_lat() { return gemv_w4_lat_enabled(); }
 
 // stage x (optionally RMS-normalised, HF rounding order) as bf16 into LDS + the per-group sums of the staged values; any blockDim
 // that is a multiple of 64.  Chunk c = 8 consecutive elements; 16 consecutive chunks (= 16 consecutive lanes) form a group.
@@ -201,7 +203,10 @@ __device__ __forceinline__ void stage_x_attn_w4_batched(const float* __restrict_
 // MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials (5: with the batched merge) ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
 // (q/k rows interleaved so RoPE partners i, i + hd/2 are neighbours).  UB = groups (KB) per wave and item; PIPE = the next
 // item's weights are issued before the current item is consumed (persistent blocks walking several tiles).
-template <int MODE, int UB, bool PIPE>
+// LAT (added unmeasured at the end of round 4, with the bf16 GEMVs' GE variants — gemv.hip): the epilogue's bf16 operands are kept AS LOADED and
+// converted in the epilogue.  Converted at the request, the compiler waits for them there with vmcnt(0), which also drains the weight batch issued
+// in front of them before the staging loads are issued.  VILA_GEMV_W4_LAT=1 or the master switch VILA_DECODE_LAT=1.
+template <int MODE, int UB, bool PIPE, bool LAT = false>
 __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, G = K >> 7;
@@ -230,10 +235,33 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     };
     // operands of the epilogue (bias / residual / RoPE row), fetched by the 16 epilogue lanes when a tile starts
     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    bf16_t r0 = 0, r1 = 0;                         // LAT: e0 / e1 as loaded
     int pos = 0;
     auto epi_fetch = [&](int tile_) {
         if (tid >= 16) return;
         const int pr = tile_ * 16 + tid;
+        if constexpr (LAT) {
+            r0 = 0; r1 = 0;
+            if (MODE == 0 || MODE == 4 || MODE == 5) {
+                if (pr < p.N) {
+                    if (p.bias != nullptr) r0 = p.bias[pr];
+                    if (p.residual != nullptr) r1 = p.residual[pr];
+                }
+            } else if (MODE == 3) {
+                const int head = pr / p.hd, within = pr - head * p.hd;
+                if (head < p.nq + 2 * p.nkv) {
+                    pos = *p.pos_ptr;
+                    if (head >= p.nq + p.nkv) {
+                        if (p.bias != nullptr) r0 = p.bias[pr];
+                    } else {
+                        const int i = within >> 1, b = within & 1;
+                        if (p.bias != nullptr) { r0 = p.bias[head * p.hd + i + b * half]; r1 = p.bias[head * p.hd + i + (b ^ 1) * half]; }
+                        e2 = p.rope_cs[i]; e3 = p.rope_cs[half + i];
+                    }
+                }
+            }
+            return;
+        }
         if (MODE == 0 || MODE == 4 || MODE == 5) {
             if (pr < p.N) {
                 e0 = p.bias != nullptr ? bf2f(p.bias[pr]) : 0.f;
@@ -303,6 +331,11 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
                 float v = 0.f, vp = 0.f;                        // own row and the partner row (n ^ 1)
                 for (int i = 0; i < W; ++i) { v += rd[i * 16 + tid]; vp += rd[i * 16 + (tid ^ 1)]; }
                 const int pr = tile * 16 + tid;                 // packed row
+                if constexpr (LAT) {                            // (the empty asm pins the conversion here)
+                    uint32_t a0 = r0, a1 = r1;
+                    asm volatile("" : "+v"(a0), "+v"(a1));
+                    e0 = bf2f((bf16_t)a0); e1 = bf2f((bf16_t)a1);
+                }
                 if (MODE == 0 || MODE == 4 || MODE == 5) {
                     if (pr < p.N) {
                         v += e0;
@@ -381,7 +414,9 @@ int launch_gemv_w4(const GemvW4Args& a, hipStream_t s) {
         lds += (size_t)a.n_splits * G * 4;                     // the merge weights [n_splits][heads]
     }
     VILA_REQUIRE(lds <= 160 * 1024, "gemv_w4: K=%d does not fit the 160 KB LDS", a.K);
-#define W4_LAUNCH(MODE, UB_, PIPE_) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles)
+    const bool lat = w4_lat() && a.mode != 1;                  // (the gate/up mode has no epilogue operands)
+#define W4_LAUNCH(MODE, UB_, PIPE_) do { if (lat) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_, true>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles); \
+                                         else hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles); } while (0)
     if (a.mode == 1) { if (pipe) W4_LAUNCH(1, 7, true); else W4_LAUNCH(1, 7, false); }
     else if (a.mode == 3) W4_LAUNCH(3, 7, false);
     else if (a.mode == 4 && w4_merge_batch()) { if (pipe) W4_LAUNCH(5, 7, true); else W4_LAUNCH(5, 7, false); }
