@@ -162,13 +162,46 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
     float* wst = (float*)smem + wave * 32 * STG;
     const int ncol0 = n0 + wc * (16 * NF);
     float bv[NF];
+    if constexpr (!PIPE) {
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int col = ncol0 + j * 16 + l15;
         bv[j] = (p.bias != nullptr && col < N) ? bf2f(p.bias[col]) : 0.f;
     }
+    }
     constexpr int LPR = 4 * NF, RPI = 64 / LPR;             // lanes per row (4 floats each), rows per store instruction
     const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
+    constexpr int NIT = 32 / RPI;
+    // PIPE: the epilogue's operands are requested up front.  Left as written, each of the 2 x NIT store passes below is
+    // `global_load_dwordx2 (residual) -> s_waitcnt vmcnt(0) -> add -> global_store` and the bias is `global_load_ushort -> vmcnt(0)` per fragment:
+    // 8-16 dependent round trips in the tail of every o_proj / out_proj / fc2 block (gfx950 counts stores in vmcnt too, so each wait also sits out the
+    // previous pass's store).  A thread only ever reads the residual elements it writes itself, so an in-place residual stream stays correct.
+    u32x2 rres[PIPE ? 2 * NIT : 1];
+    if constexpr (PIPE) {
+        bf16_t braw[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int col = ncol0 + j * 16 + l15;
+            braw[j] = (p.bias != nullptr) ? p.bias[col < N ? col : 0] : (bf16_t)0;
+        }
+        if (p.residual != nullptr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int gm = m0 + wr * 64 + h * 32 + it * RPI + rr0, gc = ncol0 + c4;
+                    const bool ok = gm < M && gc < N;          // out-of-range slots fetch element (0, 0) and are never used
+                    const int gmr = ok ? (p.res_mod > 0 ? gm % p.res_mod : gm) : 0;
+                    rres[h * NIT + it] = *(const u32x2*)(p.residual + (int64_t)gmr * p.ldr + (ok ? gc : 0));
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            uint32_t bb = braw[j];
+            asm volatile("" : "+v"(bb));                       // (pins the conversion behind the requests above)
+            bv[j] = (ncol0 + j * 16 + l15 < N) ? bf2f((bf16_t)bb) : 0.f;
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -191,7 +224,9 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
             if (gm < M && gc < N) {
                 f32x4 v = *(const f32x4*)(wst + rr * STG + c4);
                 if (p.residual != nullptr) {
-                    const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
+                    u32x2 rv;
+                    if constexpr (PIPE) rv = rres[h * NIT + it];
+                    else rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
                     v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
                 }
                 u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
