@@ -34,6 +34,10 @@ void vila_gemm_force_group(int grp);
 /* the K-sliced GEMMs' reduce takes the next block's LayerNorm / RMSNorm along (prefill down_proj -> next input_layernorm, tower fc2 -> next
  * layer_norm1): 1 = on (default), 0 = separate norm launches (A/B and the parity test of the fused kernel); environment: VILA_FUSE_NORM */
 void vila_gemm_force_fuse_norm(int on);
+/* 256x256 kernel with a residual epilogue (o_proj / down_proj / fc2 forward, dgrad + accumulated residual): request a store pass's residual words
+ * before the pass instead of one dependent load per store (gemm256_kernel.h EPF; added unmeasured at the end of round 4): -1 = VILA_GEMM256_EPF from
+ * the environment (default 0), 0 = off, 1 = on */
+void vila_gemm_force_epf(int on);
 /* decode GEMVs with an RMSNorm prologue (gate/up, qkv, lm_head): request the norm's gain by LDS-DMA ahead of x instead of one dependent load per
  * chunk after the reduction (gemv_common.h stage_x_ge; added unmeasured at the end of round 4): -1 = VILA_GEMV_GAIN_EARLY from the environment
  * (default 0), 0 = off, 1 = on.  A captured decode graph keeps the kernels it was captured with. */

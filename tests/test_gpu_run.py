@@ -227,3 +227,33 @@ def test_w4_o_proj_batched_merge_equals_the_plain_merge_bit_for_bit(n_prompt):
         lib.vila_decode_force_early_kv(-1)
         model.llm._drop_decode_session()
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("M,N,K", [(3076, 3584, 512), (769, 3584, 1024), (300, 264, 136), (513, 260, 128), (1000, 1032, 1496)])
+def test_gemm256_epilogue_prefetch_equals_the_plain_epilogue_bit_for_bit(M, N, K):
+    """`gemm256_kernel<..., EPF>` (`vila_gemm_force_epf(1)`): a store pass's residual words requested ahead of the pass.  Forward layout (256- and
+    192-row tiles, the extra-row fragment), in place on the residual stream, and the contraction-major dgrad layout with an accumulated residual:
+    identical output to the plain epilogue."""
+    from tests.gpu_util import randn_bf16
+    from vila_amd import _lib, ops
+    lib = _lib.load()
+    a, w = randn_bf16(M, K, seed=61), randn_bf16(N, K, seed=62, scale=K ** -0.5)
+    bias, res = randn_bf16(N, seed=63), randn_bf16(M, N, seed=64)
+    dy, wt = randn_bf16(M, N, seed=65), randn_bf16(N, K, seed=66, scale=N ** -0.5)     # dgrad: dX[M,K] = dY[M,N] . W[N,K] (+ residual [M,K])
+    resk = randn_bf16(M, K, seed=67)
+    outs = {}
+    try:
+        for on in (0, 1):
+            lib.vila_gemm_force_epf(on)
+            lib.vila_gemm_force_tile(4)
+            plain = ops.gemm(a, w, bias=bias, residual=res)
+            x = res.clone()
+            ops.gemm(a, w, residual=x, out=x)
+            lib.vila_gemm_force_tile(0)
+            dx = ops.gemm_t(dy, wt, b_cm=True, residual=resk) if (N >= 128 and K % 8 == 0 and M >= 128) else None
+            outs[on] = (plain, x, dx)
+    finally:
+        lib.vila_gemm_force_epf(-1)
+        lib.vila_gemm_force_tile(0)
+    for u, v in zip(outs[0], outs[1]):
+        assert (u is None and v is None) or torch.equal(u, v)

@@ -45,4 +45,8 @@ import json
 for f in ('$O/ring_splitk_$v.json', '$O/ring_splitk_lite_$v.json'):
     d=json.loads(open(f).read().strip().splitlines()[-1]); print('VILA_RING_SPLITK=$v', d['config'].get('workload'), ': ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_splitk_$v.err"
 done
+# 3c. the SFT step with the 256x256 kernel's epilogue prefetch (VILA_GEMM256_EPF = 0 / 1)
+for v in 0 1; do
+  VILA_GEMM256_EPF=$v timeout 400 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/sft_epf$v.err" | tee "$O/sft_epf$v.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('VILA_GEMM256_EPF=$v: sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
+done
 timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -25 > "$O/pytest.log"; tail -3 "$O/pytest.log"
