@@ -250,7 +250,7 @@ def test_gemm256_epilogue_prefetch_equals_the_plain_epilogue_bit_for_bit(M, N, K
             x = res.clone()
             ops.gemm(a, w, residual=x, out=x)
             lib.vila_gemm_force_tile(0)
-            dx = ops.gemm_t(dy, wt, b_cm=True, residual=resk) if (N >= 128 and K % 8 == 0 and M >= 128) else None
+            dx = ops.gemm_t(dy, wt, b_cm=True, residual=resk) if (N >= 128 and N % 8 == 0 and K % 8 == 0 and M >= 128) else None
             outs[on] = (plain, x, dx)
     finally:
         lib.vila_gemm_force_epf(-1)
