@@ -23,7 +23,8 @@ void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible,
  * 6 / 7 = 128x64 LDS-DMA ring with 4 / 3 stages, 8 / 9 / 10 = 128x128 ring with 2 / 3 / 4 stages (9, 10: added unmeasured, see gemm_ring.hip), 11 = the K-sliced 128x64 ring of
  * gemm_ring_splitk.hip when a workspace is given (added unmeasured; environment: VILA_RING_SPLITK=1 for M < 512), 12 / 13 / 14 / 15 = the ring kernels' PIPE
- * fragment schedule on the 128x64 3-stage / 128x128 3- / 4- / 2-stage tile (added unmeasured; environment: VILA_RING_PIPE=1 for every ring launch) */
+ * fragment schedule on the 128x64 3-stage / 128x128 3- / 4- / 2-stage tile (added unmeasured; environment: VILA_RING_PIPE=1 for every ring launch), 16..19 = the same tiles with
+ * PIPE 2 (inline-asm fragment reads retired by register-tied waits: the ks = 1 reads land under the ks = 0 MFMAs; VILA_RING_PIPE=2) */
 void vila_gemm_force_tile(int tile);
 /* leftover rows (M = 256 k + r, 1 <= r <= 16) as an extra fragment of the last 256-row tile (gemm256_kernel.h, EX): -1 = VILA_GEMM_EX from the
  * environment (default 1), 0 = off, 1 = when it saves a round of tiles (and in every K-sliced launch), 2 = whenever the rows fit (tests) */

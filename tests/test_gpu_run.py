@@ -98,7 +98,7 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
     assert [r["loss"] for r in sd.log_history[10:]] == [r["loss"] for r in sa.log_history[10:]]
 
 
-@pytest.mark.parametrize("tile", [9, 10, 12, 13, 14, 15])
+@pytest.mark.parametrize("tile", [9, 10, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 136), (769, 3584, 512), (1, 24, 40), (769, 4608, 3584), (1024, 3456, 1152), (513, 260, 72), (700, 520, 128)])
 def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
     """The 128x128 LDS-DMA ring with 3 / 4 stages (gemm_ring.hip variants 12 / 16, `vila_gemm_force_tile(9 / 10)`) and the PIPE fragment schedule
@@ -119,7 +119,7 @@ def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
         assert rel_l2(ops.gemm(a, w, bias=bias, epi=2), torch.nn.functional.gelu(ref + bias.float())) < 5e-3
         if tile >= 12:
             piped = ops.gemm(a, w, bias=bias, residual=res)
-            lib.vila_gemm_force_tile({12: 7, 13: 9, 14: 10, 15: 8}[tile])
+            lib.vila_gemm_force_tile({12: 7, 13: 9, 14: 10, 15: 8, 16: 7, 17: 9, 18: 10, 19: 8}[tile])     # (16..19: PIPE 2 = asm fragment reads retired by tied waits)
             assert torch.equal(piped, ops.gemm(a, w, bias=bias, residual=res))
     finally:
         lib.vila_gemm_force_tile(0)

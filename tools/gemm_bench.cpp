@@ -226,7 +226,7 @@ int main(int argc, char** argv) {
             {"ViT qkv  M=1024 cold", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res cold", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc1 cold", 1024, 4304, 1152, 0, 0, 0},
             {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
         };
-        for (auto& c : pc) run_case(c, {300, 307, 312, 308, 315, 309, 313, 310, 314, 300, 307, 312, 308, 315, 309, 313, 310, 314}, ws, ws_bytes);   // 312..315 = the PIPE fragment schedule on 307 / 309 / 310 / 308
+        for (auto& c : pc) run_case(c, {300, 307, 312, 316, 308, 315, 319, 309, 313, 317, 310, 314, 318, 300, 307, 312, 316, 308, 315, 319, 309, 313, 317, 310, 314, 318}, ws, ws_bytes);   // 312..315 = the PIPE fragment schedule on 307 / 309 / 310 / 308, 316..319 = PIPE 2 (asm reads, progressive waits)
         // short prompts: the K-sliced 128x64 ring (force_tile 11, gemm_ring_splitk.hip) vs the automatic choice and the plain ring
         std::vector<Case> sc = {
             {"LLM qkv M=64 cold", 64, 4608, 3584, 0, 0, 0}, {"LLM qkv M=160 cold", 160, 4608, 3584, 0, 0, 0}, {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0},

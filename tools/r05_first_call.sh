@@ -12,9 +12,11 @@ O=$GRAFT_REPO_ROOT/gpurun_out/r05_first; mkdir -p "$O"
 VILA_TEST_UNVERIFIED=1 timeout 600 python -m pytest tests/test_gpu_run.py -m gpu -q -s 2>&1 | tail -40 > "$O/pytest_unverified.log"; tail -5 "$O/pytest_unverified.log"
 [ -x tools/gemm_bench ] || hipcc -O2 -std=c++17 tools/gemm_bench.cpp -o tools/gemm_bench -Iinclude -Lvila_amd/lib -lvila_hip -Wl,-rpath,'$ORIGIN/../vila_amd/lib'
 timeout 300 tools/gemm_bench prering > "$O/gemm_bench_prering.log" 2>&1; tail -72 "$O/gemm_bench_prering.log"
-VILA_RING_PIPE=1 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_pipe.json" 2> "$O/ring_pipe.err"
-python -c "
-import json; d=json.loads(open('$O/ring_pipe.json').read().strip().splitlines()[-1]); print('VILA_RING_PIPE=1: ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_pipe.err"
+for v in 1 2; do
+  VILA_RING_PIPE=$v timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline --steps 32 --warmup 8 > "$O/ring_pipe$v.json" 2> "$O/ring_pipe$v.err"
+  python -c "
+import json; d=json.loads(open('$O/ring_pipe$v.json').read().strip().splitlines()[-1]); print('VILA_RING_PIPE=$v: ttft', d['ttft_ms'], 'ms  decode', d['value'], 'tok/s')" || tail -3 "$O/ring_pipe$v.err"
+done
 # decode: the RMSNorm gain by LDS-DMA ahead of x (stage_x_ge) — three runs each, the headline metric
 for v in VILA_GEMV_GAIN_EARLY VILA_GEMV_MERGE_BATCH VILA_DECODE_ATTN_EARLY_KV VILA_GEMV_X_FIRST; do
   env $v=1 timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline > "$O/decode_$v.json" 2> "$O/decode_$v.err"

@@ -25,6 +25,14 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __attribute__((aligned(16))) unsigned int g_ring_zero_chunk[4];   // K-tail source (zero-initialised)
 
+// PIPE = 2: fragment read the compiler's wait insertion does not see (retired by common.h lds_wait)
+template <int OFF> __device__ __forceinline__ u32x4 ring_ds_read_b128(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
 // NF = 16-column fragments per wave: NF = 2 -> 128 x 64 tile (24 KB per stage), NF = 4 -> 128 x 128 tile (32 KB per stage, wave
 // tile 64 x 64: 16 ds_read_b128 per 32 MFMAs).  RG_STAGES x stage bytes <= 72 KB keeps two blocks per CU, so a second wave per
 // SIMD overlaps one block's LDS reads with the other's MFMAs:  <NF=2, 3 stages> for grids of about one round (two K-tiles in
@@ -35,7 +43,10 @@ __device__ __attribute__((aligned(16))) unsigned int g_ring_zero_chunk[4];   // 
 // PIPE reads the ks = 0 operands first, then the ks = 1 operands, and pins "all reads, then the MFMAs" with sched_group_barrier: the counted
 // lgkmcnt waits the compiler inserts then retire the reads progressively and the ks = 1 reads land under the ks = 0 MFMAs.  Scheduling hints only:
 // the arithmetic and its order are unchanged (bit-identical results).
-template <int EPI, int RG_STAGES, int NF, bool PIPE = false>
+// PIPE = 2 (VILA_RING_PIPE=2) goes one step further: with PIPE = 1 the compiler still waits for ALL 12 reads (`lgkmcnt(0)`) before the first MFMA.
+// Here the fragment reads are inline-asm `ds_read_b128` (invisible to the compiler's wait insertion) retired by register-tied `s_waitcnt lgkmcnt`
+// (common.h lds_wait): the ks = 0 MFMAs start when the first 4 + NF reads are back and the ks = 1 reads land under them.
+template <int EPI, int RG_STAGES, int NF, int PIPE = 0>
 __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 72 * 1024) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 32 * NF;
@@ -125,6 +136,32 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
         const char* cA = smem + (t % RG_STAGES) * STAGE_BYTES + wr * 64 * 128;
         const char* cB = smem + (t % RG_STAGES) * STAGE_BYTES + A_BYTES + wc * (16 * NF) * 128;
         bf16x8 af[4][2], bfr[NF][2];
+        if constexpr (PIPE == 2) {
+            u32x4 ra[4][2], rb[NF][2];
+            const uint32_t aA = lds_addr(cA), aB = lds_addr(cB);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                static_for<0, NF>([&](auto J) { constexpr int j = decltype(J)::value; rb[j][ks] = ring_ds_read_b128<j * 2048>(aB + foff[ks]); });
+                static_for<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ra[i][ks] = ring_ds_read_b128<i * 2048>(aA + foff[ks]); });
+            }
+            // 2 x (4 + NF) reads are outstanding, in issue order: the first 4 + NF are the ks = 0 operands
+            if constexpr (NF == 2) { lds_wait<6>(rb[0][0], rb[1][0], ra[0][0], ra[1][0]); lds_wait<6>(ra[2][0], ra[3][0]); }
+            else { lds_wait<8>(rb[0][0], rb[1][0], rb[2][0], rb[3][0], ra[0][0], ra[1][0], ra[2][0], ra[3][0]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[i][0]), __builtin_bit_cast(bf16x8, rb[j][0]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);       // keep the ks = 0 MFMAs in front of the wait for ks = 1 (the scheduler otherwise sinks them behind it)
+            if constexpr (NF == 2) { lds_wait<0>(rb[0][1], rb[1][1], ra[0][1], ra[1][1]); lds_wait<0>(ra[2][1], ra[3][1]); }
+            else { lds_wait<0>(rb[0][1], rb[1][1], rb[2][1], rb[3][1], ra[0][1], ra[1][1], ra[2][1], ra[3][1]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[i][1]), __builtin_bit_cast(bf16x8, rb[j][1]), acc[i][j], 0, 0, 0);
+            continue;
+        }
         if constexpr (PIPE) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
     }
 }
 
-template <int EPI, int STAGES, int NF, bool PIPE = false>
+template <int EPI, int STAGES, int NF, int PIPE = 0>
 static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = cdiv(a.M, RG_BM), tiles_n = cdiv(a.N, 32 * NF);
     const size_t lds = (size_t)STAGES * (RG_BM + 32 * NF) * RG_BK * 2;    // >= 4 waves x 32 x (16 NF + 4) x 4 B of staging
@@ -257,7 +294,7 @@ bool gemm_ring_supported(const GemmArgs& a) {
            (int64_t)a.N * a.ldw < (1ll << 31);
 }
 
-template <int STAGES, int NF, bool PIPE = false>
+template <int STAGES, int NF, int PIPE = 0>
 static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
     switch (a.epi) {
         case EPI_NONE: return launch_ring_t<EPI_NONE, STAGES, NF, PIPE>(a, s);
@@ -273,19 +310,27 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
 // S = 769 q/k/v/o launches are one round of 504 / 392 128x64 blocks that pull 677 MB through L2 for 39 MB of operands (24 KB per block and
 // K-tile); a 128x128 tile halves that traffic per flop, and what the 2-stage variant lacked at one block per CU was loads in flight.
 // variant + 100 (or VILA_RING_PIPE=1 in the environment) = the same tile with the PIPE fragment schedule.
-static int ring_pipe_env() {
+static int ring_pipe_env() {               // VILA_RING_PIPE = 1 / 2
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
     return v;
 }
 int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {
+    if (variant >= 200 || (variant < 100 && ring_pipe_env() == 2)) {           // PIPE = 2: asm fragment reads, progressive waits
+        variant %= 100;
+        if (variant == 16) return launch_ring_epi<4, 4, 2>(a, s);
+        if (variant == 12) return launch_ring_epi<3, 4, 2>(a, s);
+        if (variant == 8) return launch_ring_epi<2, 4, 2>(a, s);
+        if (variant == 4) return launch_ring_epi<4, 2, 2>(a, s);
+        return launch_ring_epi<3, 2, 2>(a, s);
+    }
     if (variant >= 100 || ring_pipe_env()) {
         variant %= 100;
-        if (variant == 16) return launch_ring_epi<4, 4, true>(a, s);
-        if (variant == 12) return launch_ring_epi<3, 4, true>(a, s);
-        if (variant == 8) return launch_ring_epi<2, 4, true>(a, s);
-        if (variant == 4) return launch_ring_epi<4, 2, true>(a, s);
-        return launch_ring_epi<3, 2, true>(a, s);
+        if (variant == 16) return launch_ring_epi<4, 4, 1>(a, s);
+        if (variant == 12) return launch_ring_epi<3, 4, 1>(a, s);
+        if (variant == 8) return launch_ring_epi<2, 4, 1>(a, s);
+        if (variant == 4) return launch_ring_epi<4, 2, 1>(a, s);
+        return launch_ring_epi<3, 2, 1>(a, s);
     }
     if (variant == 16) return launch_ring_epi<4, 4>(a, s);
     if (variant == 12) return launch_ring_epi<3, 4>(a, s);
