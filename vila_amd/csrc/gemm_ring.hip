@@ -139,14 +139,19 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
         if constexpr (PIPE == 2) {
             u32x4 ra[4][2], rb[NF][2];
             const uint32_t aA = lds_addr(cA), aB = lds_addr(cB);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                static_for<0, NF>([&](auto J) { constexpr int j = decltype(J)::value; rb[j][ks] = ring_ds_read_b128<j * 2048>(aB + foff[ks]); });
-                static_for<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ra[i][ks] = ring_ds_read_b128<i * 2048>(aA + foff[ks]); });
+            // issue order: the 4 + NF operands of ks = 0, then those of ks = 1.  lgkmcnt is a 4-bit counter: never more than 15 reads in flight, so
+            // with NF = 4 (16 reads) the last ks = 1 read is issued behind the first wait.
+            static_for<0, NF>([&](auto J) { constexpr int j = decltype(J)::value; rb[j][0] = ring_ds_read_b128<j * 2048>(aB + foff[0]); });
+            static_for<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ra[i][0] = ring_ds_read_b128<i * 2048>(aA + foff[0]); });
+            static_for<0, NF>([&](auto J) { constexpr int j = decltype(J)::value; rb[j][1] = ring_ds_read_b128<j * 2048>(aB + foff[1]); });
+            static_for<0, 3>([&](auto I) { constexpr int i = decltype(I)::value; ra[i][1] = ring_ds_read_b128<i * 2048>(aA + foff[1]); });
+            if constexpr (NF == 2) {
+                ra[3][1] = ring_ds_read_b128<3 * 2048>(aA + foff[1]);                     // 12 in flight
+                lds_wait<6>(rb[0][0], rb[1][0], ra[0][0], ra[1][0]); lds_wait<6>(ra[2][0], ra[3][0]);
+            } else {
+                lds_wait<7>(rb[0][0], rb[1][0], rb[2][0], rb[3][0], ra[0][0], ra[1][0], ra[2][0], ra[3][0]);   // 15 in flight, the first 8 back
+                ra[3][1] = ring_ds_read_b128<3 * 2048>(aA + foff[1]);
             }
-            // 2 x (4 + NF) reads are outstanding, in issue order: the first 4 + NF are the ks = 0 operands
-            if constexpr (NF == 2) { lds_wait<6>(rb[0][0], rb[1][0], ra[0][0], ra[1][0]); lds_wait<6>(ra[2][0], ra[3][0]); }
-            else { lds_wait<8>(rb[0][0], rb[1][0], rb[2][0], rb[3][0], ra[0][0], ra[1][0], ra[2][0], ra[3][0]); }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
