@@ -39,6 +39,9 @@ void vila_gemm_force_fuse_norm(int on);
  * before the pass instead of one dependent load per store (gemm256_kernel.h EPF; added unmeasured at the end of round 4): -1 = VILA_GEMM256_EPF from
  * the environment (default 0), 0 = off, 1 = on */
 void vila_gemm_force_epf(int on);
+/* LayerNorm / RMSNorm over rows wider than 1536 columns: every load (x, w, b) requested up front instead of x -> reduce -> w (elementwise.hip
+ * norm_block_lat_kernel; added unmeasured at the end of round 4): -1 = VILA_NORM_LAT from the environment (default 0), 0 = off, 1 = on */
+void vila_norm_force_lat(int on);
 /* decode GEMVs with an RMSNorm prologue (gate/up, qkv, lm_head): request the norm's gain by LDS-DMA ahead of x instead of one dependent load per
  * chunk after the reduction (gemv_common.h stage_x_ge; added unmeasured at the end of round 4): -1 = VILA_GEMV_GAIN_EARLY from the environment
  * (default 0), 0 = off, 1 = on.  A captured decode graph keeps the kernels it was captured with. */

@@ -257,3 +257,23 @@ def test_gemm256_epilogue_prefetch_equals_the_plain_epilogue_bit_for_bit(M, N, K
         lib.vila_gemm_force_tile(0)
     for u, v in zip(outs[0], outs[1]):
         assert (u is None and v is None) or torch.equal(u, v)
+
+
+@pytest.mark.parametrize("rows,cols", [(769, 3584), (8, 3584), (16, 2048), (5, 8192), (3, 13824), (7, 1544)])
+def test_norm_lat_kernel_equals_the_block_per_row_kernel_bit_for_bit(rows, cols):
+    """`norm_block_lat_kernel` (`vila_norm_force_lat(1)`): x, w and b requested up front instead of x -> reduce -> w; same per-thread summation
+    order and block reduction as `norm_kernel`, so RMSNorm and LayerNorm outputs are identical."""
+    from tests.gpu_util import randn_bf16
+    from vila_amd import _lib, ops
+    lib = _lib.load()
+    x = randn_bf16(rows, cols, seed=71)
+    w, b = randn_bf16(cols, seed=72, scale=0.1) + 1, randn_bf16(cols, seed=73, scale=0.1)
+    outs = {}
+    try:
+        for on in (0, 1):
+            lib.vila_norm_force_lat(on)
+            outs[on] = (ops.rmsnorm(x, w, 1e-6), ops.layernorm(x, w, b, 1e-5), ops.layernorm(x, w, None, 1e-5))
+    finally:
+        lib.vila_norm_force_lat(-1)
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)

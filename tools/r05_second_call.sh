@@ -26,6 +26,10 @@ for v in 0 1; do
   VILA_RING_SPLITK=$v timeout 300 python bench.py --prompt-tokens 32 $B --steps 32 --warmup 8 > "$O/ring_splitk_$v.json" 2> "$O/ring_splitk_$v.err"; line "$O/ring_splitk_$v.json" "VILA_RING_SPLITK=$v S=289"
   VILA_RING_SPLITK=$v timeout 300 python bench.py --config nvila_lite_3b --prompt-tokens 32 $B --steps 32 --warmup 8 > "$O/ring_splitk_lite_$v.json" 2> "$O/ring_splitk_lite_$v.err"; line "$O/ring_splitk_lite_$v.json" "VILA_RING_SPLITK=$v Lite-3B"
 done
+# batched decode (8 rows) with the norm LAT kernel
+for v in 0 1; do
+  VILA_NORM_LAT=$v timeout 300 python bench.py --batch 8 $B --steps 48 --warmup 8 > "$O/batch8_normlat$v.json" 2> "$O/batch8_normlat$v.err"; line "$O/batch8_normlat$v.json" "batch 8, VILA_NORM_LAT=$v"
+done
 # the SFT step with the 256x256 kernel's epilogue prefetch (and the ring PIPE for the tower's shapes)
 for v in 0 1; do
   VILA_GEMM256_EPF=$v VILA_RING_PIPE=$v timeout 400 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/sft_epf$v.err" | tee "$O/sft_epf$v.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('VILA_GEMM256_EPF=$v VILA_RING_PIPE=$v: sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"

@@ -1,5 +1,6 @@
 // HBM-bound helpers around the MFMA kernels: norms, patchify, space-to-depth, RoPE + KV scatter, row gathers, argmax.
 // All are vectorised 16 B per lane (guide G13) and keep statistics in fp32.
+#include <stdlib.h>
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -163,6 +164,101 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const bf16_t* __restrict
     }
 }
 
+// norm_kernel with every load requested UP FRONT ("LAT", added at the end of round 4 from the ISA alone, OFF by default until measured —
+// VILA_NORM_LAT=1): norm_kernel's loads sit inside `if (c < nch)` (x) and behind the block reduction (w, b), so a 3584-wide row is
+// x -> x -> reduce -> w -> w = five dependent round trips (8 `global_load -> s_waitcnt vmcnt(0)` pairs in the RMS kernel's ISA); one block
+// per row means nothing else hides them when the rows are few (8-16 rows in the batched decode step: 2 x 5.1 us per layer) and the kernel
+// sits at 7.8 us for 11 MB at S = 769.  Here x, w (and b) are requested unconditionally (chunks past the row re-read its last chunk and are
+// zeroed by a select) before anything is reduced.  Same per-thread summation order and the same block reduction: bit-identical results.
+template <bool RMS, int MAXC>
+__global__ __launch_bounds__(256) void norm_block_lat_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                             bf16_t* __restrict__ y, int cols, float eps) {
+    __shared__ float scratch[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)row * cols;
+    bf16_t* yr = y + (int64_t)row * cols;
+    const int nch = cols >> 3;                                   // <= 256 * MAXC
+    u32x4 v[MAXC], wv[MAXC], bv[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i, cc = c < nch ? c : nch - 1;
+        v[i] = *(const u32x4*)(xr + cc * 8);
+        wv[i] = *(const u32x4*)(w + cc * 8);
+        if constexpr (!RMS) bv[i] = *(const u32x4*)((b != nullptr ? b : w) + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const bool ok = tid + 256 * i < nch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[i][k] = ok ? v[i][k] : 0u;
+            if constexpr (!RMS) bv[i][k] = (ok && b != nullptr) ? bv[i][k] : 0u; else bv[i][k] = 0u;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = lo_bf(v[i][k]), bb = hi_bf(v[i][k]);
+            s += RMS ? (a * a + bb * bb) : (a + bb);
+        }
+    s = block_sum_256(s, scratch);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / cols + eps);
+    } else {
+        mean = s / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            if (tid + 256 * i < nch) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = lo_bf(v[i][k]) - mean, bb = hi_bf(v[i][k]) - mean;
+                    q += a * a + bb * bb;
+                }
+            }
+        }
+        q = block_sum_256(q, scratch);
+        rstd = rsqrtf(q / cols + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) {
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = lo_bf(v[i][k]), bb = hi_bf(v[i][k]);
+                if (RMS) {
+                    a = lo_bf(wv[i][k]) * bfround(a * rstd);
+                    bb = hi_bf(wv[i][k]) * bfround(bb * rstd);
+                } else {
+                    a = (a - mean) * rstd * lo_bf(wv[i][k]) + lo_bf(bv[i][k]);
+                    bb = (bb - mean) * rstd * hi_bf(wv[i][k]) + hi_bf(bv[i][k]);
+                }
+                o[k] = pack2bf(a, bb);
+            }
+            *(u32x4*)(yr + c * 8) = o;
+        }
+    }
+}
+static int g_norm_lat = -1;               // -1 = VILA_NORM_LAT from the environment (default 0), 0 / 1 = forced (vila_norm_force_lat)
+extern "C" void vila_norm_force_lat(int on) { g_norm_lat = on; }
+static int norm_lat() {
+    if (g_norm_lat < 0) { const char* e = getenv("VILA_NORM_LAT"); g_norm_lat = (e && e[0] == '1') ? 1 : 0; }
+    return g_norm_lat;
+}
+template <bool RMS>
+static int launch_norm_block_lat(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int cols, float eps, hipStream_t s) {
+    if (cols <= 4096) hipLaunchKernelGGL((norm_block_lat_kernel<RMS, 2>), dim3(rows), dim3(256), 0, s, x, w, b, y, cols, eps);
+    else if (cols <= 8192) hipLaunchKernelGGL((norm_block_lat_kernel<RMS, 4>), dim3(rows), dim3(256), 0, s, x, w, b, y, cols, eps);
+    else hipLaunchKernelGGL((norm_block_lat_kernel<RMS, 8>), dim3(rows), dim3(256), 0, s, x, w, b, y, cols, eps);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int cols, float eps, hipStream_t s) {
     VILA_REQUIRE(cols % 8 == 0 && cols <= 16384 && rows > 0, "layernorm: cols=%d must be a multiple of 8 and <= 16384", cols);
     if (cols <= 1536) {          // wider rows: the block-per-row kernel wins (3584 columns: 6.7 us vs 19 for one wave per 7-KB row at S = 769)
@@ -170,6 +266,7 @@ int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* 
         VILA_LAUNCH_CHECK();
         return 0;
     }
+    if (norm_lat()) return launch_norm_block_lat<false>(x, w, b, y, rows, cols, eps, s);
     hipLaunchKernelGGL(norm_kernel<false>, dim3(rows), dim3(256), 0, s, x, w, b, y, cols, eps);
     VILA_LAUNCH_CHECK();
     return 0;
@@ -181,6 +278,7 @@ int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int co
         VILA_LAUNCH_CHECK();
         return 0;
     }
+    if (norm_lat()) return launch_norm_block_lat<true>(x, w, nullptr, y, rows, cols, eps, s);
     hipLaunchKernelGGL(norm_kernel<true>, dim3(rows), dim3(256), 0, s, x, w, (const bf16_t*)nullptr, y, cols, eps);
     VILA_LAUNCH_CHECK();
     return 0;
