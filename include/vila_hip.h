@@ -255,6 +255,10 @@ int vila_act_bwd_bf16(const void* z, const void* dy, void* dz, int64_t n, int ac
 int vila_silu_mul_fwd_bf16(const void* gate, const void* up, void* act, int64_t n, vila_stream_t stream);
 int vila_silu_mul_bwd_bf16(const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, vila_stream_t stream);
 int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_t stream);
+/* Gradient accumulation across the micro-batches of one update (`--gradient_accumulation_steps`; HF Trainer adds each micro-batch's
+ * backward into the fp32 / param-dtype .grad, transformer_normalize_monkey_patch.py:236-249): the running sum `acc` is fp32.
+ * mode 0: acc = g;  mode 1: acc += g;  mode 2: out = bf16(acc + g) (acc untouched, out may alias g).  g, out: bf16[n]; n % 8 == 0. */
+int vila_grad_accum_f32(float* acc, const void* g, void* out, int64_t n, int mode, vila_stream_t stream);
 /* out[c] (+)= sum_r x[r][c] (scratch: cols fp32); period > 0: out[p][c] = sum over rows r == p (mod period) (position-embedding gradient) */
 int vila_colsum_bf16(const void* x, void* out, float* scratch, int rows, int cols, int64_t ld, int accumulate, int period, vila_stream_t stream);
 /* LayerNorm (rms=0) / RMSNorm (rms=1) backward; scratch = 2*cols fp32 */

@@ -297,6 +297,24 @@ def test_embed_and_copy_rows(ops):
 # ---------------------------------------------------------------------------------------------------------------------
 # backward GEMMs on the forward tensors as they lie (contraction-major operands, vila_gemm_bf16_t)
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [8, 4096 + 8, 3_000_000 + 16])
+def test_grad_accum_f32_is_the_fp32_sum_rounded_once(ops, n):
+    """vila_grad_accum_f32 (gradient accumulation over micro-batches): modes 0 / 1 keep the running sum in fp32 BIT-EXACTLY (bf16 -> fp32 is
+    exact and fp32 addition is the same on both sides); mode 2 = bf16(acc + g) with one rounding, acc untouched, out aliasing g."""
+    gs = [randn_bf16(n, seed=40 + k) * (10.0 ** -k) for k in range(9)]              # later micro-batches 1e-8 of the first: bf16 sums would absorb them
+    acc = torch.full((n,), 7.0, device="cuda", dtype=torch.float32)                # mode 0 must overwrite whatever is there
+    want = torch.zeros(n, device="cuda", dtype=torch.float32)
+    for k, g in enumerate(gs[:-1]):
+        ops.grad_accum(acc, g, mode=0 if k == 0 else 1)
+        want = g.float() if k == 0 else want + g.float()
+    assert torch.equal(acc, want)
+    last = gs[-1].clone()
+    keep = acc.clone()
+    ops.grad_accum(acc, last, out=last, mode=2)
+    assert torch.equal(acc, keep)
+    assert torch.equal(last, (want + gs[-1].float()).to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("T,N,K", [(3076, 3584, 3584), (1538, 4608, 3584), (1000, 1032, 1496), (777, 520, 1032), (128, 128, 128), (3076, 18944, 3584)])
 def test_gemm_t_dgrad_and_wgrad_match_fp32(ops, T, N, K):
     """dX = dY . W (W read as [contraction N][K]) and dW = dY^T . X (both read as [contraction T][rows]) against fp32 matmuls of the

@@ -1,8 +1,10 @@
-"""GPU legs of the SFT run (vila_amd/run.py, SFTTrainer.step_accumulated).
+"""GPU legs of the SFT run (vila_amd/run.py, SFTTrainer.step_accumulated) and the bit-equality tests of the kernel variants that only re-order
+instructions or requests (ring PIPE schedules, the decode-latency variants, the 256x256 kernel's epilogue prefetch).
 
-WRITTEN WITHOUT A GPU: the round's GPU minutes were spent when these were added, so they have never run on an MI355X.  They are therefore
-skipped unless VILA_TEST_UNVERIFIED=1 (tools/validate_gpu.sh sets it) — a test that was never seen green must not be able to stop the suite.
-Once they have passed on hardware the gate goes.  Their host logic is covered on CPU (tests/test_run_cpu.py, tests/test_train_cpu.py)."""
+Written at the end of round 4 without a GPU and gated then; first run on an MI355X in round 5 (gpurun_out/r05_first: 91 of 92 green; the one
+failure was this file's own expectation — a resumed run cannot equal the uninterrupted one BIT FOR BIT because the step's column reductions use
+fp32 atomics — now held to a measured run-to-run noise floor instead).  The gate is gone.  Host logic on CPU: tests/test_run_cpu.py,
+tests/test_train_cpu.py."""
 import os
 
 import pytest
@@ -10,8 +12,7 @@ import torch
 
 from vila_amd import configs, run, synthetic
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("VILA_TEST_UNVERIFIED") != "1", reason="never run on hardware yet: set VILA_TEST_UNVERIFIED=1")]
+pytestmark = [pytest.mark.gpu]
 
 
 def _samples(cfg, n, seed):
@@ -58,7 +59,8 @@ def test_accumulated_update_equals_the_sum_of_its_micro_batch_gradients():
     torch.cuda.synchronize()
     got = tr.flat.grads.float()
     rel = float((got - want).norm() / want.norm())
-    assert abs(loss - sum(losses)) < 1e-3 * abs(sum(losses)) and rel < 1e-2, (loss, sum(losses), rel)
+    # the held sum is fp32 (vila_grad_accum_f32): the accumulated gradient is the fp32 sum rounded to bf16 ONCE (rel-L2 of one bf16 rounding ~ 1.2e-3)
+    assert abs(loss - sum(losses)) < 1e-3 * abs(sum(losses)) and rel < 3e-3, (loss, sum(losses), rel)
     assert set(tr.flat.bucket_steps.values()) == {1} and "mm_projector." in tr.flat.bucket_steps
     print(f"accumulated update: loss {loss:.5f} vs {sum(losses):.5f}, gradient rel-L2 vs the fp32 sum of the micro-batches {rel:.2e}")
 
@@ -73,10 +75,18 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
 
     def fresh():
         return SFTTrainer(build_model(cfg, seed=12), lr=1e-3)
+    init = fresh().flat.master.clone()
     a = fresh()
     sa = run.train(a, data, _collate(cfg), mk("a"))
     assert sa.global_step == 16 and sa.log_history[-1]["loss"] < sa.log_history[0]["loss"]
     assert os.path.isfile(tmp_path / "a" / "config.json") and os.path.isdir(tmp_path / "a" / "llm")
+    # the same run once more, uninterrupted: how far two IDENTICAL runs drift apart (norm_bwd / colsum / the embedding scatter reduce columns with
+    # fp32 atomics, so a step's gradients are equal only up to summation order and AdamW's m / sqrt(v) carries that on)
+    b = fresh()
+    sb = run.train(b, data, _collate(cfg), mk("b"))
+    torch.cuda.synchronize()
+    moved = float((a.flat.master - init).norm())
+    noise = float((b.flat.master - a.flat.master).norm()) / moved
     # the same run stopped after 10 of its 16 planned updates (checkpoints 5 and 10 on disk), then started again
     c = fresh()
     calls = {"n": 0}
@@ -94,8 +104,14 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
     sd = run.train(d, data, _collate(cfg), mk("c"))
     torch.cuda.synchronize()
     assert sd.global_step == 16 and [r["step"] for r in sd.log_history] == list(range(1, 17))
-    assert torch.equal(d.flat.master, a.flat.master) and torch.equal(d.flat.params, a.flat.params)
-    assert [r["loss"] for r in sd.log_history[10:]] == [r["loss"] for r in sa.log_history[10:]]
+    # a replayed or skipped batch, a rate taken from the wrong step or lost optimizer moments move the weights by a sizeable fraction of one
+    # update (1 / 16 of `moved` ~ 6e-2); summation-order noise is orders of magnitude below that
+    drift = float((d.flat.master - a.flat.master).norm()) / moved
+    print(f"resumed vs uninterrupted: {drift:.2e} of the run's total weight movement; two identical uninterrupted runs: {noise:.2e}")
+    assert drift <= max(5 * noise, 2e-3), (drift, noise)
+    la, ld = [r["loss"] for r in sa.log_history], [r["loss"] for r in sd.log_history]
+    assert ld[:10] == pytest.approx(la[:10], rel=2e-3) and ld[10:] == pytest.approx(la[10:], rel=2e-3), (la, ld)
+    assert [r.get("learning_rate") for r in sd.log_history] == [r.get("learning_rate") for r in sa.log_history]
 
 
 @pytest.mark.parametrize("tile", [9, 10, 12, 13, 14, 15, 16, 17, 18, 19])

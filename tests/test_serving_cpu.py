@@ -194,7 +194,7 @@ def test_video_url_content_becomes_one_image_token_per_frame(monkeypatch):
     seen = {}
 
     def fake_frames(path, num_frames=8, fps=0.0):
-        seen.update(path=path, num_frames=num_frames, fps=fps)
+        seen.update(path=path, num_frames=num_frames, fps=fps, body=open(path, "rb").read())
         return [np.zeros((56, 56, 3), np.uint8)] * 3
     monkeypatch.setattr(serving, "load_video_frames", fake_frames)
     client = TestClient(serving.create_app(m, tok, "NVILA-8B"))
@@ -205,7 +205,11 @@ def test_video_url_content_becomes_one_image_token_per_frame(monkeypatch):
     assert r.status_code == 200, r.text
     ids, media = m.calls[-1][0], m.calls[-1][1]
     assert int((ids == m.cfg.image_token_id).sum()) == 3 and len(media["image"]) == 3
-    assert seen["num_frames"] == 3 and seen["fps"] == 0.0 and seen["path"].endswith(".mp4") and open(seen["path"], "rb").read() == b"fake mp4 bytes"
+    assert seen["num_frames"] == 3 and seen["fps"] == 0.0 and seen["path"].endswith(".mp4") and seen["body"] == b"fake mp4 bytes"
+    import os
+    assert not os.path.exists(os.path.dirname(seen["path"]))         # the request's temp directory does not outlive its decoding
+    monkeypatch.setattr(serving, "load_video_frames", lambda path, num_frames=8, fps=0.0: [])
+    assert client.post("/chat/completions", json=body).status_code != 200          # a request whose video yields no frame is refused
     body["messages"][0]["content"][0]["video_url"]["url"] = "/etc/passwd"
     r = client.post("/chat/completions", json=body)
     assert r.status_code == 500 and "Invalid video url" in r.json()["error"]
@@ -378,6 +382,46 @@ def test_continuous_batcher_admits_a_late_request_between_steps_and_retires_rows
         assert f2.result(timeout=30) == "solo S:4 t=0.7" and f3.result(timeout=30).startswith("solo T:4")
         assert f1.result(timeout=30) == _want(20) and f4.result(timeout=30) == _want(4)
         assert eng.threads == b.thread_ids and threading.get_ident() not in eng.threads and len(eng.threads) == 1
+    finally:
+        b.close()
+
+
+def test_continuous_batcher_returns_the_slot_when_admission_fails_and_survives_a_failing_decode():
+    """a prefill that raises after the slot was taken used to leak the slot — after max_batch such failures the
+    free list was empty, nothing was live and the worker spun while every greedy request hung; a tokenizer error in the post-chunk loop
+    killed the worker thread.  Now the slot goes back, only the failing request fails, and a dead worker fails what it held."""
+    eng = _StubEngine(n_slots=2, step_sleep=0.0)
+    real_admit, real_decode = eng.admit, eng.decode
+
+    def admit(slot, e):
+        if e.script[0] == 100 + 0 and len(e.script) == 3 + 1 + 64:     # prompts "X:3" fail in the prefill
+            raise RuntimeError("HIP out of memory (stub)")
+        return real_admit(slot, e)
+
+    def decode(toks):
+        if len(toks) == 6:                                             # replies of 6 tokens fail in the tokenizer
+            raise ValueError("tokenizer (stub)")
+        return real_decode(toks)
+    eng.admit, eng.decode = admit, decode
+    b = serving.ContinuousBatcher(eng, max_batch=2, chunk=4)
+    try:
+        for _ in range(5):                                             # more failures than there are slots
+            with pytest.raises(RuntimeError, match="out of memory"):
+                b.submit("X:3", 48).result(timeout=30)
+        assert len([ev for ev in b.events if ev[0] == "admit_failed"]) == 5
+        assert b.submit("A:9", 48).result(timeout=30) == _want(9)     # the slots are still there
+        fa, fb, fc = b.submit("B:6", 48), b.submit("C:11", 48), b.submit("D:4", 48)
+        with pytest.raises(ValueError, match="tokenizer"):
+            fa.result(timeout=30)                                      # only this request fails ...
+        assert fb.result(timeout=30) == _want(11) and fc.result(timeout=30) == _want(4)   # ... its neighbours and successors go on
+        assert b._thread.is_alive()
+        # a worker that dies fails everything it held and everything submitted afterwards instead of hanging
+        eng.read = lambda: (_ for _ in ()).throw(KeyboardInterrupt())  # not an Exception: escapes the per-chunk handler
+        fd = b.submit("E:20", 48)
+        with pytest.raises(RuntimeError, match="worker died"):
+            fd.result(timeout=30)
+        with pytest.raises(RuntimeError, match="worker died"):
+            b.submit("F:3", 48).result(timeout=30)
     finally:
         b.close()
 

@@ -353,6 +353,16 @@ def test_reference_collated_batch_is_what_the_step_plans_on():
 # ---------------------------------------------------------------------------------------------------------------------
 # gradient accumulation: one update from several micro-batches (SFTTrainer.step_accumulated)
 # ---------------------------------------------------------------------------------------------------------------------
+def _grad_accum_reference(acc, g, out=None, mode=1):
+    """TEST stand-in for vila_grad_accum_f32 on a CPU-only host: mode 0 acc = g, 1 acc += g, 2 out = (acc + g) in g's dtype."""
+    if mode == 0:
+        acc.copy_(g)
+    elif mode == 1:
+        acc.add_(g.to(acc.dtype))
+    else:
+        out.copy_((acc + g.to(acc.dtype)).to(out.dtype))
+
+
 def _accumulation_worker(rank, world, port, q, clip):
     """Two ranks x three micro-batches.  Media appears only in SOME micro-batches of SOME ranks (rank 0: micro-batch 0; rank 1: none), and the
     LAST micro-batch is text-only everywhere — the held sums must still reach the exchange and the update of the projector / tower buckets."""
@@ -365,6 +375,7 @@ def _accumulation_worker(rank, world, port, q, clip):
         m = _tiny_model()
         ops.adamw_step = _adamw_reference
         ops.add = lambda a, b, out=None: torch.add(a, b, out=out)          # TEST stand-ins for the HIP kernels on a CPU-only host
+        ops.grad_accum = _grad_accum_reference
         ops.sumsq = lambda x: (x.double() ** 2).sum().float().reshape(1)
         tr = SFTTrainer(m, lr=1e-2, weight_decay=0.0, max_grad_norm=clip)
         tr.flat.grads = tr.flat.grads.float()
@@ -473,6 +484,7 @@ def _dp_run_worker(rank, world, port, q, out_dir):
         m = _tiny_model()
         ops.adamw_step = _adamw_reference
         ops.add = lambda a, b, out=None: torch.add(a, b, out=out)
+        ops.grad_accum = _grad_accum_reference
         ops.sumsq = lambda x: (x.double() ** 2).sum().float().reshape(1)
         tr = SFTTrainer(m, lr=0.0, weight_decay=0.0)
         tr.flat.grads = tr.flat.grads.float()

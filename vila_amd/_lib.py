@@ -159,6 +159,7 @@ PROTOTYPES = {
     "vila_silu_mul_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vila_silu_mul_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vila_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vila_grad_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vila_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "vila_norm_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vila_ce_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),

@@ -94,7 +94,7 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30) -> N
            "s2_resize_output_to_scale_idx": cfg.s2_resize_output_to_scale_idx, "image_aspect_ratio": cfg.image_aspect_ratio or None,
            "min_tiles": cfg.min_tiles, "max_tiles": cfg.max_tiles, "video_max_tiles": cfg.video_max_tiles, "chat_template": cfg.chat_template or None,
            "hidden_size": c.hidden_size,
-           "mm_hidden_size": cfg.mm_hidden_size, "image_token_id": cfg.image_token_id, "newline_token_id": cfg.newline_token_id,
+           "mm_hidden_size": cfg.mm_hidden_size, "image_token_id": cfg.image_token_id, "video_token_id": cfg.video_token_id, "newline_token_id": cfg.newline_token_id,
            "_name_or_path": output_dir}
     with open(os.path.join(output_dir, "config.json"), "w") as f:
         json.dump(top, f, indent=1)
@@ -146,7 +146,8 @@ def config_from_pretrained(model_dir: str) -> VilaConfig:
                        select_layer=opt(top, "mm_vision_select_layer", -2))
     scales = opt(top, "s2_scales", "448,896,1344")
     return VilaConfig(vision=vis, llm=llm, mm_projector_type=resolve_projector_type(top, model_dir),
-                      image_token_id=opt(top, "image_token_id", 151649), newline_token_id=opt(top, "newline_token_id", 198),
+                      image_token_id=opt(top, "image_token_id", 151649), video_token_id=opt(top, "video_token_id", 151650),
+                      newline_token_id=opt(top, "newline_token_id", 198),
                       dynamic_s2=bool(opt(top, "dynamic_s2", False)), s2_scales=tuple(int(s) for s in str(scales).split(",")),
                       s2_resize_output_to_scale_idx=opt(top, "s2_resize_output_to_scale_idx", -1),
                       image_aspect_ratio=str(opt(top, "image_aspect_ratio", "")), min_tiles=int(opt(top, "min_tiles", 1)),

@@ -756,6 +756,9 @@ extern "C" int vila_silu_mul_bwd_bf16(const void* g, const void* u, const void* 
     return launch_silu_mul_bwd(B(g), B(u), B(da), B(dg), B(du), n, S(stream));
 }
 extern "C" int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_t stream) { return launch_add(B(a), B(b), B(y), n, S(stream)); }
+extern "C" int vila_grad_accum_f32(float* acc, const void* g, void* out, int64_t n, int mode, vila_stream_t stream) {
+    return launch_grad_accum(acc, B(g), B(out), n, mode, S(stream));
+}
 extern "C" int vila_colsum_bf16(const void* x, void* out, float* scratch, int R, int C, int64_t ld, int accumulate, int period, vila_stream_t stream) {
     return launch_colsum(B(x), B(out), scratch, R, C, ld, accumulate, period, S(stream));
 }

@@ -217,10 +217,12 @@ static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 1
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
 // VILA_RING_BIG = 12 / 16: about-one-round grids of the 128x128 ring (128..288 tiles: the S = 769 q/k/v/o projections, the tower's qkv / fc1 at one
 // image) take the 3- / 4-stage 128x128 variant instead of the 128x64 ring.  Unset / 0 = off (the default until measured, gemm_ring.hip).
-// VILA_RING_SPLITK = 1: q/k/v/o-sized GEMMs of SHORT prompts (M < 512, a workspace given) take the K-sliced ring (gemm_ring_splitk.hip).
+// q/k/v/o-sized GEMMs of SHORT prompts (M < 512, a workspace given) take the K-sliced ring (gemm_ring_splitk.hip) — ON by default since round 5
+// (tools/gemm_bench prering, cold weights, profiles/r05_gemm_bench_prering.log: qkv M = 64 / 160 / 289 28.5 / 28.6 / 29.8 -> 17.8 / 20.8 / 29.5 us,
+// o_proj + residual M = 64 / 289 29.8 / 31.4 -> 14.2 / 24.3 us, Lite-3B qkv / o at M = 154 18.0 / 19.0 -> 14.6 / 12.5 us); VILA_RING_SPLITK=0 = off.
 static int ring_splitk_env() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_RING_SPLITK"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char* e = getenv("VILA_RING_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
     return v;
 }
 static int ring_big() {

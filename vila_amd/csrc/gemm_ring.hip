@@ -315,9 +315,9 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
 // S = 769 q/k/v/o launches are one round of 504 / 392 128x64 blocks that pull 677 MB through L2 for 39 MB of operands (24 KB per block and
 // K-tile); a 128x128 tile halves that traffic per flop, and what the 2-stage variant lacked at one block per CU was loads in flight.
 // variant + 100 (or VILA_RING_PIPE=1 in the environment) = the same tile with the PIPE fragment schedule.
-static int ring_pipe_env() {               // VILA_RING_PIPE = 1 / 2
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+static int ring_pipe_env() {               // VILA_RING_PIPE = 0 / 1 / 2; default 2 since round 5 (bit-identical results; cold-weight times of
+    static int v = -1;                     // profiles/r05_gemm_bench_prering.log: S = 769 qkv 44.8 -> 43.6 us, o_proj + residual 43.2 -> 42.4, ViT out_proj
+    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }   // 14.2 -> 12.8; TTFT 15.62 -> 15.44 ms)
     return v;
 }
 int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void smp_final_kernel(const uint64_t* __restri
 // Keys are a strict total order (value, then LOWER index first), so "the k most likely" and "the tokens whose more-likely mass is below top_p"
 // are both `key >= threshold` sets:
 //   T_k : 8 radix passes (one byte of the 64-bit key per pass, integer histograms) find the k-th largest key
-//   T_p : 8 passes with MASS histograms (sum of exp((v - vmax) / T) per bin; one histogram row per wave, rows added in a fixed order) descend to
+//   T_p : 8 passes with MASS histograms (sum of exp((v - vmax) / T) per bin, accumulated as 2^-40 fixed-point integers so the sums do not depend on
+//         lane arrival order; one histogram row per wave, rows added in a fixed order) descend to
 //         the smallest key whose strictly-more-likely mass is still below top_p x total  (HF TopPLogitsWarper: drop while ascending cumulative
 //         mass <= 1 - top_p; the top token always survives)
 //   draw: u in [0, kept mass) located by prefix sums over the kept tokens in INDEX order (any fixed order gives the same distribution)
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(SMPL_T) void smp_large_kernel(const float* __restri
                                                            uint64_t seed_imm, const uint64_t* __restrict__ seed_dev, const int32_t* __restrict__ counter,
                                                            int64_t* __restrict__ out, float* __restrict__ prob_out) {
     __shared__ uint32_t hist[256];
-    __shared__ float histf[SMPL_T / 64][256];
+    __shared__ unsigned long long histq[SMPL_T / 64][256];     // nucleus masses in 2^-40 fixed point: INTEGER atomics commute, so a bin's sum
+                                                               // has the same bits whatever order the lanes of a wave arrive in
     __shared__ float red[SMPL_T / 64];
     __shared__ float scan[SMPL_T];
     __shared__ uint64_t sh_key;
@@ -143,9 +145,9 @@ __global__ __launch_bounds__(SMPL_T) void smp_large_kernel(const float* __restri
     uint64_t kmax = 0;
     for (int i = tid; i < n; i += SMPL_T) { const uint64_t k = smp_key(logits[i], i); kmax = k > kmax ? k : kmax; }
     for (int o = 32; o > 0; o >>= 1) { const uint64_t t = __shfl_xor((unsigned long long)kmax, o, 64); kmax = t > kmax ? t : kmax; }
-    if ((tid & 63) == 0) ((uint64_t*)histf)[wave] = kmax;
+    if ((tid & 63) == 0) ((uint64_t*)histq)[wave] = kmax;
     __syncthreads();
-    if (tid == 0) { uint64_t m = 0; for (int w = 0; w < SMPL_T / 64; ++w) { const uint64_t t = ((uint64_t*)histf)[w]; m = t > m ? t : m; } sh_key = m; }
+    if (tid == 0) { uint64_t m = 0; for (int w = 0; w < SMPL_T / 64; ++w) { const uint64_t t = ((uint64_t*)histq)[w]; m = t > m ? t : m; } sh_key = m; }
     __syncthreads();
     kmax = sh_key;
     const float zmax = smp_val(kmax) * inv_temperature;
@@ -187,16 +189,17 @@ __global__ __launch_bounds__(SMPL_T) void smp_large_kernel(const float* __restri
         uint64_t prefix = 0;
         float above = 0.f;                                       // mass of the keys above the current prefix range
         for (int b = 7; b >= 0; --b) {
-            for (int i = tid; i < (SMPL_T / 64) * 256; i += SMPL_T) (&histf[0][0])[i] = 0.f;
+            for (int i = tid; i < (SMPL_T / 64) * 256; i += SMPL_T) (&histq[0][0])[i] = 0ull;
             __syncthreads();
             const uint64_t hi_mask = b == 7 ? 0ull : (~0ull << (8 * (b + 1)));
             for (int i = tid; i < n; i += SMPL_T) {
                 const float v = logits[i];
                 const uint64_t k = smp_key(v, i);
-                if (k >= Tk && (k & hi_mask) == prefix) atomicAdd(&histf[wave][(k >> (8 * b)) & 255u], __expf(v * inv_temperature - zmax));
+                if (k >= Tk && (k & hi_mask) == prefix)      // e <= 1 (shifted by the largest logit): e * 2^40 fits, 2^18 of them fit 64 bits
+                    atomicAdd(&histq[wave][(k >> (8 * b)) & 255u], (unsigned long long)(__expf(v * inv_temperature - zmax) * 1099511627776.0f));
             }
             __syncthreads();
-            if (tid < 256) { float m = 0.f; for (int w = 0; w < SMPL_T / 64; ++w) m += histf[w][tid]; scan[tid] = m; }
+            if (tid < 256) { unsigned long long m = 0ull; for (int w = 0; w < SMPL_T / 64; ++w) m += histq[w][tid]; scan[tid] = (float)m * (1.0f / 1099511627776.0f); }
             __syncthreads();
             if (tid == 0) {
                 // bins from the top: G(d) = above + mass of bins > d; descend into the LOWEST bin whose G is still below the threshold

@@ -21,6 +21,7 @@ int launch_act_bwd(const bf16_t* z, const bf16_t* dy, bf16_t* dz, int64_t n, int
 int launch_silu_mul_fwd(const bf16_t* g, const bf16_t* u, bf16_t* a, int64_t n, hipStream_t s);
 int launch_silu_mul_bwd(const bf16_t* g, const bf16_t* u, const bf16_t* da, bf16_t* dg, bf16_t* du, int64_t n, hipStream_t s);
 int launch_add(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream_t s);
+int launch_grad_accum(float* acc, const bf16_t* g, bf16_t* out, int64_t n, int mode, hipStream_t s);
 int launch_colsum(const bf16_t* x, bf16_t* out, float* scratch, int R, int C, int64_t ld, int accumulate, int period, hipStream_t s);
 int launch_norm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, float* scratch,
                     int rows, int cols, float eps, int rms, int accumulate, hipStream_t s);

@@ -162,6 +162,39 @@ int launch_add(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream
     return 0;
 }
 
+// gradient accumulation over the micro-batches of one update (SFTTrainer.step_accumulated): the running sum is fp32, so 8-16 micro-batches
+// (the NVILA scripts' --gradient_accumulation_steps) round to bf16 ONCE, when the last micro-batch's bucket is handed to the exchange.
+//   MODE 0: acc = g            MODE 1: acc += g            MODE 2: out = bf16(acc + g)   (acc untouched; out may alias g)
+template <int MODE>
+__global__ void grad_accum_kernel(float* __restrict__ acc, const bf16_t* g, bf16_t* out, int64_t n8) {
+    EW_LOOP(n8) {
+        const u32x4 gv = *(const u32x4*)(g + i * 8);
+        f32x4 a0, a1;
+        if (MODE != 0) { a0 = *(const f32x4*)(acc + i * 8); a1 = *(const f32x4*)(acc + i * 8 + 4); }
+        else { a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+        a0[0] += lo_bf(gv[0]); a0[1] += hi_bf(gv[0]); a0[2] += lo_bf(gv[1]); a0[3] += hi_bf(gv[1]);
+        a1[0] += lo_bf(gv[2]); a1[1] += hi_bf(gv[2]); a1[2] += lo_bf(gv[3]); a1[3] += hi_bf(gv[3]);
+        if (MODE == 2) {
+            u32x4 o;
+            o[0] = pack2bf(a0[0], a0[1]); o[1] = pack2bf(a0[2], a0[3]); o[2] = pack2bf(a1[0], a1[1]); o[3] = pack2bf(a1[2], a1[3]);
+            *(u32x4*)(out + i * 8) = o;
+        } else {
+            *(f32x4*)(acc + i * 8) = a0; *(f32x4*)(acc + i * 8 + 4) = a1;
+        }
+    }
+}
+int launch_grad_accum(float* acc, const bf16_t* g, bf16_t* out, int64_t n, int mode, hipStream_t s) {
+    VILA_REQUIRE(n % 8 == 0, "grad_accum: n %% 8");
+    VILA_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || out != nullptr), "grad_accum: mode 0 / 1 / 2 (2 needs out)");
+    if (n == 0) return 0;
+    const dim3 g_(EW_GRID(n / 8)), b_(256);
+    if (mode == 0) hipLaunchKernelGGL(grad_accum_kernel<0>, g_, b_, 0, s, acc, g, out, n / 8);
+    else if (mode == 1) hipLaunchKernelGGL(grad_accum_kernel<1>, g_, b_, 0, s, acc, g, out, n / 8);
+    else hipLaunchKernelGGL(grad_accum_kernel<2>, g_, b_, 0, s, acc, g, out, n / 8);
+    VILA_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sums: out[c] (+)= sum_r x[r][c]  (bias / position-embedding gradients).  One block per 64 columns; each of the
 // 4 waves walks a quarter of the rows with lane = column; fp32 accumulate.

@@ -305,6 +305,12 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+def grad_accum(acc: torch.Tensor, g: torch.Tensor, out: Optional[torch.Tensor] = None, mode: int = 1) -> None:
+    """Gradient accumulation in fp32 (vila_grad_accum_f32): mode 0 acc = g, 1 acc += g, 2 out = bf16(acc + g)."""
+    assert acc.dtype == torch.float32 and g.dtype == torch.bfloat16 and acc.numel() == g.numel() and acc.is_contiguous() and g.is_contiguous()
+    check(_L().vila_grad_accum_f32(acc.data_ptr(), g.data_ptr(), _p(out), g.numel(), int(mode), _stream()), "grad_accum")
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False, period: int = 0) -> None:
     assert x.dim() == 2 and x.stride(1) == 1 and out.is_contiguous()
     scratch = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32) if period == 0 else None

@@ -140,7 +140,7 @@ def video_frame_indices(frame_count: int, num_frames: int, fps: float = 0.0, vid
     (`np.round(np.linspace(0, n - 1, num_frames))`).  Pinned by tests/golden/video_sampling_ref.json = the reference's own `_load_video`
     executed over a synthetic capture."""
     if fps and fps > 0:
-        duration = frame_count / video_fps if video_fps > 0 else 0
+        duration = frame_count / video_fps if video_fps > 0 else 0    # (a container without a frame rate selects nothing: the loader raises)
         stamps = np.arange(0, duration, 1.0 / fps)[:num_frames]
         return [int(t * video_fps) for t in stamps]
     return [int(i) for i in np.round(np.linspace(0, frame_count - 1, num_frames)).astype(int)]
@@ -180,6 +180,21 @@ def load_video_frames(path: str, num_frames: int = 8, fps: float = 0.0):
         if ok:
             frames[i] = Image.fromarray(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB))
     return [frames[i] for i in idx if i in frames]
+
+
+def load_video_url_frames(url: str, num_frames: int = 8, fps: float = 0.0):
+    """A request's `video_url` -> frames.  The reference writes the body to a temp file that stays (server.py:60-78); here the file lives
+    only while it is decoded, so a long-running server does not keep one video per request on disk."""
+    import shutil
+    path = load_video(url)
+    try:
+        frames = load_video_frames(path, num_frames=num_frames, fps=fps)
+        if not frames:                       # `_load_video` itself returns [] here (media.py:62-86, pinned); a REQUEST with no frames is refused
+            raise ValueError("video_url: no frame could be selected (a container that reports no frame rate under the fps rule, or "
+                             "unreadable frames)")
+        return frames
+    finally:
+        shutil.rmtree(os.path.dirname(path), ignore_errors=True)
 
 
 def load_video(url: str) -> str:
@@ -579,7 +594,11 @@ class ContinuousBatcher:
         `fail()` with the exception the future gets."""
         from concurrent.futures import Future
         f: Future = Future()
-        self._q.put(SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f, stream=stream))
+        req = SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f, stream=stream)
+        if getattr(self, "dead", None) is not None:
+            self._fail(req, self.dead)
+            return f
+        self._q.put(req)
         return f
 
     def close(self):
@@ -624,13 +643,35 @@ class ContinuousBatcher:
             row.req.stream.end()
 
     def _loop(self):
+        """The worker: `_loop_body` under a guard — if the worker dies, everything it held and everything still queued fails with the
+        cause instead of hanging (the futures / streams of a dead worker would never resolve)."""
         import collections
+        import queue
+        pending = collections.deque()
+        rows: Dict[int, Any] = {}
+        try:
+            self._loop_body(pending, rows)
+        except BaseException as ex:                                    # noqa: BLE001 — the thread is going away either way
+            self._stop = True
+            err = RuntimeError(f"batcher worker died: {ex!r}")
+            for r in list(rows.values()):
+                self._fail(r.req, err)
+            for p in pending:
+                self._fail(p, err)
+            while True:
+                try:
+                    item = self._q.get(block=False)
+                except queue.Empty:
+                    break
+                if item is not None:
+                    self._fail(item, err)
+            self.dead = err
+
+    def _loop_body(self, pending, rows):
         import queue
         import threading
         self.thread_ids.add(threading.get_ident())
         eng = self.engine
-        pending = collections.deque()
-        rows: Dict[int, Any] = {}
         free = list(range(self.max_batch))
         steps = 0
         with torch.inference_mode():
@@ -653,6 +694,7 @@ class ContinuousBatcher:
                 # ---- admit greedy requests at the head of the line into free rows; a solo request waits for the rows to drain ----
                 while pending and free:
                     req = pending[0]
+                    slot = None                                        # the KV slot this admission took, if it got that far
                     try:
                         if not self._greedy(req) or req.gen.get("_solo"):
                             break
@@ -671,11 +713,22 @@ class ContinuousBatcher:
                             eng.release([slot])
                             free.append(slot)
                             self.events.append(("retire", slot, steps))
+                            slot = None
                         else:
                             rows[slot] = row
-                    except Exception as ex:                            # the request fails, the batch goes on
+                            slot = None                                # owned by `rows` from here on
+                    except Exception as ex:                            # the request fails, the batch goes on — and the slot goes back
                         if pending and pending[0] is req:
                             pending.popleft()
+                        if slot is not None:
+                            rows.pop(slot, None)
+                            try:
+                                eng.release([slot])
+                            except Exception:
+                                pass
+                            if slot not in free:
+                                free.append(slot)
+                            self.events.append(("admit_failed", slot, steps))
                         self._fail(req, ex)
                 if not rows:
                     if pending and (not self._greedy(pending[0]) or pending[0].gen.get("_solo")):
@@ -707,12 +760,16 @@ class ContinuousBatcher:
                 self.events.append(("run", k, len(rows)))
                 done = []
                 for slot, row in rows.items():
-                    new = out[slot][row.read:n_out[slot]]
-                    row.toks.extend(new)
-                    row.read = n_out[slot]
-                    self._emit(row, new)
-                    if any(t in eng.eos for t in row.toks) or len(row.toks) >= row.req.max_new:
-                        self._finish(row, row.toks[:row.req.max_new])
+                    try:                                               # a tokenizer / stream failure fails THIS request only
+                        new = out[slot][row.read:n_out[slot]]
+                        row.toks.extend(new)
+                        row.read = n_out[slot]
+                        self._emit(row, new)
+                        if any(t in eng.eos for t in row.toks) or len(row.toks) >= row.req.max_new:
+                            self._finish(row, row.toks[:row.req.max_new])
+                            done.append(slot)
+                    except Exception as ex:
+                        self._fail(row.req, ex)
                         done.append(slot)
                 for slot in done:
                     del rows[slot]
@@ -778,7 +835,7 @@ def create_app(model, tokenizer, model_name: str = "NVILA-8B", batch_window_s: O
                         elif c.get("type") == "video_url":           # server.py:47-52, 214-221: `frames` (default 8) / `fps` (default 2) ride in the content
                             frames = c.get("frames", 8) if c.get("frames") is not None else 8
                             fps = c.get("fps", 2) if c.get("fps") is not None else 2
-                            parts.append(Video(load_video_frames(load_video(c["video_url"]["url"]), num_frames=int(frames), fps=float(fps))))
+                            parts.append(Video(load_video_url_frames(c["video_url"]["url"], num_frames=int(frames), fps=float(fps))))
                         else:
                             raise NotImplementedError(f"Unsupported content type: {c.get('type')}")
             elif m.role == "assistant" and isinstance(m.content, str):

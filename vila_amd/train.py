@@ -335,7 +335,7 @@ class SFTTrainer:
         stream the exchange and the update of the bucket are ordered on."""
         if self._acc_mode == "add":
             a, b = self.flat.span(prefix)
-            ops.add(self._acc[a:b], self.flat.grads[a:b], out=self.flat.grads[a:b])
+            ops.grad_accum(self._acc[a:b], self.flat.grads[a:b], out=self.flat.grads[a:b], mode=2)    # bf16(fp32 sum + this one): ONE rounding
 
     def _adamw_bucket(self, prefix: str, grad_scale: float) -> None:
         """AdamW on the slice of one gradient bucket.  Semantics = torch.optim.AdamW with grad = None for what a step did not touch:
@@ -624,11 +624,10 @@ class SFTTrainer:
         """splice_plan for the step: one block per media placeholder.  The flat media space (images, then videos) is the row space of
         `_media_rows`."""
         cfg, model = self.cfg, self.model
-        lens = {"image": [int(b.numel()) for b in img_blocks]}
-        toks = {"image": cfg.image_token_id}
-        if vid_blocks:
-            lens["video"] = [int(b.numel()) for b in vid_blocks]
-            toks["video"] = cfg.video_token_id
+        # both media kinds ALWAYS take part: a `<vila/video>` token with no video supplied must raise like the reference's empty deque
+        # (llava_arch.py:462-466), not be embedded as a text token (ADVICE round 4)
+        lens = {"image": [int(b.numel()) for b in img_blocks], "video": [int(b.numel()) for b in (vid_blocks or [])]}
+        toks = {"image": cfg.image_token_id, "video": cfg.video_token_id}
         return splice_plan(input_ids, attention_mask, labels, lens, toks, "right",
                            max_length=getattr(getattr(model, "tokenizer", None), "model_max_length", None))
 
@@ -999,7 +998,7 @@ class SFTTrainer:
         targets of ALL micro-batches of the update, on all ranks, into `num_items_in_batch` — so every micro-batch's loss is its sum CE over
         that one global count and the gradients simply add up, transformer_normalize_monkey_patch.py:236-249).  Each element of
         `micro_batches` is the keyword dict of `step` (`input_ids`, `images`, `labels`, `attention_mask`, `block_sizes`, `videos`).  The earlier
-        micro-batches' gradients are held in one flat bf16 buffer; the exchange across ranks and the update happen once, bucket by bucket,
+        micro-batches' gradients are held in one flat FP32 buffer (rounded to bf16 once, with the last micro-batch's); the exchange across ranks and the update happen once, bucket by bucket,
         under the LAST micro-batch's backward (DDP's `no_sync` for the others).  Returns the update's (local) loss = sum over the micro-batches."""
         mbs = [dict(mb) for mb in micro_batches]
         if len(mbs) == 1:
@@ -1009,8 +1008,8 @@ class SFTTrainer:
         media = [len(mb.get("images") or []) + len(mb.get("videos") or []) > 0 for mb in mbs]
         n_global = self._global_counts(n_local, any(media))
         any_media = any(media) or self._media_elsewhere                    # on some rank, in some micro-batch of this update
-        if self._acc is None:
-            self._acc = torch.zeros_like(self.flat.grads)
+        if self._acc is None:                      # fp32: 8-16 micro-batches must not round to bf16 after every add
+            self._acc = torch.zeros(self.flat.grads.shape, device=self.flat.grads.device, dtype=torch.float32)
         fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
         losses = []
         try:
@@ -1024,10 +1023,7 @@ class SFTTrainer:
                 losses.append(fb(mb["input_ids"], list(mb.get("images") or []), mb["labels"], mb.get("attention_mask"), n_global,
                                  mb.get("block_sizes"), **({"videos": mb["videos"]} if mb.get("videos") else {})))
                 if not last:                         # `_finish_backward` joined the wgrad stream: the micro-batch's gradients are final here
-                    if i == 0:
-                        self._acc.copy_(self.flat.grads)
-                    else:
-                        ops.add(self._acc, self.flat.grads, out=self._acc)
+                    ops.grad_accum(self._acc, self.flat.grads, mode=0 if i == 0 else 1)
             self.optimizer_step()
         finally:
             self._bucket_step, self._acc_mode = False, None
