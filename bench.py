@@ -128,6 +128,41 @@ def init_dist(backend: str, dev=None):
     return dist
 
 
+class Deadline:
+    """A wall-clock guard around a multi-rank side measurement.  When it expires, the process prints `make_line()` (rank 0: the bench's ONE JSON
+    line; other ranks: nothing) and exits with status 0 through os._exit — the main thread may be stuck inside a collective that will never
+    complete, so nothing that needs it (atexit handlers, process-group teardown) can be waited for.  `cancel()` -> True when the guard was
+    stopped in time, False when it has fired (the caller must then stay away from stdout)."""
+
+    def __init__(self, seconds: float, make_line=None, _exit=os._exit):
+        import threading
+        self._lock = threading.Lock()
+        self._fired = False
+        self._make_line, self._exit = make_line, _exit
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def _fire(self):
+        with self._lock:
+            self._fired = True
+            try:
+                if self._make_line is not None:
+                    sys.stdout.write(self._make_line() + "\n")
+                sys.stdout.flush()
+                sys.stderr.write("bench.py: SFT side measurement hit its deadline; exiting with the decode line only\n")
+                sys.stderr.flush()
+            finally:
+                self._exit(0)
+
+    def cancel(self) -> bool:
+        with self._lock:
+            if self._fired:
+                return False
+            self._t.cancel()
+            return True
+
+
 def timed_region(dist, dev, steps: int, step_fn, sync):
     """The contract's bracket: barrier + sync, EXACTLY `steps` steps, sync + barrier, MAX over ranks."""
     sync()
@@ -748,13 +783,47 @@ def decode_main(a, rank, world, dev, dist):
                                "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                "gpu_ms_per_step_hip_events": round(ev0.elapsed_time(ev1) / a.steps, 4)}}
 
+    def line(sft, cpu):
+        value = world * a.steps / elapsed
+        return {
+            "metric": "decode tokens/sec + TTFT, NVILA-Lite-3B-shaped 1-image prompt (BASELINE configs[0] on the GPU)" if a.config == "nvila_lite_3b" else
+                      "decode tokens/sec + TTFT, NVILA-8B 1-image prompt",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / A100_DECODE_TOKS, 3) if a.config == "nvila_8b" else None,
+            "vs_baseline_note": "value / 82.1 tok/s (NVILA-8B FP16 on ONE A100, TinyChat backend, README.md:65) — other hardware and fp16; no MI355X number is published",
+            "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16",
+            "data": f"synthetic (seeded random weights at {cfg.name} shapes; U(-1,1) pixels; random prompt ids)",
+            "ttft_ms": round(ttft * 1e3, 3),
+            "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
+            "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}{' + W8A8 vision tower' if a.w8_vit else ''}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
+                                   f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                       "decode": f"hipGraph replay of {launches} launches/token" + (", kernels chained over two streams (each streams its weights under its predecessor's tail)" if chained else ""),
+                       **({"parity": "unpinned against the reference (its quantised backend, TinyChat / llm-awq, is external: no reference-held vectors); "
+                                     "pinned against the dequantise-then-fp32 oracle of the same quantised weights"} if (a.w4 or a.w8_vit) else {})},
+            "roofline": roofline,
+            "prefill": prefill,
+            "sft": sft,
+            "sustained": sustained,
+            "cpu_baseline": cpu,
+        }
+
     # ---- bounded SFT sub-measurement: 1 warm + 2 timed steps of the configs[2] per-GPU workload (needs ~150 GB of the 288 GB).  With
     # world > 1 (the driver's `bench.py --gpus N`) EVERY rank runs it with the process group: the per-layer gradient buckets go through RCCL's
     # SUM all-reduce under the backward (replaces scripts/zero3.json + transformer_normalize_monkey_patch.py:242-263), so the
-    # scaling runs exercise the 16.1 GB exchange without any extra flag. ----
+    # scaling runs exercise the 16.1 GB exchange without any extra flag.  The decode line above is complete at this point: with world > 1 a
+    # deadline guards it, so a rank that dies inside a step (the others would sit in its all-reduce until RCCL's watchdog ends the job
+    # without any output) costs the `sft` block, not the measurement. ----
     sft = None
     if not a.no_sft and not a.w4 and not a.dynamic_s2 and not a.w8_vit and a.config == "nvila_8b":
+        guard = None
+        if world > 1:
+            secs = float(os.environ.get("VILA_BENCH_SFT_DEADLINE_S", "300"))
+            guard = Deadline(secs, (lambda: json.dumps(line({"error": f"side measurement exceeded its {secs:.0f}-s deadline (a rank hung or died inside a "
+                                                                       "data-parallel step); the decode line stands", "world": world}, None))) if rank == 0 else None)
         sft = sft_side_measurement(model, cfg, a, rank, world, dev, dist)
+        if guard is not None and not guard.cancel():
+            return                                   # the deadline is already printing / exiting: leave stdout to it
 
     if rank != 0:
         if dist is not None:
@@ -763,30 +832,7 @@ def decode_main(a, rank, world, dev, dist):
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, S, os.cpu_count() or 1)
-    value = world * a.steps / elapsed
-    out = {
-        "metric": "decode tokens/sec + TTFT, NVILA-Lite-3B-shaped 1-image prompt (BASELINE configs[0] on the GPU)" if a.config == "nvila_lite_3b" else
-                  "decode tokens/sec + TTFT, NVILA-8B 1-image prompt",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": round(value / A100_DECODE_TOKS, 3) if a.config == "nvila_8b" else None,
-        "vs_baseline_note": "value / 82.1 tok/s (NVILA-8B FP16 on ONE A100, TinyChat backend, README.md:65) — other hardware and fp16; no MI355X number is published",
-        "dtype": "w4a16 (int4 group-128 weights, bf16 activations, fp32 accumulate)" if a.w4 else "bf16",
-        "data": f"synthetic (seeded random weights at {cfg.name} shapes; U(-1,1) pixels; random prompt ids)",
-        "ttft_ms": round(ttft * 1e3, 3),
-        "ttft_note": "median of 5: pixels+ids on device -> ViT(26 layers) + mm_projector + splice + 769-token prefill + argmax -> id on host",
-        "config": {"workload": f"{cfg.name} {'W4A16 decode / bf16 prefill' if a.w4 else 'bf16'}{' + W8A8 vision tower' if a.w8_vit else ''}, 1x448^2 image + {a.prompt_tokens}-token prompt (S={S}), batch 1, greedy decode, "
-                               f"context {S + a.warmup}..{S + a.warmup + a.steps}", "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                   "decode": f"hipGraph replay of {launches} launches/token" + (", kernels chained over two streams (each streams its weights under its predecessor's tail)" if chained else ""),
-                   **({"parity": "unpinned against the reference (its quantised backend, TinyChat / llm-awq, is external: no reference-held vectors); "
-                                 "pinned against the dequantise-then-fp32 oracle of the same quantised weights"} if (a.w4 or a.w8_vit) else {})},
-        "roofline": roofline,
-        "prefill": prefill,
-        "sft": sft,
-        "sustained": sustained,
-        "cpu_baseline": cpu,
-    }
-    print(json.dumps(out))
+    print(json.dumps(line(sft, cpu)))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -74,3 +74,24 @@ def test_stdout_redirect_also_catches_c_stdio_writes():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1000:]
     assert r.stdout.strip() == '{"ok": 1}' and "BANNER via C stdio" in r.stderr
+
+
+def test_deadline_guard_prints_the_decode_line_and_exits_when_the_side_measurement_hangs(capsys):
+    """bench.py's `Deadline` around the multi-rank SFT side measurement: a rank that dies inside a data-parallel step leaves the others in its
+    all-reduce; the decode line (complete by then) must still come out, once, as the last stdout line, with exit status 0."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    codes = []
+    g = bench.Deadline(30.0, lambda: '{"never": 1}', _exit=codes.append)
+    assert g.cancel() is True and codes == []                       # finished in time: nothing printed, nothing exits
+    g = bench.Deadline(0.05, lambda: '{"value": 341.0, "sft": {"error": "deadline"}}', _exit=codes.append)
+    time.sleep(0.4)
+    assert codes == [0] and g.cancel() is False                      # fired: the caller is told to stay away from stdout
+    out = capsys.readouterr()
+    assert out.out.strip().splitlines() == ['{"value": 341.0, "sft": {"error": "deadline"}}'] and "deadline" in out.err
+    g = bench.Deadline(0.05, None, _exit=codes.append)              # a rank other than 0: exits quietly
+    time.sleep(0.4)
+    assert codes == [0, 0] and capsys.readouterr().out == ""
