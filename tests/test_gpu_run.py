@@ -109,8 +109,11 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
     drift = float((d.flat.master - a.flat.master).norm()) / moved
     print(f"resumed vs uninterrupted: {drift:.2e} of the run's total weight movement; two identical uninterrupted runs: {noise:.2e}")
     assert drift <= max(5 * noise, 2e-3), (drift, noise)
-    la, ld = [r["loss"] for r in sa.log_history], [r["loss"] for r in sd.log_history]
-    assert ld[:10] == pytest.approx(la[:10], rel=2e-3) and ld[10:] == pytest.approx(la[10:], rel=2e-3), (la, ld)
+    # the logged losses of two IDENTICAL runs differ too (measured: 2e-4 relative at step 4, 6e-3 at step 10 of this 16-step run at lr 1e-3), so the
+    # resumed run's are held to the uninterrupted one's within 5x what the twin run shows at that step (at least 1 %)
+    la, lb, ld = ([r["loss"] for r in st.log_history] for st in (sa, sb, sd))
+    for k in range(16):
+        assert abs(ld[k] - la[k]) <= max(5 * abs(lb[k] - la[k]), 1e-2 * abs(la[k])), (k, la, lb, ld)
     assert [r.get("learning_rate") for r in sd.log_history] == [r.get("learning_rate") for r in sa.log_history]
 
 

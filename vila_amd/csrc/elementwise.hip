@@ -244,10 +244,11 @@ __global__ __launch_bounds__(256) void norm_block_lat_kernel(const bf16_t* __res
         }
     }
 }
-static int g_norm_lat = -1;               // -1 = VILA_NORM_LAT from the environment (default 0), 0 / 1 = forced (vila_norm_force_lat)
+static int g_norm_lat = -1;               // -1 = VILA_NORM_LAT from the environment (default 1 since round 5: bit-identical outputs, batch-8 decode
+                                          // 3.551 -> 3.497 ms per step, profiles/r05_second_call_ab.log), 0 / 1 = forced (vila_norm_force_lat)
 extern "C" void vila_norm_force_lat(int on) { g_norm_lat = on; }
 static int norm_lat() {
-    if (g_norm_lat < 0) { const char* e = getenv("VILA_NORM_LAT"); g_norm_lat = (e && e[0] == '1') ? 1 : 0; }
+    if (g_norm_lat < 0) { const char* e = getenv("VILA_NORM_LAT"); g_norm_lat = (e && e[0] == '0') ? 0 : 1; }
     return g_norm_lat;
 }
 template <bool RMS>
