@@ -21,10 +21,10 @@ void vila_decode_force_chain(int on);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible,
- * 6 / 7 = 128x64 LDS-DMA ring with 4 / 3 stages, 8 / 9 / 10 = 128x128 ring with 2 / 3 / 4 stages (9, 10: added unmeasured, see gemm_ring.hip), 11 = the K-sliced 128x64 ring of
- * gemm_ring_splitk.hip when a workspace is given (added unmeasured; environment: VILA_RING_SPLITK=1 for M < 512), 12 / 13 / 14 / 15 = the ring kernels' PIPE
- * fragment schedule on the 128x64 3-stage / 128x128 3- / 4- / 2-stage tile (added unmeasured; environment: VILA_RING_PIPE=1 for every ring launch), 16..19 = the same tiles with
- * PIPE 2 (inline-asm fragment reads retired by register-tied waits: the ks = 1 reads land under the ks = 0 MFMAs; VILA_RING_PIPE=2) */
+ * 6 / 7 = 128x64 LDS-DMA ring with 4 / 3 stages, 8 = 128x128 ring with 2 stages, 11 = the K-sliced 128x64 ring of gemm_ring_splitk.hip when a
+ * workspace is given (automatic for M < 512 since round 5; environment: VILA_RING_SPLITK=0 turns that off), 12 / 13 / 14 = rings 7 / 8 / 6 with the
+ * PIPE 2 fragment schedule (inline-asm fragment reads retired by register-tied waits: the ks = 1 reads land under the ks = 0 MFMAs; the default for
+ * every ring launch since round 5, environment: VILA_RING_PIPE=0 = plain), 15 / 16 / 17 = the same three rings with the plain schedule */
 void vila_gemm_force_tile(int tile);
 /* leftover rows (M = 256 k + r, 1 <= r <= 16) as an extra fragment of the last 256-row tile (gemm256_kernel.h, EX): -1 = VILA_GEMM_EX from the
  * environment (default 1), 0 = off, 1 = when it saves a round of tiles (and in every K-sliced launch), 2 = whenever the rows fit (tests) */
@@ -35,32 +35,9 @@ void vila_gemm_force_group(int grp);
 /* the K-sliced GEMMs' reduce takes the next block's LayerNorm / RMSNorm along (prefill down_proj -> next input_layernorm, tower fc2 -> next
  * layer_norm1): 1 = on (default), 0 = separate norm launches (A/B and the parity test of the fused kernel); environment: VILA_FUSE_NORM */
 void vila_gemm_force_fuse_norm(int on);
-/* 256x256 kernel with a residual epilogue (o_proj / down_proj / fc2 forward, dgrad + accumulated residual): request a store pass's residual words
- * before the pass instead of one dependent load per store (gemm256_kernel.h EPF; added unmeasured at the end of round 4): -1 = VILA_GEMM256_EPF from
- * the environment (default 0), 0 = off, 1 = on */
-void vila_gemm_force_epf(int on);
 /* LayerNorm / RMSNorm over rows wider than 1536 columns: every load (x, w, b) requested up front instead of x -> reduce -> w (elementwise.hip
- * norm_block_lat_kernel; added unmeasured at the end of round 4): -1 = VILA_NORM_LAT from the environment (default 0), 0 = off, 1 = on */
+ * norm_block_lat_kernel; bit-identical outputs; on by default since round 5): -1 = VILA_NORM_LAT from the environment (default 1), 0 = off, 1 = on */
 void vila_norm_force_lat(int on);
-/* decode GEMVs with an RMSNorm prologue (gate/up, qkv, lm_head): request the norm's gain by LDS-DMA ahead of x instead of one dependent load per
- * chunk after the reduction (gemv_common.h stage_x_ge; added unmeasured at the end of round 4): -1 = VILA_GEMV_GAIN_EARLY from the environment
- * (default 0), 0 = off, 1 = on.  A captured decode graph keeps the kernels it was captured with. */
-void vila_gemv_force_gain_early(int on);
-/* decode o_proj GEMV with the split-KV attention merge in its prologue: request every slice's statistics / partial outputs up front instead of one
- * dependent load per slice (gemv.hip stage_x_attn_batched; added unmeasured at the end of round 4): -1 = VILA_GEMV_MERGE_BATCH from the
- * environment (default 0), 0 = off, 1 = on */
-void vila_gemv_force_merge_batch(int on);
-/* decode attention over 256-key slices: request the wave's first K / V chunk before q is staged (gemv.hip attn_decode_head_ek; added unmeasured
- * at the end of round 4): -1 = VILA_DECODE_ATTN_EARLY_KV from the environment (default 0), 0 = off, 1 = on.
- * VILA_DECODE_LAT=1 in the environment switches all three decode-latency variants (gain early, merge batch, early K/V) on at once; the
- * individual variables and these hooks win over it. */
-void vila_decode_force_early_kv(int on);
-/* the long no-norm GEMV (down_proj): x requested first, the first weight batch behind it (gemv.hip gemv_xfirst_kernel; added unmeasured at the end
- * of round 4; also under VILA_DECODE_LAT): -1 = VILA_GEMV_X_FIRST from the environment (default 0), 0 = off, 1 = on */
-void vila_gemv_force_x_first(int on);
-/* W4 GEMVs: keep the epilogue's bf16 operands as loaded and convert them in the epilogue (gemv_w4.hip LAT variants; added unmeasured at the end of
- * round 4; also under VILA_DECODE_LAT): -1 = VILA_GEMV_W4_LAT from the environment (default 0), 0 = off, 1 = on */
-void vila_gemv_w4_force_lat(int on);
 #ifdef __cplusplus
 }
 #endif

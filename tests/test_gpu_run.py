@@ -1,9 +1,10 @@
 """GPU legs of the SFT run (vila_amd/run.py, SFTTrainer.step_accumulated) and the bit-equality tests of the kernel variants that only re-order
-instructions or requests (ring PIPE schedules, the decode-latency variants, the 256x256 kernel's epilogue prefetch).
+instructions or requests (the ring GEMMs' PIPE 2 schedule, the norm kernel with its loads requested up front) plus the K-sliced ring.
 
-Written at the end of round 4 without a GPU and gated then; first run on an MI355X in round 5 (gpurun_out/r05_first: 91 of 92 green; the one
-failure was this file's own expectation — a resumed run cannot equal the uninterrupted one BIT FOR BIT because the step's column reductions use
-fp32 atomics — now held to a measured run-to-run noise floor instead).  The gate is gone.  Host logic on CPU: tests/test_run_cpu.py,
+Written at the end of round 4 without a GPU and gated then; first run on an MI355X in round 5 (profiles/r05_pytest_gated_first.log: 91 of 92 green;
+the one failure was this file's own expectation — a resumed run cannot equal the uninterrupted one BIT FOR BIT because the step's column reductions
+use fp32 atomics — now held to a measured run-to-run noise floor instead).  The gate is gone, and so are the variants that measured no gain (the
+decode-latency kernels, the 256x256 kernel's epilogue prefetch, the compiler-scheduled PIPE 1, the 128x128 ring with 3 / 4 stages) with their tests.  Host logic on CPU: tests/test_run_cpu.py,
 tests/test_train_cpu.py."""
 import os
 
@@ -74,7 +75,10 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
                                        learning_rate=1e-3, warmup_ratio=0.1, **kw)
 
     def fresh():
-        return SFTTrainer(build_model(cfg, seed=12), lr=1e-3)
+        # eps 1e-4 instead of AdamW's 1e-8: with the default, coordinates whose gradient is pure summation-order noise (the step's column reductions
+        # use fp32 atomics) still move by lr * sign(noise) — measured on hardware, two IDENTICAL 16-step runs then end 1.9e-2 of the run's total
+        # weight movement apart and their logged losses differ by up to 3 % — which would drown what this test is looking for
+        return SFTTrainer(build_model(cfg, seed=12), lr=1e-3, eps=1e-4)
     init = fresh().flat.master.clone()
     a = fresh()
     sa = run.train(a, data, _collate(cfg), mk("a"))
@@ -109,20 +113,20 @@ def test_resumed_run_ends_with_the_weights_of_the_uninterrupted_one(tmp_path):
     drift = float((d.flat.master - a.flat.master).norm()) / moved
     print(f"resumed vs uninterrupted: {drift:.2e} of the run's total weight movement; two identical uninterrupted runs: {noise:.2e}")
     assert drift <= max(5 * noise, 2e-3), (drift, noise)
-    # the logged losses of two IDENTICAL runs differ too (measured: 2e-4 relative at step 4, 6e-3 at step 10 of this 16-step run at lr 1e-3), so the
-    # resumed run's are held to the uninterrupted one's within 5x what the twin run shows at that step (at least 1 %)
+    # the logged losses: within 5x what the twin run shows at that step, at least 2 %
     la, lb, ld = ([r["loss"] for r in st.log_history] for st in (sa, sb, sd))
     for k in range(16):
-        assert abs(ld[k] - la[k]) <= max(5 * abs(lb[k] - la[k]), 1e-2 * abs(la[k])), (k, la, lb, ld)
+        assert abs(ld[k] - la[k]) <= max(5 * abs(lb[k] - la[k]), 2e-2 * abs(la[k])), (k, la, lb, ld)
     assert [r.get("learning_rate") for r in sd.log_history] == [r.get("learning_rate") for r in sa.log_history]
 
 
-@pytest.mark.parametrize("tile", [9, 10, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("tile", [12, 13, 14])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 136), (769, 3584, 512), (1, 24, 40), (769, 4608, 3584), (1024, 3456, 1152), (513, 260, 72), (700, 520, 128)])
-def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
-    """The 128x128 LDS-DMA ring with 3 / 4 stages (gemm_ring.hip variants 12 / 16, `vila_gemm_force_tile(9 / 10)`) and the PIPE fragment schedule
-    on every ring tile (`force_tile(12..15)`): same epilogues, same tolerances as every other tile shape
-    (tests/test_gpu_ops.py::test_gemm_every_tile_shape); PIPE only re-orders instructions, so its result equals the plain variant's bit for bit."""
+def test_gemm_ring_pipe2_schedule_equals_the_plain_one_bit_for_bit(tile, M, N, K):
+    """The ring kernels' PIPE 2 fragment schedule (asm `ds_read_b128` issued ks-major, retired by register-tied waits; bias / residual requested up
+    front — the default since round 5) on the 128x64 3-stage, the 128x128 2-stage and the 128x64 4-stage ring (`vila_gemm_force_tile(12 / 13 / 14)`):
+    every epilogue within the tolerance of every other tile shape (tests/test_gpu_ops.py::test_gemm_every_tile_shape), and — it only re-orders
+    instructions and requests — BIT-EQUAL to the plain schedule of the same tile (`force_tile(15 / 16 / 17)`)."""
     from tests.gpu_util import randn_bf16, rel_l2
     from vila_amd import _lib, ops
     lib = _lib.load()
@@ -130,18 +134,19 @@ def test_gemm_ring_128x128_with_3_and_4_stages(tile, M, N, K):
     w = randn_bf16(N, K, seed=42, scale=K ** -0.5)
     bias, res = randn_bf16(N, seed=44), randn_bf16(M, N, seed=45)
     ref = a.float() @ w.float().t()
-    lib.vila_gemm_force_tile(tile)
+    outs = {}
     try:
-        assert rel_l2(ops.gemm(a, w, bias=bias, residual=res), ref + bias.float() + res.float()) < 4e-3
-        assert rel_l2(ops.gemm(a, w), ref) < 4e-3
-        assert rel_l2(ops.gemm(a, w, bias=bias, epi=1), torch.nn.functional.gelu(ref + bias.float(), approximate="tanh")) < 5e-3
-        assert rel_l2(ops.gemm(a, w, bias=bias, epi=2), torch.nn.functional.gelu(ref + bias.float())) < 5e-3
-        if tile >= 12:
-            piped = ops.gemm(a, w, bias=bias, residual=res)
-            lib.vila_gemm_force_tile({12: 7, 13: 9, 14: 10, 15: 8, 16: 7, 17: 9, 18: 10, 19: 8}[tile])     # (16..19: PIPE 2 = asm fragment reads retired by tied waits)
-            assert torch.equal(piped, ops.gemm(a, w, bias=bias, residual=res))
+        for t in (tile, tile + 3):
+            lib.vila_gemm_force_tile(t)
+            outs[t] = (ops.gemm(a, w, bias=bias, residual=res), ops.gemm(a, w), ops.gemm(a, w, bias=bias, epi=1), ops.gemm(a, w, bias=bias, epi=2))
     finally:
         lib.vila_gemm_force_tile(0)
+    o = outs[tile]
+    assert rel_l2(o[0], ref + bias.float() + res.float()) < 4e-3 and rel_l2(o[1], ref) < 4e-3
+    assert rel_l2(o[2], torch.nn.functional.gelu(ref + bias.float(), approximate="tanh")) < 5e-3
+    assert rel_l2(o[3], torch.nn.functional.gelu(ref + bias.float())) < 5e-3
+    for u, v in zip(o, outs[tile + 3]):
+        assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize("M,N,K", [(289, 4608, 3584), (64, 3584, 3584), (160, 4608, 3584), (300, 264, 1096), (1, 24, 1024), (511, 520, 2056)])
@@ -166,116 +171,6 @@ def test_gemm_ring_k_sliced_for_short_prompts(M, N, K):
         lib.vila_gemm_force_tile(0)
     assert rel_l2(out, ref) < 4e-3 and rel_l2(out, plain.float()) < 4e-3, (rel_l2(out, ref), rel_l2(out, plain.float()))
     assert torch.equal(x, out)
-
-
-def test_gain_early_staging_equals_the_plain_staging_bit_for_bit():
-    """`stage_x_ge` (gemv_common.h; `vila_gemv_force_gain_early(1)`): the RMSNorm gain arrives by LDS-DMA ahead of x instead of one dependent
-    load per chunk after the reduction.  Same values, same arithmetic: the normalising GEMVs (plain, gate/up), the decode QKV kernel and a whole
-    decode run at NVILA-8B widths must reproduce the plain staging BIT FOR BIT, eager and through a re-captured graph.  The same run flips
-    `vila_gemv_force_merge_batch`: the split-KV attention merge in the o_proj GEMV's prologue with every slice's loads requested up front (two
-    active 256-key slices at the 300-token prompt used here; same combine order)."""
-    from tests.gpu_util import randn_bf16
-    from vila_amd import _lib, ops
-    from vila_amd.vlm import build_model
-    lib = _lib.load()
-
-    def gemvs():
-        out = []
-        for N, K in ((3584, 3584), (1000, 512), (64, 1096), (6, 64), (152, 8192)):
-            x, w, w2 = randn_bf16(K, seed=27), randn_bf16(N, K, seed=28, scale=K ** -0.5), randn_bf16(N, K, seed=33, scale=K ** -0.5)
-            g = randn_bf16(K, seed=31, scale=0.1) + 1
-            out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, out_f32=True))
-            out.append(ops.gemv(x, w, norm_w=g, eps=1e-6, w2=w2))
-        for N, K in ((3584, 18944), (70, 18944), (6, 4104)):                       # long rows without a norm: gemv_xfirst_kernel when switched on
-            x, w = randn_bf16(K, seed=41), randn_bf16(N, K, seed=42, scale=K ** -0.5)
-            out.append(ops.gemv(x, w, bias=randn_bf16(N, seed=43), residual=randn_bf16(N, seed=44)))
-            out.append(ops.gemv(x, w, out_f32=True))
-        return out
-    cfg = configs.reduced_8b(layers_v=2, layers_l=3, vocab=32000)
-    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
-    model = build_model(cfg, seed=11)
-    e = (torch.randn(1, 300, cfg.llm.hidden_size, generator=torch.Generator().manual_seed(11)) * 0.5).to(torch.bfloat16).cuda()
-    runs = {}
-    try:
-        for on in (0, 1):
-            lib.vila_gemv_force_gain_early(on)
-            lib.vila_gemv_force_merge_batch(on)                  # the o_proj GEMV's attention merge with its loads batched (stage_x_attn_batched)
-            lib.vila_decode_force_early_kv(on)                   # the decode attention's first K / V chunk requested ahead of q (attn_decode_head_ek)
-            lib.vila_gemv_force_x_first(on)                      # down_proj: x requested first, the first weight batch behind it (gemv_xfirst_kernel)
-            model.llm._invalidate()
-            ids, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=10, return_logits=True, use_graph=False, eos_token_id=-1)
-            free = model.llm.generate(inputs_embeds=e, max_new_tokens=10, use_graph=True, eos_token_id=-1)
-            runs[on] = (gemvs(), ids, lg, free)
-    finally:
-        lib.vila_gemv_force_gain_early(-1)
-        lib.vila_gemv_force_merge_batch(-1)
-        lib.vila_decode_force_early_kv(-1)
-        lib.vila_gemv_force_x_first(-1)
-        model.llm._invalidate()
-    for a, b in zip(runs[0][0], runs[1][0]):
-        assert torch.equal(a, b)
-    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][3], runs[1][3])
-
-
-@pytest.mark.parametrize("n_prompt", [16, 560])
-def test_w4_o_proj_batched_merge_equals_the_plain_merge_bit_for_bit(n_prompt):
-    """`gemv_w4_kernel<5>` (`vila_gemv_force_merge_batch(1)`): the W4 o_proj kernel's attention merge with every slice's loads requested up
-    front, at two and four active 256-key slices, against MODE 4 on the same W4 model: identical logits, eager and replayed."""
-    from tests.test_gpu_w4 import _w4_model
-    from vila_amd import _lib
-    cfg = configs.reduced_8b(layers_v=2, layers_l=2, vocab=32000)
-    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
-    _, model = _w4_model(cfg, 5, (-9, -8, -7))
-    px = synthetic.make_pixels(cfg, 1, 5).to(torch.bfloat16)
-    ids = synthetic.make_prompt(cfg, n_prompt, 1, 5)[None]
-    e, _, _ = model._embed(ids, {"image": [px[0].cuda()]})
-    lib = _lib.load()
-    runs = {}
-    try:
-        for on in (0, 1):
-            lib.vila_gemv_force_merge_batch(on)
-            lib.vila_gemv_w4_force_lat(on)                       # the W4 GEMVs' LAT variants (epilogue operands converted in the epilogue)
-            lib.vila_decode_force_early_kv(on)
-            model.llm._drop_decode_session()
-            _, lg = model.llm.generate(inputs_embeds=e, max_new_tokens=6, return_logits=True, use_graph=False, eos_token_id=-1)
-            free = model.llm.generate(inputs_embeds=e, max_new_tokens=6, use_graph=True, eos_token_id=-1)
-            runs[on] = (lg, free)
-    finally:
-        lib.vila_gemv_force_merge_batch(-1)
-        lib.vila_gemv_w4_force_lat(-1)
-        lib.vila_decode_force_early_kv(-1)
-        model.llm._drop_decode_session()
-    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
-
-
-@pytest.mark.parametrize("M,N,K", [(3076, 3584, 512), (769, 3584, 1024), (300, 264, 136), (513, 260, 128), (1000, 1032, 1496)])
-def test_gemm256_epilogue_prefetch_equals_the_plain_epilogue_bit_for_bit(M, N, K):
-    """`gemm256_kernel<..., EPF>` (`vila_gemm_force_epf(1)`): a store pass's residual words requested ahead of the pass.  Forward layout (256- and
-    192-row tiles, the extra-row fragment), in place on the residual stream, and the contraction-major dgrad layout with an accumulated residual:
-    identical output to the plain epilogue."""
-    from tests.gpu_util import randn_bf16
-    from vila_amd import _lib, ops
-    lib = _lib.load()
-    a, w = randn_bf16(M, K, seed=61), randn_bf16(N, K, seed=62, scale=K ** -0.5)
-    bias, res = randn_bf16(N, seed=63), randn_bf16(M, N, seed=64)
-    dy, wt = randn_bf16(M, N, seed=65), randn_bf16(N, K, seed=66, scale=N ** -0.5)     # dgrad: dX[M,K] = dY[M,N] . W[N,K] (+ residual [M,K])
-    resk = randn_bf16(M, K, seed=67)
-    outs = {}
-    try:
-        for on in (0, 1):
-            lib.vila_gemm_force_epf(on)
-            lib.vila_gemm_force_tile(4)
-            plain = ops.gemm(a, w, bias=bias, residual=res)
-            x = res.clone()
-            ops.gemm(a, w, residual=x, out=x)
-            lib.vila_gemm_force_tile(0)
-            dx = ops.gemm_t(dy, wt, b_cm=True, residual=resk) if (N >= 128 and N % 8 == 0 and K % 8 == 0 and M >= 128) else None
-            outs[on] = (plain, x, dx)
-    finally:
-        lib.vila_gemm_force_epf(-1)
-        lib.vila_gemm_force_tile(0)
-    for u, v in zip(outs[0], outs[1]):
-        assert (u is None and v is None) or torch.equal(u, v)
 
 
 @pytest.mark.parametrize("rows,cols", [(769, 3584), (8, 3584), (16, 2048), (5, 8192), (3, 13824), (7, 1544)])

@@ -57,8 +57,7 @@ static void run_case(const Case& c, const std::vector<int>& scheds, void* ws, si
         if (sched == 9 && (c.a_cm || c.b_cm)) continue;
         // pseudo schedules 100 / 101: default kernels with the launch policy "whole rounds + K-sliced tail tiles" off / on, automatic tile choice
         // pseudo schedules 256 / 192: default kernels with that tile height forced (0 elsewhere = automatic)
-        const bool tilef = sched >= 300 && sched < 320;          // (9 / 10 / 11 / 12..15: the variants added unmeasured at the end of round 4)
-        //          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
+        const bool tilef = sched >= 300 && sched < 320;          // pseudo schedules 300 + t: default kernels with vila_gemm_force_tile(t)
         const bool grpf = sched >= 400 && sched < 420;            // pseudo schedules 400 + g: default kernels with vila_gemm_force_group(g) (0 = row-tile-fastest order)
         vila_gemm_force_group(grpf ? sched - 400 : -1);
         const bool bmf = sched == 256 || sched == 192;
@@ -219,14 +218,14 @@ int main(int argc, char** argv) {
         for (auto& c : pc) run_case(c, {300, 305, 304, 307, 308, 300, 305, 304, 307, 308}, ws, ws_bytes);
         g_cold = 0;
     }
-    if (!strcmp(what, "prering")) {    // round 5, first thing: the 128x128 ring with 3 / 4 stages (force_tile 9 / 10, written without a GPU) vs the current choices, cold weights
-        g_cold = 1;
-        std::vector<Case> pc = {
+    if (!strcmp(what, "prering")) {    // ring kernels, cold weights: the automatic choice (300) vs the 128x64 3-stage ring / the 128x128 2-stage ring with the PIPE 2
+        g_cold = 1;                    // fragment schedule (312 / 313) and with the plain one (315 / 316).  (The round-5 run of this mode, with the since-removed
+        std::vector<Case> pc = {       // PIPE 1 and 128x128 3- / 4-stage variants in it, is profiles/r05_gemm_bench_prering.log.)
             {"LLM qkv  S=769 cold", 769, 4608, 3584, 0, 0, 0}, {"LLM o+res S=769 cold", 769, 3584, 3584, 0, 0, 1},
             {"ViT qkv  M=1024 cold", 1024, 3456, 1152, 0, 0, 0}, {"ViT out+res cold", 1024, 1152, 1152, 0, 0, 1}, {"ViT fc1 cold", 1024, 4304, 1152, 0, 0, 0},
             {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0}, {"LLM o+res M=289 cold", 289, 3584, 3584, 0, 0, 1},
         };
-        for (auto& c : pc) run_case(c, {300, 307, 312, 316, 308, 315, 319, 309, 313, 317, 310, 314, 318, 300, 307, 312, 316, 308, 315, 319, 309, 313, 317, 310, 314, 318}, ws, ws_bytes);   // 312..315 = the PIPE fragment schedule on 307 / 309 / 310 / 308, 316..319 = PIPE 2 (asm reads, progressive waits)
+        for (auto& c : pc) run_case(c, {300, 312, 315, 313, 316, 300, 312, 315, 313, 316}, ws, ws_bytes);
         // short prompts: the K-sliced 128x64 ring (force_tile 11, gemm_ring_splitk.hip) vs the automatic choice and the plain ring
         std::vector<Case> sc = {
             {"LLM qkv M=64 cold", 64, 4608, 3584, 0, 0, 0}, {"LLM qkv M=160 cold", 160, 4608, 3584, 0, 0, 0}, {"LLM qkv M=289 cold", 289, 4608, 3584, 0, 0, 0},

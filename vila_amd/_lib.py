@@ -131,15 +131,9 @@ PROTOTYPES = {
     "vila_gemm_force_ex": (None, [c_int]),
     "vila_gemm_force_group": (None, [c_int]),
     "vila_gemm_force_fuse_norm": (None, [c_int]),
-    "vila_gemm_force_epf": (None, [c_int]),
     "vila_norm_force_lat": (None, [c_int]),
     "vila_decode_force_attn": (None, [c_int]),
     "vila_decode_force_chain": (None, [c_int]),
-    "vila_gemv_force_gain_early": (None, [c_int]),
-    "vila_gemv_force_merge_batch": (None, [c_int]),
-    "vila_decode_force_early_kv": (None, [c_int]),
-    "vila_gemv_force_x_first": (None, [c_int]),
-    "vila_gemv_w4_force_lat": (None, [c_int]),
     "vila_llm_decode_chain_error": (c_int, [c_void_p, c_void_p]),
     "vila_gemm_bf16_t": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

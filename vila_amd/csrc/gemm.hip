@@ -213,24 +213,13 @@ bool gemm_ring_supported(const GemmArgs& a);
 int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
 int gemm_ring_splitk_slices(const GemmArgs& a);      // gemm_ring_splitk.hip: K-sliced 128x64 ring for short prompts (unmeasured, opt-in)
 int launch_gemm_ring_splitk(const GemmArgs& a, int splits, hipStream_t s);
-static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring, 9 / 10 = 128x128 DMA ring with 3 / 4 stages, 11 = K-sliced 128x64 ring (needs a workspace), 12 / 13 / 14 / 15 = PIPE schedule on the 128x64 3-stage / 128x128 3- / 4- / 2-stage ring, 16..19 = the same with PIPE = 2
+static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring (2 stages), 11 = K-sliced 128x64 ring (needs a workspace), 12 / 13 / 14 = rings 7 / 8 / 6 with the PIPE 2 fragment schedule whatever VILA_RING_PIPE says, 15 / 16 / 17 = the same three with the plain schedule
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }
-// VILA_RING_BIG = 12 / 16: about-one-round grids of the 128x128 ring (128..288 tiles: the S = 769 q/k/v/o projections, the tower's qkv / fc1 at one
-// image) take the 3- / 4-stage 128x128 variant instead of the 128x64 ring.  Unset / 0 = off (the default until measured, gemm_ring.hip).
-// q/k/v/o-sized GEMMs of SHORT prompts (M < 512, a workspace given) take the K-sliced ring (gemm_ring_splitk.hip) — ON by default since round 5
-// (tools/gemm_bench prering, cold weights, profiles/r05_gemm_bench_prering.log: qkv M = 64 / 160 / 289 28.5 / 28.6 / 29.8 -> 17.8 / 20.8 / 29.5 us,
-// o_proj + residual M = 64 / 289 29.8 / 31.4 -> 14.2 / 24.3 us, Lite-3B qkv / o at M = 154 18.0 / 19.0 -> 14.6 / 12.5 us); VILA_RING_SPLITK=0 = off.
 static int ring_splitk_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VILA_RING_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
     return v;
 }
-static int ring_big() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_RING_BIG"); v = e ? atoi(e) : 0; if (v != 12 && v != 16) v = 0; }
-    return v;
-}
-
 // Measured and rejected (tools/gemm_bench pol, profiles/r02_gemm_bench_policies.log): slicing K four ways for ONE under-filled round with a
 // long contraction (SFT down_proj forward / dgrad of gate and up: 182 tiles, 296 K-tiles -> 728 blocks = 2.84 rounds of a quarter of the
 // work).  The slabs (4 x 44 MB written and read) eat the gain: 488 -> 481, 522 -> 545, 559 -> 544 us.
@@ -280,16 +269,13 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         // resident blocks (S=769 q/k/v 473 -> 675 TF/s, o_proj 397 -> 557, ViT fc2 168 -> 297); beyond that the 128x128 2-stage
         // ring takes over from the register-staged 128x128 kernel (SFT ViT shapes 376-590 -> 459-697, 4096^3 810 -> 1015)
         const int64_t tiles128r = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
-        if (sel >= 12 && sel <= 15) return launch_gemm_ring(a, sel == 12 ? 103 : sel == 13 ? 112 : sel == 14 ? 116 : 108, s);   // PIPE schedule
-        if (sel >= 16 && sel <= 19) return launch_gemm_ring(a, sel == 16 ? 203 : sel == 17 ? 212 : sel == 18 ? 216 : 208, s);   // PIPE = 2 (asm reads)
-        if (sel == 9) return launch_gemm_ring(a, 12, s);
-        if (sel == 10) return launch_gemm_ring(a, 16, s);
-        if (sel == 0 && ring_big() && tiles128r >= 128 && tiles128r <= 288) return launch_gemm_ring(a, ring_big(), s);
+        if (sel >= 12 && sel <= 14) return launch_gemm_ring(a, sel == 12 ? 203 : sel == 13 ? 208 : 204, s);   // PIPE = 2 explicitly
+        if (sel >= 15 && sel <= 17) return launch_gemm_ring(a, sel == 15 ? 303 : sel == 16 ? 308 : 304, s);   // plain schedule explicitly
         if (sel == 7 || (sel == 0 && tiles_ring <= 560 && tiles128r < 270)) return launch_gemm_ring(a, 3, s);
         if (sel == 6) return launch_gemm_ring(a, 4, s);
         if (sel == 8 || sel == 0) return launch_gemm_ring(a, 8, s);
     }
-    if (sel >= 6 && sel <= 19) sel = 0;
+    if (sel >= 6 && sel <= 17) sel = 0;
     if (sel == 0) {
         const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, (EPI == EPI_GATEUP) ? 64 : 128);
         if (tiles128 < 320 && EPI != EPI_GATEUP) sel = 2;

@@ -190,8 +190,6 @@ int g_gemm256_group = -1;           // tuning hook (vila_gemm_force_group): tile
 extern "C" void vila_gemm_force_group(int grp) { g_gemm256_group = grp; }
 int g_gemm256_ex = -1;             // tuning hook (vila_gemm_force_ex): see gemm256_kernel.h
 extern "C" void vila_gemm_force_ex(int mode) { g_gemm256_ex = mode; }
-int g_gemm256_epf = -1;            // tuning hook (vila_gemm_force_epf): the epilogue-prefetch kernels, see gemm256_kernel.h
-extern "C" void vila_gemm_force_epf(int on) { g_gemm256_epf = on; }
 int g_gemm256_bm = 0;              // tuning hook (vila_gemm_force_bm): 0 = prefer_bm192's rule, 192 / 256 = force that tile height
 extern "C" void vila_gemm_force_bm(int bm) { g_gemm256_bm = bm; }
 static int g_gemm256_hybrid = 1;   // tuning hook: 0 = never cut a GEMM into whole rounds + K-sliced tail

@@ -77,13 +77,10 @@ static inline int gemm256_group(int tiles_m, int tiles_n, bool gateup) {
     return tiles_m > 16 ? 4 : 0;
 }
 
-// EPF ("epilogue prefetch", added at the end of round 4 from the ISA alone, OFF by default until measured — VILA_GEMM256_EPF=1): with a residual
-// the store loop of the epilogue is `global_load_dwordx2 -> s_waitcnt vmcnt(0) -> add -> global_store`, 32 times per wave and tile (gfx950 counts
-// stores in vmcnt, so every wait also sits out the previous store): the o_proj / down_proj forward and the dgrads with an accumulated residual
-// end every 256x256 tile with 32 dependent round trips.  EPF requests a pass's 8 residual words before that pass's staging writes (4 round
-// trips per tile).  A thread reads only the residual elements it writes itself, so an in-place residual stream stays correct; same values, same
-// arithmetic: bit-identical results.
-template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256, bool EX = false, bool EPF = false>
+// (Measured and removed in round 5: an "epilogue prefetch" variant that requested a store pass's residual words ahead of the pass — the ISA shows
+// `global_load_dwordx2 -> s_waitcnt vmcnt(0) -> add -> global_store` 32 times per wave and tile with a residual.  Bit-identical results, and no
+// effect on the SFT step: 194.9 / 196.1 ms without, 195.3 / 216.0 with; profiles/r05_second_call_ab.log.)
+template <int MODE, int EPI, bool ACM, bool BCM, int SCHED, int BM = 256, bool EX = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m, int k_tiles_per_split, int tile0, int col0, int grp) {
     static_assert(BM == 256 || (BM == 192 && !ACM && (SCHED == 5 || SCHED == 6 || SCHED == 7) && MODE == 0), "192-row tiles: role-split schedules, forward-layout A");
     static_assert(!EX || (!ACM && SCHED == 7 && BM == 256 && MODE != 5), "the extra row fragment: forward-layout A, default schedule, 256-row tiles");
@@ -686,18 +683,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     for (int pl = 0; pl < PASSES; ++pl) {
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-        u32x2 rres[EPF ? 32 / RPI : 1];
-        if constexpr (EPF) {
-            if (p.residual != nullptr) {
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int gm = m0 + wr * (BM / 2) + q * 32 + it * RPI + rr0, gc = ncol0 + c4;
-                    const bool ok = gm < M && gc < N;          // out-of-range slots fetch element (0, 0) and are never used
-                    const int gmr = ok ? (p.res_mod > 0 ? gm % p.res_mod : gm) : 0;
-                    rres[it] = *(const u32x2*)(p.residual + (int64_t)gmr * p.ldr + (ok ? gc : 0));
-                }
-            }
-        }
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -732,9 +717,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                     *(f32x4*)(slab + (gm - m0) * 256 + (gc - n0)) = v;
                 } else {
                     if (p.residual != nullptr) {
-                        u32x2 rv;
-                        if constexpr (EPF) rv = rres[it];
-                        else rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
+                        const u32x2 rv = *(const u32x2*)(p.residual + (int64_t)(p.res_mod > 0 ? gm % p.res_mod : gm) * p.ldr + gc);
                         v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
                     }
                     if constexpr (MODE == 1) {
@@ -853,11 +836,6 @@ static inline bool gemm256_ex_saves_round(int M, int tiles_n) {
     return cdiv((M / 256) * tiles_n, 256) < cdiv(cdiv(M, 256) * tiles_n, 256);
 }
 
-extern int g_gemm256_epf;     // gemm256.hip: -1 = VILA_GEMM256_EPF from the environment (default 0), 0 = off, 1 = on (vila_gemm_force_epf)
-static inline int gemm256_epf() {          // the EPF kernels for MODE 0 launches with a residual (unmeasured; see the kernel's header)
-    if (g_gemm256_epf < 0) { const char* e = getenv("VILA_GEMM256_EPF"); g_gemm256_epf = (e && e[0] == '1') ? 1 : 0; }
-    return g_gemm256_epf;
-}
 // tile range [tile0, tile0 + n_tiles) of the tile order (gemm256_tile_of; n_tiles < 0: all); per = K-tiles per slice for the split modes
 template <int MODE, int EPI, bool ACM = false, bool BCM = false, int SCHED = 0, int BM = 256, bool EX = false>
 static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int tile0 = 0, int n_tiles = -1, int col0 = 0, int per = 0) {
@@ -875,18 +853,6 @@ static int launch256_t(const GemmArgs& a, hipStream_t s, int splits = 1, int til
     // fused gate/up: grouped only when this launch covers the whole grid (its whole-rounds + sliced-tail policy cuts whole tile COLUMNS)
     const bool gu_partial = (MODE == 4) || (MODE == 2 && (tile0 != 0 || n_tiles != tiles_m * tiles_n));
     const int grp = gemm256_group(tiles_m, tiles_n, gu_partial);
-    if constexpr (MODE == 0 && EPI == EPI_NONE && SCHED == 7) {           // the residual epilogues of the path: o_proj / down_proj / fc2, dgrad + residual
-        if (a.residual != nullptr && gemm256_epf()) {
-            static bool attr_set_epf = false;
-            if (!attr_set_epf) {
-                VILA_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set_epf = true;
-            }
-            hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX, true>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0, grp);
-            VILA_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     hipLaunchKernelGGL((gemm256_kernel<MODE, EPI, ACM, BCM, SCHED, BM, EX>), dim3(n_tiles, splits), dim3(512), lds, s, a, tiles_m, per, tile0, col0, grp);
     VILA_LAUNCH_CHECK();
     return 0;

@@ -37,15 +37,16 @@ template <int OFF> __device__ __forceinline__ u32x4 ring_ds_read_b128(uint32_t a
 // tile 64 x 64: 16 ds_read_b128 per 32 MFMAs).  RG_STAGES x stage bytes <= 72 KB keeps two blocks per CU, so a second wave per
 // SIMD overlaps one block's LDS reads with the other's MFMAs:  <NF=2, 3 stages> for grids of about one round (two K-tiles in
 // flight per block), <NF=4, 2 stages> for the mid-size GEMMs of the SFT step's ViT (M = 4096, N, K in 1152..4304).
-// PIPE (added at the end of round 4 from the ISA alone, OFF by default until measured — VILA_RING_PIPE=1 / vila_gemm_force_tile(12..15)): left to
-// itself the compiler issues the 12 fragment reads of a K-tile in FOUR groups, each followed by `s_waitcnt lgkmcnt(0)` and 4 MFMAs (it schedules
-// for the smallest register footprint: 82 VGPRs where 256 are free at two waves per SIMD), so every K-tile exposes the LDS round trip four times.
-// PIPE reads the ks = 0 operands first, then the ks = 1 operands, and pins "all reads, then the MFMAs" with sched_group_barrier: the counted
-// lgkmcnt waits the compiler inserts then retire the reads progressively and the ks = 1 reads land under the ks = 0 MFMAs.  Scheduling hints only:
-// the arithmetic and its order are unchanged (bit-identical results).
-// PIPE = 2 (VILA_RING_PIPE=2) goes one step further: with PIPE = 1 the compiler still waits for ALL 12 reads (`lgkmcnt(0)`) before the first MFMA.
-// Here the fragment reads are inline-asm `ds_read_b128` (invisible to the compiler's wait insertion) retired by register-tied `s_waitcnt lgkmcnt`
-// (common.h lds_wait): the ks = 0 MFMAs start when the first 4 + NF reads are back and the ks = 1 reads land under them.
+// PIPE = 2 (the default since round 5; PIPE = 0 = the plain schedule, VILA_RING_PIPE=0): left to itself the compiler issues the 12 fragment reads of
+// a K-tile in FOUR groups, each followed by `s_waitcnt lgkmcnt(0)` and 4 MFMAs (it schedules for the smallest register footprint: 82 VGPRs where
+// 256 are free at two waves per SIMD), so every K-tile exposes the LDS round trip four times.  With PIPE = 2 the fragment reads are inline-asm
+// `ds_read_b128` (invisible to the compiler's wait insertion) issued ks-major and retired by register-tied `s_waitcnt lgkmcnt` (common.h lds_wait):
+// the ks = 0 MFMAs start when the first 4 + NF reads are back and the ks = 1 reads land under them; the epilogue's bias / residual are requested
+// up front instead of one dependent round trip per store pass.  Same arithmetic in the same order: results are bit-identical (tests/test_gpu_run.py).
+// Measured (tools/gemm_bench prering, cold weights, profiles/r05_gemm_bench_prering.log): S = 769 qkv 44.8 -> 43.6 us, o_proj + residual 43.2 -> 42.4,
+// ViT qkv 18.7 -> 18.3, ViT out_proj + residual 14.2 -> 12.8; TTFT 15.53 -> 15.33 ms (profiles/r05_second_call_ab.log).  Two things built with it at
+// the end of round 4 (no GPU then) measured SLOWER or equal in the same log and are gone: a compiler-scheduled variant of the same order (PIPE = 1:
+// 44.7 / 43.3 us) and 128x128 tiles with 3 / 4 stages (46.3 / 45.1 us for qkv, 48.3 / 47.9 for o_proj: one block per CU lacks waves, not stages).
 template <int EPI, int RG_STAGES, int NF, int PIPE = 0>
 __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 72 * 1024) ? 2 : 1) void gemm_ring_kernel(GemmArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,15 +168,6 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[i][1]), __builtin_bit_cast(bf16x8, rb[j][1]), acc[i][j], 0, 0, 0);
             continue;
         }
-        if constexpr (PIPE) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[j][ks] = *(const bf16x8*)(cB + j * 16 * 128 + foff[ks]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
-            }
-        } else {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
@@ -184,19 +176,12 @@ __global__ __launch_bounds__(256, (RG_STAGES * (RG_BM + 32 * NF) * RG_BK * 2 <= 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(cA + i * 16 * 128 + foff[ks]);
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
-        if constexpr (PIPE) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);      // DS reads: the ks = 0 operands
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);      // DS reads: the ks = 1 operands
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);      // MFMAs of ks = 0 (the ks = 1 reads land under them)
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);      // MFMAs of ks = 1
-        }
     }
     __syncthreads();   // all LDS reads of the last tile done before the ring is reused as staging
 
@@ -309,36 +294,21 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
     VILA_FAIL(-1, "gemm_ring: unsupported epilogue %d", a.epi);
 }
 
-// variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU);
-// 12 / 16 = 128x128 tile with 3 / 4 stages (96 / 128 KB of LDS, one block per CU, two / three K-tiles in flight).  12 and 16 were ADDED
-// WITHOUT A GPU at the end of round 4 and are reachable only through vila_gemm_force_tile(9 / 10) / VILA_RING_BIG (off by default): the
-// S = 769 q/k/v/o launches are one round of 504 / 392 128x64 blocks that pull 677 MB through L2 for 39 MB of operands (24 KB per block and
-// K-tile); a 128x128 tile halves that traffic per flop, and what the 2-stage variant lacked at one block per CU was loads in flight.
-// variant + 100 (or VILA_RING_PIPE=1 in the environment) = the same tile with the PIPE fragment schedule.
-static int ring_pipe_env() {               // VILA_RING_PIPE = 0 / 1 / 2; default 2 since round 5 (bit-identical results; cold-weight times of
-    static int v = -1;                     // profiles/r05_gemm_bench_prering.log: S = 769 qkv 44.8 -> 43.6 us, o_proj + residual 43.2 -> 42.4, ViT out_proj
-    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }   // 14.2 -> 12.8; TTFT 15.62 -> 15.44 ms)
+// variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU).
+// + 200 = PIPE 2 explicitly, + 300 = the plain fragment schedule explicitly (tests / tools/gemm_bench); otherwise VILA_RING_PIPE decides (default 2).
+static int ring_pipe_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] == '0') ? 0 : 2; }
     return v;
 }
 int launch_gemm_ring(const GemmArgs& a, int variant, hipStream_t s) {
-    if (variant >= 200 || (variant < 100 && ring_pipe_env() == 2)) {           // PIPE = 2: asm fragment reads, progressive waits
-        variant %= 100;
-        if (variant == 16) return launch_ring_epi<4, 4, 2>(a, s);
-        if (variant == 12) return launch_ring_epi<3, 4, 2>(a, s);
+    const int pipe = variant >= 300 ? 0 : variant >= 200 ? 2 : ring_pipe_env();
+    variant %= 100;
+    if (pipe) {
         if (variant == 8) return launch_ring_epi<2, 4, 2>(a, s);
         if (variant == 4) return launch_ring_epi<4, 2, 2>(a, s);
         return launch_ring_epi<3, 2, 2>(a, s);
     }
-    if (variant >= 100 || ring_pipe_env()) {
-        variant %= 100;
-        if (variant == 16) return launch_ring_epi<4, 4, 1>(a, s);
-        if (variant == 12) return launch_ring_epi<3, 4, 1>(a, s);
-        if (variant == 8) return launch_ring_epi<2, 4, 1>(a, s);
-        if (variant == 4) return launch_ring_epi<4, 2, 1>(a, s);
-        return launch_ring_epi<3, 2, 1>(a, s);
-    }
-    if (variant == 16) return launch_ring_epi<4, 4>(a, s);
-    if (variant == 12) return launch_ring_epi<3, 4>(a, s);
     if (variant == 8) return launch_ring_epi<2, 4>(a, s);
     if (variant == 4) return launch_ring_epi<4, 2>(a, s);
     return launch_ring_epi<3, 2>(a, s);

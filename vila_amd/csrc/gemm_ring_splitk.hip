@@ -1,7 +1,10 @@
 // K-SLICED variant of the 128x64 LDS-DMA ring GEMM (gemm_ring.hip) for SHORT PROMPTS: q/k/v/o of the LLM at M < 512 rows.
 //
-// WRITTEN WITHOUT A GPU (end of round 4, no GPU minutes left): reachable only through vila_gemm_force_tile(11) / VILA_RING_SPLITK=1,
-// OFF by default, its own translation unit so that the measured default kernels are untouched.  First run: tools/r05_first_call.sh.
+// Written at the end of round 4 without a GPU, measured in round 5 and ON by default since (gemm.hip launch_t; VILA_RING_SPLITK=0 turns it off,
+// vila_gemm_force_tile(11) forces it): tools/gemm_bench prering, cold weights (profiles/r05_gemm_bench_prering.log) — qkv at M = 64 / 160 / 289
+// 28.5 / 28.6 / 29.8 -> 17.8 / 20.8 / 29.5 us, o_proj + residual at M = 64 / 289 29.8 / 31.4 -> 14.2 / 24.3 us, Lite-3B qkv / o_proj at M = 154
+// 18.0 / 19.0 -> 14.6 / 12.5 us; end to end the Lite-3B-shaped TTFT (S = 154) 8.67 -> 8.18 ms, NVILA-8B at S = 289 10.84 -> 10.82 ms
+// (profiles/r05_second_call_ab.log).
 //
 // Why (profiles/r04_gemm_bench_presmall.log): at M = 64 .. 289 the q/k/v (N = 4608, K = 3584) and o_proj launches are
 // 72 .. 216 blocks that each walk 56 K-tiles — 29-31 us whatever M is, i.e. the 33 / 26 MB of weights stream at ~1.1 TB/s, because the
@@ -25,8 +28,6 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __attribute__((aligned(16))) unsigned int g_rsk_zero_chunk[4];   // K-tail source (zero-initialised)
 
-// PIPE: the fragment schedule of gemm_ring.hip's PIPE variants (all reads of a K-tile ahead of its MFMAs); chosen by VILA_RING_PIPE=1.
-template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void gemm_ring_splitk_kernel(GemmArgs p, int tiles_m, int per, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = 2;
@@ -126,12 +127,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_splitk_kernel(GemmArgs p, in
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
-        if constexpr (PIPE) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NF, 0);
-        }
     }
     __syncthreads();
 
@@ -207,15 +202,12 @@ int launch_gemm_ring_splitk(const GemmArgs& a, int splits, hipStream_t s) {
                  (size_t)splits * a.M * a.N * 4 <= a.ws_bytes, "gemm_ring split-K: %d K tiles / %d slices / workspace %zu B do not fit", kt, splits, a.ws_bytes);
     const int tiles_m = cdiv(a.M, RS_BM), tiles_n = cdiv(a.N, RS_BN);
     const size_t lds = (size_t)RS_STAGES * (RS_BM + RS_BN) * RS_BK * 2;
-    static int pipe = -1;
-    if (pipe < 0) {
-        const char* e = getenv("VILA_RING_PIPE");
-        pipe = (e && e[0] == '1') ? 1 : 0;
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool attr_set = false;
+    if (!attr_set) {
+        VILA_HIP(hipFuncSetAttribute((const void*)gemm_ring_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
     }
-    if (pipe) hipLaunchKernelGGL(gemm_ring_splitk_kernel<true>, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
-    else hipLaunchKernelGGL(gemm_ring_splitk_kernel<false>, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
+    hipLaunchKernelGGL(gemm_ring_splitk_kernel, dim3(tiles_m * tiles_n, splits), dim3(256), lds, s, a, tiles_m, per, a.ws);
     VILA_LAUNCH_CHECK();
     const int64_t total = (int64_t)a.M * (a.N / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -59,60 +59,6 @@ __device__ __forceinline__ void stage_x_attn(const float* __restrict__ part_o, c
     __syncthreads();
 }
 
-// The same merge with its loads BATCHED ("MB": added at the end of round 4 from the ISA alone, OFF by default until measured —
-// VILA_GEMV_MERGE_BATCH=1 / vila_gemv_force_merge_batch).  stage_x_attn's `for s` loops have a run-time trip count, so the compiler emits one
-// `global_load -> s_waitcnt vmcnt(0)` per iteration: with 4 active 256-key slices that is ~8 dependent round trips for the statistics and
-// 3.5 x 4 = 14 for the partial outputs, in front of an o_proj that streams its 25.7 MB in 3.7 us (the kernel takes 9.8 us).  Here every slice's
-// word is requested up front (slots past n_active re-read slot 0 and are not used): one round trip for the statistics, one per 256-chunk pass
-// for the outputs.  Same values combined in the same order (max, sum over s = 0.., fmaf over s = 0..): bit-identical results.
-// For up to MERGE_MAXS slices (256-key slices of a cache of <= 2048 positions); the caller falls back to stage_x_attn beyond that.
-#define MERGE_MAXS 8
-__device__ __forceinline__ void stage_x_attn_batched(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active,
-                                                     int nq, bf16_t* sx, float* wsm /* [n_active*nq] */) {
-    typedef __attribute__((ext_vector_type(2))) float mb_f32x2;
-    const int tid = threadIdx.x;
-    for (int h = tid; h < nq; h += 256) {
-        float m[MERGE_MAXS], l[MERGE_MAXS];
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) {
-            const int ss = s < n_active ? s : 0;
-            const mb_f32x2 ml = *(const mb_f32x2*)(part_ml + ((int64_t)ss * nq + h) * 2);
-            m[s] = ml[0]; l[s] = ml[1];
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) M = fmaxf(M, m[s]);
-        float L = 0.f;
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) L += __expf(m[s] - M) * l[s];
-        const float invL = 1.f / L;
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) if (s < n_active) wsm[s * nq + h] = __expf(m[s] - M) * invL;
-    }
-    __syncthreads();
-    const int n4 = nq * 32;   // float4 chunks
-    for (int i = tid; i < n4; i += 256) {
-        const int h = i >> 5;
-        f32x4 pv[MERGE_MAXS];
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) {
-            const int ss = s < n_active ? s : 0;
-            pv[s] = *(const f32x4*)(part_o + ((int64_t)ss * nq) * 128 + i * 4);
-        }
-        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < MERGE_MAXS; ++s) {
-            if (s < n_active) {
-                const float w = wsm[s * nq + h];
-                o[0] = fmaf(w, pv[s][0], o[0]); o[1] = fmaf(w, pv[s][1], o[1]); o[2] = fmaf(w, pv[s][2], o[2]); o[3] = fmaf(w, pv[s][3], o[3]);
-            }
-        }
-        u32x2 r; r[0] = pack2bf(o[0], o[1]); r[1] = pack2bf(o[2], o[3]);
-        *(u32x2*)(sx + i * 4) = r;
-    }
-    __syncthreads();
-}
-
 // ---- weight streaming -----------------------------------------------------------------------------
 template <int R, int U> struct Batch { u32x4 v[U][R]; };
 
@@ -155,7 +101,7 @@ __device__ __forceinline__ void wave_rows_dot(const bf16_t* const (&wrow)[R], co
 // ------------------------------------------------------------------------------------------------
 // U = 16-B loads in flight per row and lane: 7 covers a whole K = 3584 row in ONE round trip (the short K=hidden GEMVs are
 // latency-bound), 4 is enough for the long rows (K = 18944) where many iterations pipeline anyway.
-template <int MODE, int U, bool GE = false>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials; GE: gemv_common.h stage_x_ge
+template <int MODE, int U>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
@@ -181,9 +127,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     // stores both as ONE write-through 4-byte word (gemv_common.h store_bf16_pair).
     const bool coh_out = p.chain.ctr != nullptr && p.chain.done_idx >= 0;
     float e_bias = 0.f, e_res = 0.f;
-    // GE variants keep the epilogue's operands AS LOADED and convert them in `finish`: converting at the request makes the compiler wait for them
-    // there — and, loads retiring in order, for the whole weight prefetch issued in front of them — before the staging loads can even be issued
-    bf16_t eb_raw = 0, er_raw = 0;
     auto finish = [&](int gg, float (&acc)[R]) {
         const int n = gg * 2;
         bf16_t o = 0;
@@ -193,11 +136,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
             o = f2bf(bfround(silu_f(gv)) * uv);
         } else {
             float v = lane == 0 ? acc[0] : acc[1];
-            if constexpr (GE) {        // (the empty asm pins the conversion HERE: left free, the compiler folds it back into the request)
-                uint32_t bb = eb_raw, rb = er_raw;
-                asm volatile("" : "+v"(bb), "+v"(rb));
-                e_bias = bf2f((bf16_t)bb); e_res = bf2f((bf16_t)rb);
-            }
             v += e_bias;
             if (lane < 2 && n + lane < p.N && p.y_f32 != nullptr) p.y_f32[n + lane] = v;
             if (p.residual != nullptr) v = bfround(v) + e_res;
@@ -216,18 +154,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     auto epi_fetch = [&](int gg) {
         if constexpr (MODE != 1) {
             const int nn = gg * 2 + lane;
-            if constexpr (GE) {
-                eb_raw = 0; er_raw = 0;
-                if (lane < 2 && nn < p.N) {
-                    if (p.bias != nullptr) eb_raw = p.bias[nn];
-                    if (p.residual != nullptr && p.y != nullptr) er_raw = p.residual[nn];
-                }
-            } else {
             e_bias = 0.f; e_res = 0.f;
             if (lane < 2 && nn < p.N) {
                 if (p.bias != nullptr) e_bias = bf2f(p.bias[nn]);
                 if (p.residual != nullptr && p.y != nullptr) e_res = bf2f(p.residual[nn]);
-            }
             }
         }
     };
@@ -245,17 +175,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     if constexpr (MODE == 2) {
         const int ks = p.split_keys > 0 ? p.split_keys : DEC_KS;
         const int n_active = (*p.pos_ptr + ks) / ks;             // ceil((pos+1)/ks)
-        if constexpr (GE) {                                       // (MODE 2: GE = the batched merge)
-            if (n_active <= MERGE_MAXS) stage_x_attn_batched(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
-            else stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
-        } else {
-            stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
-        }
+        stage_x_attn(p.part_o, p.part_ml, n_active, p.K >> 7, sx, scratch);
     } else if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) {
         stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);   // x comes from the kernel just waited for: sc1 loads
     } else {
-        if constexpr (GE) stage_x_ge(p.x, p.norm_w, p.eps, p.K, sx, scratch, (bf16_t*)((char*)scratch + 16));   // (the launcher adds K bf16 of LDS)
-        else stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
+        stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     }
     if (early) {
         float acc[R];
@@ -278,85 +202,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
     chain_done(p.chain);
 }
 
-// The long-row GEMV (down_proj: K = 18944, no norm) with x REQUESTED FIRST ("XF", added at the end of round 4 from the ISA alone, OFF by
-// default until measured — VILA_GEMV_X_FIRST=1 or the master switch VILA_DECODE_LAT=1).  gemv_kernel stages such an x in three passes of
-// `4 loads -> wait -> 4 LDS writes` and only then starts its weight stream (queuing the weight prefetch IN FRONT of the staging measured 13 %
-// slower: loads retire in order, so every staging wait then also waits for the weights).  Here all of a thread's x chunks (<= XF_MAXC = 10)
-// are requested at once, the first weight batch is requested BEHIND them, and the wait for x leaves the weights in flight: one round trip
-// for x instead of three, with the HBM latency of the first weights under it.  MODE 0, R = 2, U = 4, no norm, no chain; same loads, same
-// accumulation order as gemv_kernel<0, 4>: bit-identical results.
-#define XF_MAXC 10
-__global__ __launch_bounds__(256) void gemv_xfirst_kernel(GemvArgs p, int n_groups) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* sx = (bf16_t*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nch = p.K >> 3;
-    constexpr int R = 2, U = 4;
-    const int stride = gridDim.x * 4;
-    int g = blockIdx.x * 4 + wave;
-    u32x4 xr[XF_MAXC];
-#pragma unroll
-    for (int i = 0; i < XF_MAXC; ++i) {
-        const int c = tid + 256 * i;
-        xr[i] = (c < nch) ? *(const u32x4*)(p.x + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-    }
-    const bf16_t* rows[R];
-    auto rows_of = [&](int gg) {
-        const int n = gg * 2;
-        const int n1 = (n + 1 < p.N) ? n + 1 : n;
-        rows[0] = p.W + (int64_t)n * p.K; rows[1] = p.W + (int64_t)n1 * p.K;
-    };
-    bf16_t eb_raw = 0, er_raw = 0;            // as loaded; converted in `finish` (see gemv_kernel: a conversion here would drain the prefetch)
-    auto epi_fetch = [&](int gg) {
-        const int nn = gg * 2 + lane;
-        eb_raw = 0; er_raw = 0;
-        if (lane < 2 && nn < p.N) {
-            if (p.bias != nullptr) eb_raw = p.bias[nn];
-            if (p.residual != nullptr && p.y != nullptr) er_raw = p.residual[nn];
-        }
-    };
-    auto finish = [&](int gg, float (&acc)[R]) {
-        const int n = gg * 2;
-        uint32_t bb = eb_raw, rb = er_raw;
-        asm volatile("" : "+v"(bb), "+v"(rb));        // pins the conversion here: left free, the compiler folds it back into the request
-        const float e_bias = bf2f((bf16_t)bb), e_res = bf2f((bf16_t)rb);
-        float v = lane == 0 ? acc[0] : acc[1];
-        v += e_bias;
-        if (lane < 2 && n + lane < p.N && p.y_f32 != nullptr) p.y_f32[n + lane] = v;
-        if (p.residual != nullptr) v = bfround(v) + e_res;
-        const bf16_t o = f2bf(v);
-        if (p.y == nullptr) return;
-        if (lane < 2 && n + lane < p.N) p.y[n + lane] = o;
-    };
-    Batch<R, U> b0;
-    const bool has = g < n_groups;
-    // UNCONDITIONAL (a wave without a group fetches the last group's rows and drops them): behind a branch the compiler cannot count the loads
-    // issued after x and falls back to vmcnt(0) for the LDS writes below, i.e. waits for the weights as well
-    rows_of(has ? g : n_groups - 1);
-    load_batch<R, U>(rows, 0, lane, nch, b0);
-    if (has) epi_fetch(g);
-#pragma unroll
-    for (int i = 0; i < XF_MAXC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < nch) *(u32x4*)(sx + c * 8) = xr[i];
-    }
-    __syncthreads();
-    if (has) {
-        float acc[R] = {0.f, 0.f};
-        fma_batch<R, U>(b0, sx, 0, lane, nch, acc);
-        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 64 * U);
-        finish(g, acc);
-        g += stride;
-    }
-    for (; g < n_groups; g += stride) {
-        rows_of(g);
-        epi_fetch(g);
-        float acc[R] = {0.f, 0.f};
-        wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 0);
-        finish(g, acc);
-    }
-}
-
 // Grid sizing for the HBM-bound GEMVs: a multiple of the 256 CUs (the dispatcher deals blocks round-robin, so 448 blocks
 // would leave 64 CUs with half the work of the others) and at most 4 blocks (16 waves) per CU = everything resident at once;
 // waves then walk the row groups with a grid stride.
@@ -374,58 +219,6 @@ static inline int balanced_grid(int n_groups, int bpc = 0) {
     return want <= 256 ? want : cdiv(want, 256) * 256;
 }
 
-// VILA_DECODE_LAT=1: master switch for the decode-latency variants written at the end of round 4 (stage_x_ge, stage_x_attn_batched,
-// attn_decode_head<.., EK>); each also has its own variable / force hook, which wins over the master.
-static int decode_lat_switch(const char* name) {
-    const char* e = getenv(name);
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] - '0';
-    const char* m = getenv("VILA_DECODE_LAT");
-    return (m && m[0] == '1') ? 1 : 0;
-}
-static int g_attn_early_kv = -1;
-extern "C" void vila_decode_force_early_kv(int on) { g_attn_early_kv = on; }
-static int attn_early_kv() {
-    if (g_attn_early_kv >= 0) return g_attn_early_kv;
-    static int v = -1;
-    if (v < 0) v = decode_lat_switch("VILA_DECODE_ATTN_EARLY_KV");
-    return v;
-}
-static int g_x_first = -1;
-extern "C" void vila_gemv_force_x_first(int on) { g_x_first = on; }
-static int gemv_x_first() {               // gemv_xfirst_kernel for the long no-norm rows (unmeasured)
-    if (g_x_first >= 0) return g_x_first;
-    static int v = -1;
-    if (v < 0) v = decode_lat_switch("VILA_GEMV_X_FIRST");
-    return v;
-}
-static int g_gain_early = -1;             // -1 = VILA_GEMV_GAIN_EARLY from the environment (default 0), 0 / 1 = forced (vila_gemv_force_gain_early)
-extern "C" void vila_gemv_force_gain_early(int on) { g_gain_early = on; }
-static int gemv_gain_early() {            // the GE staging for the normalising GEMVs (unmeasured, see gemv_common.h stage_x_ge)
-    if (g_gain_early >= 0) return g_gain_early;
-    static int v = -1;
-    if (v < 0) v = decode_lat_switch("VILA_GEMV_GAIN_EARLY");
-    return v;
-}
-
-static int g_merge_batch = -1;            // -1 = VILA_GEMV_MERGE_BATCH from the environment (default 0), 0 / 1 = forced
-extern "C" void vila_gemv_force_merge_batch(int on) { g_merge_batch = on; }
-static int gemv_merge_batch() {           // the batched attention merge in the o_proj GEMV's prologue (unmeasured, see stage_x_attn_batched)
-    if (g_merge_batch >= 0) return g_merge_batch;
-    static int v = -1;
-    if (v < 0) v = decode_lat_switch("VILA_GEMV_MERGE_BATCH");
-    return v;
-}
-
-int gemv_merge_batch_enabled() { return gemv_merge_batch(); }      // for gemv_w4.hip (the W4 o_proj kernel's MODE 5)
-static int g_w4_lat = -1;
-extern "C" void vila_gemv_w4_force_lat(int on) { g_w4_lat = on; }
-int gemv_w4_lat_enabled() {               // gemv_w4.hip: the LAT variants of the W4 GEMVs (epilogue operands kept as loaded)
-    if (g_w4_lat >= 0) return g_w4_lat;
-    static int v = -1;
-    if (v < 0) v = decode_lat_switch("VILA_GEMV_W4_LAT");
-    return v;
-}
-
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
@@ -437,26 +230,19 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     if (a.mode == 1) {
         VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr && (uintptr_t)a.x % 16 == 0, "gemv: gate/up mode needs W2, bf16 y, aligned x");
         b.chain.done_blocks = (uint32_t)grid;
-        if (gemv_gain_early() && a.norm_w != nullptr && a.K <= 8192 && a.chain.ctr == nullptr)
-            hipLaunchKernelGGL((gemv_kernel<1, 4, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b, n_groups);
-        else hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else if (a.mode == 2) {
         VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
         lds += (size_t)a.n_splits * (a.K / 128) * 4;
         const int cap = a.grid_cap > 0 ? a.grid_cap : 256;           // the merge prologue is paid per block: default ~1 block per CU
         if (grid > cap) grid = cap;
         b.chain.done_blocks = (uint32_t)grid;
-        if (short_k && gemv_merge_batch() && a.chain.ctr == nullptr) hipLaunchKernelGGL((gemv_kernel<2, 7, true>), dim3(grid), dim3(256), lds, s, b, n_groups);
-        else if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
         else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
         b.chain.done_blocks = (uint32_t)grid;
-        if (gemv_gain_early() && a.norm_w != nullptr && short_k && a.chain.ctr == nullptr)
-            hipLaunchKernelGGL((gemv_kernel<0, 7, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b, n_groups);
-        else if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
-        else if (gemv_x_first() && a.norm_w == nullptr && a.chain.ctr == nullptr && (a.K >> 3) <= 256 * XF_MAXC)
-            hipLaunchKernelGGL(gemv_xfirst_kernel, dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
         else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
     }
     VILA_LAUNCH_CHECK();
@@ -469,7 +255,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
 // Group = 2 rows per wave: q/k heads -> the rotate-half pair {d, d+hd/2} of one head, v heads -> 2 consecutive rows.  cos/sin of the token's position come from the per-token table written by
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
-template <int U, bool GE = false>
+template <int U>
 __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
@@ -494,18 +280,12 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     // epilogue operands (position, the pair's biases, its RoPE row) are requested before the dot product, not after the reduction
     int e_pos = 0;
     float e_b0 = 0.f, e_b1 = 0.f, e_c = 1.f, e_s = 0.f;
-    bf16_t b0_raw = 0, b1_raw = 0;
     auto epi_fetch = [&](int gg) {
         if (lane >= 2) return;
         const int head = gg / gph, gi = gg % gph;
         e_pos = *p.pos_ptr;
-        if constexpr (GE) {                 // as loaded; converted in `finish` (gemv_kernel has the story)
-            b0_raw = p.bqkv != nullptr ? p.bqkv[rows_i[0]] : (bf16_t)0;
-            b1_raw = p.bqkv != nullptr ? p.bqkv[rows_i[1]] : (bf16_t)0;
-        } else {
         e_b0 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[0]]) : 0.f;
         e_b1 = p.bqkv != nullptr ? bf2f(p.bqkv[rows_i[1]]) : 0.f;
-        }
         if (head < p.nq + p.nkv) { e_c = p.rope_cs[gi]; e_s = p.rope_cs[half + gi]; }
     };
     auto finish = [&](int gg, float (&acc)[2]) {
@@ -513,11 +293,6 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         const int head = gg / gph;
         const bool is_v = head >= p.nq + p.nkv;
         const int pos = e_pos;
-        if constexpr (GE) {
-            uint32_t r0 = b0_raw, r1 = b1_raw;
-            asm volatile("" : "+v"(r0), "+v"(r1));
-            e_b0 = bf2f((bf16_t)r0); e_b1 = bf2f((bf16_t)r1);
-        }
         const float lo = bfround(acc[0] + e_b0);
         const float hi = bfround(acc[1] + e_b1);
         float out = lane ? hi : lo;
@@ -540,7 +315,6 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     if (has) { rows_of(g); load_batch<2, U>(rows, 0, lane, nch, b0); epi_fetch(g); }
     chain_wait(p.chain);
     if (p.chain.ctr != nullptr && p.chain.wait_idx >= 0) stage_x<true>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
-    else if constexpr (GE) stage_x_ge(p.x, p.norm_w, p.eps, p.K, sx, scratch, (bf16_t*)((char*)scratch + 16));
     else stage_x<false>(p.x, p.norm_w, p.eps, p.K, sx, scratch);
     if (has) {
         float acc[2] = {0.f, 0.f};
@@ -567,9 +341,7 @@ int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out) {
     const int grid = balanced_grid(n_groups, a.max_bpc);
     QkvDecodeArgs b = a;
     b.chain.done_blocks = (uint32_t)grid;
-    if (a.K <= 3584 && gemv_gain_early() && a.norm_w != nullptr && a.chain.ctr == nullptr)
-        hipLaunchKernelGGL((qkv_decode_kernel<7, true>), dim3(grid), dim3(256), lds + ((size_t)a.K * 2 + 15) / 16 * 16, s, b);
-    else if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
+    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
     else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(grid), dim3(256), lds, s, b);
     VILA_LAUNCH_CHECK();
     if (grid_out != nullptr) *grid_out = grid;
@@ -805,118 +577,6 @@ __global__ __launch_bounds__(1024) void attn_decode_head(AttnDecodeArgs p) {
     }
 }
 
-// attn_decode_head<true> with EARLY KEYS ("EK", added at the end of round 4 from the ISA alone, OFF by default until measured —
-// VILA_DECODE_ATTN_EARLY_KV=1 or the master switch VILA_DECODE_LAT=1): the kernel's start is three dependent round trips — the position, then
-// q (load -> wait -> LDS -> barrier), then the wave's first K / V chunk.  q and the chunk do not depend on each other: here the chunk is
-// requested BEFORE q is staged, so the two travel together.  Same loads, same arithmetic: bit-identical results.  A copy of the kernel, not a
-// template flag: re-ordering the declarations inside the shared body changed the DEFAULT instantiations' code (checked in the ISA).
-__global__ __launch_bounds__(1024) void attn_decode_head_ek(AttnDecodeArgs p) {
-    constexpr bool SPLIT = true;
-    __shared__ float sq[128];
-    __shared__ float so[16][128];
-    __shared__ float sml[16][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, kvh = h / (p.nq / p.nkv);
-    const int key_lo = SPLIT ? blockIdx.y * 256 : 0;
-    const int row = blockIdx.z;                                  // batched decode: sequence = cache slot (0 for the batch-1 step)
-    p.q += row * p.q_row_stride; p.kcache += row * p.slot_stride; p.vcache += row * p.slot_stride;
-    if (!SPLIT) p.o += row * p.o_row_stride;
-    const int nkeys_all = p.pos_ptr[row] + 1;
-    if (SPLIT && key_lo >= nkeys_all) return;                    // block-uniform: slices beyond the context write nothing (the merge skips them)
-    const int nkeys = SPLIT ? (nkeys_all < key_lo + 256 ? nkeys_all : key_lo + 256) : nkeys_all;
-    const bf16_t* kb = p.kcache + (int64_t)kvh * p.max_ctx * 128;
-    const bf16_t* vb = p.vcache + (int64_t)kvh * p.max_ctx * 128;
-    const int kq = lane >> 2, qd = lane & 3;        // scores: key within the chunk, d quarter
-    const int sg = lane >> 4, dc = lane & 15;       // P.V: 4-key subgroup, d chunk
-    u32x4 kc[4], vc[4], kn_[4], vn_[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { kn_[j] = (u32x4){0u, 0u, 0u, 0u}; vn_[j] = (u32x4){0u, 0u, 0u, 0u}; }
-    auto load_chunk = [&](int k0, u32x4 (&kk)[4], u32x4 (&vv)[4]) {
-        const int key = k0 + kq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kk[j] = (key < nkeys) ? *(const u32x4*)(kb + (int64_t)key * 128 + qd * 32 + j * 8) : (u32x4){0u, 0u, 0u, 0u};
-            const int vk = k0 + sg * 4 + j;
-            vv[j] = (vk < nkeys) ? *(const u32x4*)(vb + (int64_t)vk * 128 + dc * 8) : (u32x4){0u, 0u, 0u, 0u};
-        }
-    };
-    int k0 = key_lo + wave * 16;
-    if (k0 < nkeys) load_chunk(k0, kc, vc);           // EK: the wave's first K / V chunk is requested BEFORE q is staged
-    if (tid < 128) sq[tid] = bf2f(p.q[h * 128 + tid]) * p.scale;
-    __syncthreads();
-    float qr[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) qr[i] = sq[qd * 32 + i];
-    float m = -INFINITY, l = 0.f, o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-
-    for (; k0 < nkeys; k0 += 256) {
-        const int kn = k0 + 256;
-        if (kn < nkeys) load_chunk(kn, kn_, vn_);            // prefetch the wave's next chunk under this chunk's math
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a = fmaf(lo_bf(kc[j][e]), qr[j * 8 + 2 * e], a);
-                a = fmaf(hi_bf(kc[j][e]), qr[j * 8 + 2 * e + 1], a);
-            }
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        const float s = (k0 + kq < nkeys) ? a : -INFINITY;
-        float cm = s;
-        cm = fmaxf(cm, __shfl_xor(cm, 4, 64)); cm = fmaxf(cm, __shfl_xor(cm, 8, 64));
-        cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-        const float m_new = fmaxf(m, cm);
-        const float alpha = __expf(m - m_new);
-        const float pr = __expf(s - m_new);
-        float ps = pr;
-        ps += __shfl_xor(ps, 4, 64); ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
-        l = l * alpha + ps;
-        m = m_new;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] *= alpha;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pj = __shfl(pr, (sg * 4 + j) * 4, 64);   // probability of key k0 + sg*4 + j (held by lanes 4*key .. 4*key+3)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[2 * e] = fmaf(pj, lo_bf(vc[j][e]), o[2 * e]);
-                o[2 * e + 1] = fmaf(pj, hi_bf(vc[j][e]), o[2 * e + 1]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { kc[j] = kn_[j]; vc[j] = vn_[j]; }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
-    if (lane < 16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) so[wave][dc * 8 + e] = o[e];
-    }
-    if (lane == 0) { sml[wave][0] = m; sml[wave][1] = l; }
-    __syncthreads();
-    if (tid < 128) {
-        float M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) M = fmaxf(M, sml[w][0]);
-        float L = 0.f, acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const float wgt = __expf(sml[w][0] - M);
-            L += wgt * sml[w][1];
-            acc += wgt * so[w][tid];
-        }
-        if (SPLIT) {
-            const int64_t slot = (int64_t)blockIdx.y * p.nq + h;
-            p.part_o[slot * 128 + tid] = acc;
-            if (tid == 0) { p.part_ml[slot * 2] = M; p.part_ml[slot * 2 + 1] = L; }
-        } else {
-            p.o[h * 128 + tid] = f2bf(acc / L);
-        }
-    }
-}
 
 // batched decode: one block per (query head, sequence) over the sequence's whole context (caches up to 2048 positions)
 int launch_attn_decode_rows(const AttnDecodeArgs& a0, int n_rows, int64_t q_row_stride, int64_t o_row_stride, int64_t slot_stride, hipStream_t s) {
@@ -935,8 +595,7 @@ int launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: n_splits too small for max_ctx");
     if (a.split256) {                                            // partials per 256-key slice; merged by the o_proj GEMV (mode 2, split_keys 256)
         VILA_REQUIRE(a.max_ctx <= 2048 && a.n_splits * DEC_KS >= a.max_ctx, "attn_decode: 256-key slices need max_ctx <= 2048");
-        if (attn_early_kv()) hipLaunchKernelGGL(attn_decode_head_ek, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(attn_decode_head<true>, dim3(a.nq, cdiv(a.max_ctx, 256)), dim3(1024), 0, s, a);
         VILA_LAUNCH_CHECK();
         if (grid_out != nullptr) *grid_out = a.nq * cdiv(a.max_ctx, 256);
         return 0;

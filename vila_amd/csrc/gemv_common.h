@@ -149,56 +149,3 @@ __device__ __forceinline__ void stage_x(const bf16_t* x, const bf16_t* __restric
     __syncthreads();
 }
 
-// stage_x with the RMSNorm GAIN REQUESTED EARLY ("GE": added at the end of round 4 from the ISA alone, OFF by default until measured —
-// VILA_GEMV_GAIN_EARLY=1).  In stage_x's single-pass path the gain is fetched inside the per-chunk `if (c < nch)` AFTER the reduction and its
-// barrier, and the compiler emits `global_load_dwordx4 -> s_waitcnt vmcnt(0) -> scale -> ds_write_b128` FOUR times in a row: four dependent L2
-// round trips on the critical path of every block of the gate/up, qkv and lm_head GEMVs (each vmcnt(0) also drains the weight prefetch).
-// Here the gain goes into LDS (`sg`, K bf16 behind the scratch words) by LDS-DMA, requested BEFORE x: no VGPR holds it while x, the weight
-// prefetch and the reduction are live (a register copy measured 136 VGPRs = 3 waves per SIMD instead of 4 in the resource report), it has
-// landed when the wait for x returns (loads retire in order), and after the barrier each thread reads back the chunk its own wave requested.
-// Same values, same arithmetic, same order: bit-identical results.  A separate function so that stage_x — and with it every default kernel —
-// compiles to the code that was measured.  Caller guarantees: norm_w != nullptr, K <= 8192, sg 16-B aligned with room for K bf16.
-__device__ __forceinline__ void stage_x_ge(const bf16_t* x, const bf16_t* __restrict__ norm_w, float eps, int K, bf16_t* sx, float* scratch,
-                                           bf16_t* sg) {
-    typedef __attribute__((address_space(3))) void ge_lds_void;
-    typedef const __attribute__((address_space(1))) void ge_gbl_void;
-    const int tid = threadIdx.x, nch = K >> 3;
-    const int lane = tid & 63;
-    const int wave_c0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 64);          // first chunk of this wave inside a 256-chunk pass
-    constexpr int MAXC = 4;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c0 = 256 * i + wave_c0;                                          // wave-uniform
-        if (c0 < nch) {
-            int c = c0 + lane; c = c < nch ? c : nch - 1;                          // lanes past the end fetch a valid chunk nobody reads
-            __builtin_amdgcn_global_load_lds((ge_gbl_void*)(norm_w + c * 8), (ge_lds_void*)((char*)sg + c0 * 16), 16, 0, 0);
-        }
-    }
-    u32x4 v[MAXC];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = tid + 256 * i;
-        v[i] = (c < nch) ? *(const u32x4*)(x + c * 8) : (u32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float a = lo_bf(v[i][k]), b = hi_bf(v[i][k]); s += a * a + b * b; }
-    }
-    s = wave_sum(s);
-    if ((tid & 63) == 0) scratch[tid >> 6] = s;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // the gain DMAs (issued before x, which has been consumed)
-    __syncthreads();
-    const float rstd = rsqrtf((scratch[0] + scratch[1] + scratch[2] + scratch[3]) / K + eps);
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < nch) {
-            const u32x4 g = *(const u32x4*)(sg + c * 8);
-            u32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                o[k] = pack2bf(lo_bf(g[k]) * bfround(lo_bf(v[i][k]) * rstd), hi_bf(g[k]) * bfround(hi_bf(v[i][k]) * rstd));
-            *(u32x4*)(sx + c * 8) = o;
-        }
-    }
-    __syncthreads();
-}

@@ -22,11 +22,6 @@
 
 #define W4_MAX_WAVES 16
 
-int gemv_merge_batch_enabled();            // gemv.hip: VILA_GEMV_MERGE_BATCH / vila_gemv_force_merge_batch
-static int w4_merge_batch() { return gemv_merge_batch_enabled(); }
-int gemv_w4_lat_enabled();                 // gemv.hip: VILA_GEMV_W4_LAT / VILA_DECODE_LAT / vila_gemv_w4_force_lat
-static int w4_lat() { return gemv_w4_lat_enabled(); }
-
 // stage x (optionally RMS-normalised, HF rounding order) as bf16 into LDS + the per-group sums of the staged values; any blockDim
 // that is a multiple of 64.  Chunk c = 8 consecutive elements; 16 consecutive chunks (= 16 consecutive lanes) form a group.
 __device__ __forceinline__ void stage_x_w4(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, float eps, int K,
@@ -142,71 +137,10 @@ __device__ __forceinline__ void stage_x_attn_w4(const float* __restrict__ part_o
     __syncthreads();
 }
 
-// stage_x_attn_w4 with its loads BATCHED (gemv.hip stage_x_attn_batched has the story: the run-time `for s` loops compile to one dependent
-// round trip per slice and pass).  Added unmeasured at the end of round 4; MODE 5 of the kernel, chosen by VILA_GEMV_MERGE_BATCH=1 /
-// vila_gemv_force_merge_batch(1).  Same values, same combine order: bit-identical.  Up to W4_MERGE_MAXS slices, else the plain function.
-#define W4_MERGE_MAXS 8
-__device__ __forceinline__ void stage_x_attn_w4_batched(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_active, int nq,
-                                                        bf16_t* sx, float* xg, float* wsm /* [n_active * nq] */) {
-    typedef __attribute__((ext_vector_type(2))) float mb_f32x2;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int h = tid; h < nq; h += nt) {
-        float m[W4_MERGE_MAXS], l[W4_MERGE_MAXS];
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
-            const int ss = s < n_active ? s : 0;
-            const mb_f32x2 ml = *(const mb_f32x2*)(part_ml + ((int64_t)ss * nq + h) * 2);
-            m[s] = ml[0]; l[s] = ml[1];
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) M = fmaxf(M, m[s]);
-        float L = 0.f;
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) L += __expf(m[s] - M) * l[s];
-        const float invL = 1.f / L;
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) if (s < n_active) wsm[s * nq + h] = __expf(m[s] - M) * invL;
-    }
-    __syncthreads();
-    const int nch = nq * 16;
-    for (int c = tid; c < nch; c += nt) {
-        const int h = c >> 4;
-        f32x4 p0[W4_MERGE_MAXS], p1[W4_MERGE_MAXS];
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
-            const int ss = s < n_active ? s : 0;
-            const float* src = part_o + ((int64_t)ss * nq) * 128 + c * 8;
-            p0[s] = *(const f32x4*)src; p1[s] = *(const f32x4*)(src + 4);
-        }
-        float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < W4_MERGE_MAXS; ++s) {
-            if (s < n_active) {
-                const float w = wsm[s * nq + h];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { e[k] = fmaf(w, p0[s][k], e[k]); e[4 + k] = fmaf(w, p1[s][k], e[4 + k]); }
-            }
-        }
-        u32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { o[k] = pack2bf(e[2 * k], e[2 * k + 1]); e[2 * k] = lo_bf(o[k]); e[2 * k + 1] = hi_bf(o[k]); }
-        *(u32x4*)(sx + c * 8) = o;
-        float a = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
-        if ((c & 15) == 0) xg[h] = a;
-    }
-    __syncthreads();
-}
-
-// MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials (5: with the batched merge) ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
+// MODE 0: y = W x (+bias)(+residual) ; 4: the same with x merged from attention partials ; 1: rows interleaved gate/up, y = silu(g) * u ; 3: fused QKV + bias + RoPE + KV append
 // (q/k rows interleaved so RoPE partners i, i + hd/2 are neighbours).  UB = groups (KB) per wave and item; PIPE = the next
 // item's weights are issued before the current item is consumed (persistent blocks walking several tiles).
-// LAT (added unmeasured at the end of round 4, with the bf16 GEMVs' GE variants — gemv.hip): the epilogue's bf16 operands are kept AS LOADED and
-// converted in the epilogue.  Converted at the request, the compiler waits for them there with vmcnt(0), which also drains the weight batch issued
-// in front of them before the staging loads are issued.  VILA_GEMV_W4_LAT=1 or the master switch VILA_DECODE_LAT=1.
-template <int MODE, int UB, bool PIPE, bool LAT = false>
+template <int MODE, int UB, bool PIPE>
 __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, G = K >> 7;
@@ -235,34 +169,11 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     };
     // operands of the epilogue (bias / residual / RoPE row), fetched by the 16 epilogue lanes when a tile starts
     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-    bf16_t r0 = 0, r1 = 0;                         // LAT: e0 / e1 as loaded
     int pos = 0;
     auto epi_fetch = [&](int tile_) {
         if (tid >= 16) return;
         const int pr = tile_ * 16 + tid;
-        if constexpr (LAT) {
-            r0 = 0; r1 = 0;
-            if (MODE == 0 || MODE == 4 || MODE == 5) {
-                if (pr < p.N) {
-                    if (p.bias != nullptr) r0 = p.bias[pr];
-                    if (p.residual != nullptr) r1 = p.residual[pr];
-                }
-            } else if (MODE == 3) {
-                const int head = pr / p.hd, within = pr - head * p.hd;
-                if (head < p.nq + 2 * p.nkv) {
-                    pos = *p.pos_ptr;
-                    if (head >= p.nq + p.nkv) {
-                        if (p.bias != nullptr) r0 = p.bias[pr];
-                    } else {
-                        const int i = within >> 1, b = within & 1;
-                        if (p.bias != nullptr) { r0 = p.bias[head * p.hd + i + b * half]; r1 = p.bias[head * p.hd + i + (b ^ 1) * half]; }
-                        e2 = p.rope_cs[i]; e3 = p.rope_cs[half + i];
-                    }
-                }
-            }
-            return;
-        }
-        if (MODE == 0 || MODE == 4 || MODE == 5) {
+        if (MODE == 0 || MODE == 4) {
             if (pr < p.N) {
                 e0 = p.bias != nullptr ? bf2f(p.bias[pr]) : 0.f;
                 e1 = p.residual != nullptr ? bf2f(p.residual[pr]) : 0.f;
@@ -290,10 +201,6 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
     if constexpr (MODE == 4) {
         const int n_active = (*p.pos_ptr + p.split_keys) / p.split_keys;     // ceil((pos + 1) / split_keys)
         stage_x_attn_w4(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
-    } else if constexpr (MODE == 5) {
-        const int n_active = (*p.pos_ptr + p.split_keys) / p.split_keys;
-        if (n_active <= W4_MERGE_MAXS) stage_x_attn_w4_batched(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
-        else stage_x_attn_w4(p.part_o, p.part_ml, n_active, K >> 7, sx, xg, scratch + W4_MAX_WAVES);
     } else {
         stage_x_w4(p.x, p.norm_w, p.eps, K, sx, xg, scratch);
     }
@@ -331,12 +238,7 @@ __global__ __launch_bounds__(1024) void gemv_w4_kernel(GemvW4Args p, int n_tiles
                 float v = 0.f, vp = 0.f;                        // own row and the partner row (n ^ 1)
                 for (int i = 0; i < W; ++i) { v += rd[i * 16 + tid]; vp += rd[i * 16 + (tid ^ 1)]; }
                 const int pr = tile * 16 + tid;                 // packed row
-                if constexpr (LAT) {                            // (the empty asm pins the conversion here)
-                    uint32_t a0 = r0, a1 = r1;
-                    asm volatile("" : "+v"(a0), "+v"(a1));
-                    e0 = bf2f((bf16_t)a0); e1 = bf2f((bf16_t)a1);
-                }
-                if (MODE == 0 || MODE == 4 || MODE == 5) {
+                if (MODE == 0 || MODE == 4) {
                     if (pr < p.N) {
                         v += e0;
                         if (p.residual != nullptr) v = bfround(v) + e1;
@@ -414,12 +316,9 @@ int launch_gemv_w4(const GemvW4Args& a, hipStream_t s) {
         lds += (size_t)a.n_splits * G * 4;                     // the merge weights [n_splits][heads]
     }
     VILA_REQUIRE(lds <= 160 * 1024, "gemv_w4: K=%d does not fit the 160 KB LDS", a.K);
-    const bool lat = w4_lat() && a.mode != 1;                  // (the gate/up mode has no epilogue operands)
-#define W4_LAUNCH(MODE, UB_, PIPE_) do { if (lat) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_, true>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles); \
-                                         else hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles); } while (0)
+#define W4_LAUNCH(MODE, UB_, PIPE_) hipLaunchKernelGGL((gemv_w4_kernel<MODE, UB_, PIPE_>), dim3(grid), dim3(W * 64), lds, s, a, n_tiles)
     if (a.mode == 1) { if (pipe) W4_LAUNCH(1, 7, true); else W4_LAUNCH(1, 7, false); }
     else if (a.mode == 3) W4_LAUNCH(3, 7, false);
-    else if (a.mode == 4 && w4_merge_batch()) { if (pipe) W4_LAUNCH(5, 7, true); else W4_LAUNCH(5, 7, false); }
     else if (a.mode == 4) { if (pipe) W4_LAUNCH(4, 7, true); else W4_LAUNCH(4, 7, false); }
     else if (deep) W4_LAUNCH(0, 10, false);
     else if (pipe) W4_LAUNCH(0, 7, true);
