@@ -6,9 +6,6 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p "$O"
 timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -25 > "$O/val_pytest.log"
-# tests written while no GPU was available (skipped by default until seen green once): run them apart so they cannot stop the suite above
-VILA_TEST_UNVERIFIED=1 timeout 600 python -m pytest tests/test_gpu_run.py -m gpu -q -s 2>&1 | tail -40 > "$O/val_pytest_unverified.log"
-tail -3 "$O/val_pytest_unverified.log"
 tail -3 "$O/val_pytest.log"
 for i in 1 $([ -z "$VAL_LIGHT" ] && echo 2); do
   timeout 300 python bench.py --mode sft --steps 4 --warmup 2 2>"$O/val_sft_$i.err" | tee "$O/val_sft_$i.json" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sft ->', d['ms_per_step'], 'ms  loss', d.get('loss'))"
@@ -70,7 +67,7 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemv_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemm256_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
 done
-python tools/pmc_traffic_json.py "$O/val_pmc_hbm_counters.txt" "$O/val_pmc_traffic.json" r04 | cut -c1-200
+python tools/pmc_traffic_json.py "$O/val_pmc_hbm_counters.txt" "$O/val_pmc_traffic.json" r05 | cut -c1-200
 find "$O" -path "*pmc_val_*" -name "*.db" -delete
 # HBM traffic of the contraction-major (wgrad) GEMMs with THIS build's tile order (the round-3 json predated the 8 x 4 patches)
 timeout 900 bash tools/pmc_gemm_sft.sh 2>&1 | tail -6
