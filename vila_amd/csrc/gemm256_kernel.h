@@ -144,26 +144,51 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
     // DMA (s_load + s_waitcnt lgkmcnt(0)), and that wait also drains every LDS fragment read in flight
     const bf16_t* zero_src = (const bf16_t*)g_zero_chunk;
     asm volatile("" : "+s"(zero_src));
-    // source pointer of one piece; tiles that lie entirely inside K (block-uniform test) take the plain address, a ragged LAST K-tile the per-lane
-    // select against the zero chunk
-    auto piece_src = [&](int k0, bool is_b, int h, int i) -> const bf16_t* {
-        const bool cm = is_b ? BCM : ACM;
-        const bf16_t* base = is_b ? ((GU && b_up[h][i]) ? p.W2 : p.W) : p.A;
-        const uint32_t off = is_b ? boff[h][i] : aoff[h][i];
-        const int64_t ld = is_b ? p.ldw : p.lda;
-        const bf16_t* src = cm ? base + off + (int64_t)k0 * ld : base + off + k0;
-        if (k0 + T256_BK > p.K) {
-            const bool kin = cm ? (k0 + cm_k + 32 * i < p.K) : (k0 + kch * 8 < p.K);
-            src = kin ? src : zero_src;
-        }
-        return src;
-    };
-    // one piece = one LDS-DMA per thread (8 KB): which in {A, B}, half h, round i
-    auto issue_piece = [&](int t, int buf, bool is_b, int h, int i) {
+    // One piece = one LDS-DMA per thread (8 KB): which in {A, B}, half h, round i.
+    // Round 5: the address is formed as  WAVE-UNIFORM 64-bit base (operand pointer + this K-tile's offset, SALU)  +  per-lane 32-bit BYTE offset
+    // (fixed for the whole kernel), which the compiler encodes as the `saddr + voffset` form of global_load_lds: m0 + the load, 2 instructions per
+    // piece.  Before, the ISA of the K loop carried 7 per piece — v_lshl_add_u64 for the 64-bit per-lane pointer and FOUR v_cndmask for the K-tail
+    // select against the zero chunk, which the compiler had if-converted into every tile although only a ragged LAST tile needs it (K % 64 != 0:
+    // the wgrads' T = 3076, the tower's K = 4304) — 8 pieces x 5 VALU per wave and K-tile inside the read / issue phases that pace the loop.
+    // A ragged last tile now takes a real branch (the asm statement behind its load keeps the two loads from being merged back into a select).
+    // gemm256_supported() bounds every element offset by 2^31, so the byte offsets fit 32 bits.
+    uint32_t aoffb[2][2], boffb[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { aoffb[h][i] = aoff[h][i] * 2u; boffb[h][i] = boff[h][i] * 2u; }
+    const bool up_w = GU && (__builtin_amdgcn_readfirstlane(wave) & 4) != 0;     // == b_up[h][i] for every piece of this wave (bit 5 of the B-tile row)
+    // pieces (h, i) for h in [h0, h1), i in [i0, i1) of tile t: ONE block-uniform branch for the group
+    auto issue_pieces = [&](int t, int buf, bool is_b, int h0, int h1, int i0, int i1) {
         const int k0 = (kt0 + t) * T256_BK;
-        char* dst = smem + buf * BUF_BYTES + lds_lane_base + ((is_b ? 2 : 0) + h) * HALF_BYTES + i * 8192;
-        __builtin_amdgcn_global_load_lds((gbl_void*)piece_src(k0, is_b, h, i), (lds_void*)dst, 16, 0, 0);
+        const bool cm = is_b ? BCM : ACM;
+        const bf16_t* base = is_b ? (up_w ? p.W2 : p.W) : p.A;
+        const int64_t ld = is_b ? p.ldw : p.lda;
+        const char* sb = (const char*)(cm ? base + (int64_t)k0 * ld : base + k0);          // wave-uniform
+        char* dst0 = smem + buf * BUF_BYTES + lds_lane_base + (is_b ? 2 : 0) * HALF_BYTES;
+        if (k0 + T256_BK > p.K) {                                                           // ragged last K-tile (block-uniform)
+#pragma unroll
+            for (int h = h0; h < h1; ++h)
+#pragma unroll
+                for (int i = i0; i < i1; ++i) {
+                    const bool kin = cm ? (k0 + cm_k + 32 * i < p.K) : (k0 + kch * 8 < p.K);
+                    const uint32_t vo = is_b ? boffb[h][i] : aoffb[h][i];
+                    const char* src = kin ? sb + vo : (const char*)zero_src;
+                    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst0 + h * HALF_BYTES + i * 8192), 16, 0, 0);
+                }
+            asm volatile("" ::: "memory");                                                  // (keeps this branch a branch: see above)
+        } else {
+#pragma unroll
+            for (int h = h0; h < h1; ++h)
+#pragma unroll
+                for (int i = i0; i < i1; ++i) {
+                    uint32_t& vo = is_b ? boffb[h][i] : aoffb[h][i];                        // per lane, bytes
+                    asm volatile("" : "+v"(vo));                // in place, no instruction: the zero-extension must stay in THIS block (hoisted out
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(sb + vo), (lds_void*)(dst0 + h * HALF_BYTES + i * 8192), 16, 0, 0);   // of the loop as a 64-bit pair it hides the saddr form)
+                }
+        }
     };
+    auto issue_piece = [&](int t, int buf, bool is_b, int h, int i) { issue_pieces(t, buf, is_b, h, h + 1, i, i + 1); };
     // the extra fragment's 16 rows x 64 k = 128 chunks: one DMA instruction on wave 0 and one on wave 1, same slot swizzle as a half-tile
     uint32_t a9off = 0; int a9kch = 0;
     if constexpr (EX) {
@@ -172,15 +197,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
         int gm9 = m0 + 256 + row9; gm9 = gm9 < M ? gm9 : M - 1;
         a9off = (uint32_t)gm9 * (uint32_t)p.lda + a9kch * 8;
     }
+    uint32_t a9offb = a9off * 2u;
     const int a9_lane_base = __builtin_amdgcn_readfirstlane((wave & 1) * 1024);
     auto issue_a9 = [&](int t, int buf) {
         if constexpr (EX) {
             if (has9 && wave < 2) {
                 const int k0 = (kt0 + t) * T256_BK;
-                const bf16_t* src = p.A + a9off + k0;
-                if (k0 + T256_BK > p.K) src = (k0 + a9kch * 8 < p.K) ? src : zero_src;
                 char* dst = smem + A9_BASE + buf * 2048 + a9_lane_base;
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+                if (k0 + T256_BK > p.K) {                  // ragged last K-tile: per-lane select (a branch, like issue_pieces)
+                    const bf16_t* src = (k0 + a9kch * 8 < p.K) ? p.A + a9off + k0 : zero_src;
+                    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+                    asm volatile("" ::: "memory");
+                } else {                                   // saddr + 32-bit voffset form
+                    asm volatile("" : "+v"(a9offb));
+                    __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)(p.A + k0) + a9offb), (lds_void*)dst, 16, 0, 0);
+                }
             }
         }
     };
@@ -188,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { issue_piece(t, buf, false, h, i); issue_piece(t, buf, true, h, i); }
+            for (int i = 0; i < 2; ++i) { issue_piece(t, buf, false, h, i); issue_piece(t, buf, true, h, i); }      // (prologue only: order A, B per piece as the counted waits expect)
         issue_a9(t, buf);
     };
 
@@ -413,10 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                 }
             }
             if (t >= 1 && t + 1 < nt) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) issue_piece(t + 1, buf ^ 1, false, h, i);
+                issue_pieces(t + 1, buf ^ 1, false, 0, 2, 0, 2);
                 issue_a9(t + 1, buf ^ 1);                  // with the A halves: older than the B halves the counted wait leaves in flight
             }
             enter_mfma(true); mfma16(af, bf0, 0, 0); mfma16(af, bf1, 0, 2);
@@ -445,10 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
                 for (int i = 0; i < NA; ++i) af[i][ks] = fragA7(cA, NA * 16 + i * 16, ksc);
             });
             if (t + 2 < nt) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) issue_piece(t + 2, buf, true, h, i);
+                issue_pieces(t + 2, buf, true, 0, 2, 0, 2);
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else if (t + 1 < nt) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -616,10 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int tiles_m
             __builtin_amdgcn_s_barrier();                           // both B halves are in registers everywhere: refill them
             asm volatile("" ::: "memory");
             if (more) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) issue_piece(t + 2, buf, true, h, i);
+                issue_pieces(t + 2, buf, true, 0, 2, 0, 2);
             }
         }
 #pragma unroll
