@@ -1,7 +1,7 @@
 /* vila_hip_tuning.h — tuning and test switches of libvila_hip.so.  NOT part of the drop-in boundary (include/vila_hip.h):
  * these are PROCESS-GLOBAL, not thread-safe, and exist for the A/B measurements under tools/ and for the parity tests that pin one
  * kernel variant (tests/test_gpu_ops.py).  A product binding never calls them; every switch defaults to the measured-best policy.
- * Environment equivalents read once at first use: VILA_GEMM_EX, VILA_ATTN_FWD=v1, VILA_ATTN_BWD=v1, VILA_DECODE_ATTN, VILA_DECODE_CHAIN. */
+ * Environment equivalents read once at first use: VILA_GEMM_EX, VILA_ATTN_FWD=v1, VILA_ATTN_BWD=v1, VILA_DECODE_ATTN, VILA_DECODE_CHAIN, VILA_DECODE_PERSIST. */
 #ifndef VILA_HIP_TUNING_H
 #define VILA_HIP_TUNING_H
 #ifdef __cplusplus
@@ -18,6 +18,10 @@ void vila_decode_force_attn(int mode);
 /* the batch-1 decode step's kernels chained over two streams (api.hip "chained decode step": kernel i streams its weights while kernel i-1
  * finishes, then waits on its done counter): 0 = off (default: measured 10 % slower than the plain step, profiles/r04_decode_chain_ab.log), 1 = on */
 void vila_decode_force_chain(int on);
+/* the batch-1 decode token as ONE persistent launch (decode_persist.hip: 28 layers x 5 phases + lm_head behind fence-free grid barriers, the
+ * next phase's weights streaming across every barrier): 1 = on (default where the shape is supported), 0 = the per-kernel step (prologue +
+ * 5 launches per layer + lm_head); environment: VILA_DECODE_PERSIST=0.  Logits are bit-identical either way. */
+void vila_decode_force_persist(int on);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible,

@@ -1,4 +1,22 @@
+import json
+import os
+
 import torch
+
+# "grads cosine >= 0.999" — the stated bound of every model-gradient comparison (bf16 HIP step vs fp32 autograd).
+# A tensor that cannot meet it carries a per-tensor exception at its call site, with the measured value and the reason.
+GRAD_COS_MIN = 0.999
+
+
+def grad_cos(test: str, name: str, got: torch.Tensor, ref: torch.Tensor) -> float:
+    """Cosine of a gradient tensor against its fp32 reference.  With VILA_DUMP_COS=<file> every measured value is appended as a JSON line
+    (what the per-tensor exceptions in the tests were read from)."""
+    cos = float(torch.nn.functional.cosine_similarity(got.detach().double().cpu().flatten(), ref.detach().double().cpu().flatten(), dim=0))
+    path = os.environ.get("VILA_DUMP_COS")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": test, "tensor": name, "cos": cos, "ref_norm": float(ref.norm()), "numel": ref.numel()}) + "\n")
+    return cos
 
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:

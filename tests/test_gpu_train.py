@@ -1,12 +1,23 @@
 """GPU parity tests of the SFT step: backward operators against PyTorch fp32 autograd of the same
 op, and the whole forward+backward (ViT + projector + packed LLM + loss) against autograd through the CPU oracle.
-Tolerances: operator gradients rel-L2 <= 1.5e-2 (bf16 in/out); model gradients cosine >= 0.99 and rel-L2 <= 6e-2 per tensor
-(bf16 GPU vs fp32 CPU through ~10 layers), loss |delta| <= 1e-2 relative."""
+Tolerances: operator gradients rel-L2 <= 1.5e-2 (bf16 in/out); model gradients cosine >= 0.999 (SURVEY 8c's stated bound,
+`gpu_util.GRAD_COS_MIN`; per-tensor exceptions are listed in GRAD_COS_EXCEPTIONS with the measured value and the reason) and
+rel-L2 <= 6e-2 per tensor (bf16 GPU vs fp32 CPU through ~10 layers), loss |delta| <= 1e-2 relative."""
 import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.gpu_util import max_abs, randn_bf16, rel_l2
+from tests.gpu_util import GRAD_COS_MIN, grad_cos, max_abs, randn_bf16, rel_l2
+
+# Per-tensor exceptions to the stated cosine bound: (test tag, tensor-name suffix) -> (bound, measured, why).  Everything else: >= 0.999.
+GRAD_COS_EXCEPTIONS = {}
+
+
+def _cos_bound(test: str, name: str) -> float:
+    for (t, suffix), (bound, _measured, _why) in GRAD_COS_EXCEPTIONS.items():
+        if t == test and name.endswith(suffix):
+            return bound
+    return GRAD_COS_MIN
 
 pytestmark = pytest.mark.gpu
 
@@ -182,9 +193,9 @@ def test_adamw_matches_torch(ops, n):
 # ---------------------------------------------------------------------------------------------------------------------
 # whole step vs autograd through the CPU oracle
 # ---------------------------------------------------------------------------------------------------------------------
-def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max=6e-2, c_abi=(False,), block_sizes=None, video_frames=(), tsp=None):
+def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, tag="sft", rel_max=6e-2, c_abi=(False,), block_sizes=None, video_frames=(), tsp=None):
     """One forward+backward of the HIP trainer vs fp32 autograd through the restated reference forward (packed branch of
-    llava_llama.py:125-134): loss <= 1e-2 relative, every gradient tensor cosine >= cos_min and rel-L2 <= rel_max.
+    llava_llama.py:125-134): loss <= 1e-2 relative, every gradient tensor cosine >= 0.999 (`_cos_bound`) and rel-L2 <= rel_max.
     c_abi: which drivers to check against the ONE oracle run — False = the Python-orchestrated operator calls, True = the whole
     forward + backward as one `vila_sft_fwd_bwd` call with the grad-ready callback.
     video_frames: frame counts of the videos (one per <vila/video> token), their frames are drawn behind the `n_images` image tiles;
@@ -222,10 +233,10 @@ def _sft_vs_oracle(cfg, seed, ids, labels, mask, n_images, cos_min=0.99, rel_max
             if float(gref.norm()) < 1e-6:
                 assert float(got.norm()) < 1e-3, name
                 continue
-            cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
+            cos = grad_cos(f"{tag}{'/c' if use_c else ''}", name, got, gref)
             rel = rel_l2(got, gref)
             worst = (min(worst[0], cos), max(worst[1], rel))
-            if cos < cos_min or rel > rel_max:
+            if cos < _cos_bound(tag, name) or rel > rel_max:
                 bad.append((name, round(cos, 4), round(rel, 4)))
         assert not bad, (use_c, bad)
         out.append((tr, float(loss), float(ref), worst))
@@ -245,7 +256,7 @@ def test_sft_forward_backward_matches_oracle_autograd(proj):
     ids[1, 0] = cfg.image_token_id; ids[1, 5] = cfg.image_token_id
     mask = torch.ones(2, L, dtype=torch.bool); mask[0, 11:] = False
     labels = torch.randint(0, 900, (2, L), generator=g); labels[:, :6] = -100
-    res = _sft_vs_oracle(cfg, 3, ids, labels, mask, 3, c_abi=(False, True))
+    res = _sft_vs_oracle(cfg, 3, ids, labels, mask, 3, tag=f"tiny/{proj}", c_abi=(False, True))
     # the gradient buckets were announced in backward order and cover the exchange — identically by both drivers
     orders = [[p for p, _, _ in tr.reducer.log] for tr, _, _, _ in res]
     assert orders[0] == orders[1]
@@ -264,7 +275,7 @@ def test_sft_forward_backward_at_8b_widths_matches_oracle_autograd():
     labels = ids.clone()
     labels[:, : 1 + T - 256] = -100
     mask = torch.ones_like(ids, dtype=torch.bool)
-    for use_c, (tr, loss, ref, worst) in zip((False, True), _sft_vs_oracle(cfg, 17, ids, labels, mask, b, c_abi=(False, True))):
+    for use_c, (tr, loss, ref, worst) in zip((False, True), _sft_vs_oracle(cfg, 17, ids, labels, mask, b, tag="8b_width", c_abi=(False, True))):
         print(f"8B-width SFT fwd+bwd ({'one vila_sft_fwd_bwd call' if use_c else 'python-orchestrated'}): loss {loss:.5f} vs oracle {ref:.5f}; "
               f"worst grad cosine {worst[0]:.4f}, worst rel-L2 {worst[1]:.4f}")
 
@@ -284,7 +295,7 @@ def test_sft_dynamic_s2_forward_backward_matches_oracle_autograd():
     ids[1, 0] = cfg.image_token_id
     mask = torch.ones(2, L, dtype=torch.bool); mask[1, 9:] = False
     labels = torch.randint(0, 900, (2, L), generator=g); labels[:, :5] = -100
-    res = _sft_vs_oracle(cfg, 5, ids, labels, mask, 12, c_abi=(False, True), block_sizes=blocks)
+    res = _sft_vs_oracle(cfg, 5, ids, labels, mask, 12, tag="tiny_s2", c_abi=(False, True), block_sizes=blocks)
     orders = [[p for p, _, _ in tr.reducer.log] for tr, _, _, _ in res]
     assert orders[0] == orders[1] and "mm_projector." in orders[0]
 
@@ -304,9 +315,9 @@ def test_sft_dynamic_s2_with_videos_matches_oracle_autograd():
     mask = torch.ones(2, L, dtype=torch.bool); mask[1, 11:] = False
     labels = torch.randint(0, 900, (2, L), generator=g); labels[:, :7] = -100
     n_tiles = 1 + 4 + 4                                                   # the image: 1x and 2x scales in full, its own 2 x 2 blocks at the last scale
-    res = _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, c_abi=(False, True), block_sizes=[(2, 2)], video_frames=(2, 4))
+    res = _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, tag="tiny_s2_video", c_abi=(False, True), block_sizes=[(2, 2)], video_frames=(2, 4))
     assert abs(res[0][1] - res[1][1]) < 1e-2 * abs(res[0][1])
-    _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, c_abi=(False, True), block_sizes=[(2, 2)], video_frames=(2, 4), tsp=[[2, 2, 1], [1, 1, 1]])
+    _sft_vs_oracle(cfg, 7, ids, labels, mask, n_tiles, tag="tiny_s2_video_tsp", c_abi=(False, True), block_sizes=[(2, 2)], video_frames=(2, 4), tsp=[[2, 2, 1], [1, 1, 1]])
 
 
 def test_sft_dynamic_s2_at_8b_widths_matches_oracle_autograd():
@@ -319,7 +330,7 @@ def test_sft_dynamic_s2_at_8b_widths_matches_oracle_autograd():
     ids = synthetic.make_prompt(cfg, 64, 1, 50)[None]
     labels = ids.clone(); labels[:, :33] = -100
     mask = torch.ones_like(ids, dtype=torch.bool)
-    for use_c, (tr, loss, ref, worst) in zip((False, True), _sft_vs_oracle(cfg, 19, ids, labels, mask, 14, c_abi=(False, True), block_sizes=[(3, 3)])):
+    for use_c, (tr, loss, ref, worst) in zip((False, True), _sft_vs_oracle(cfg, 19, ids, labels, mask, 14, tag="8b_width_s2", c_abi=(False, True), block_sizes=[(3, 3)])):
         print(f"8B-width dynamic_s2 SFT fwd+bwd ({'one vila_sft_fwd_bwd call' if use_c else 'python-orchestrated'}): loss {loss:.5f} vs oracle "
               f"{ref:.5f}; worst grad cosine {worst[0]:.4f}, worst rel-L2 {worst[1]:.4f}")
 
@@ -412,7 +423,7 @@ def test_per_bucket_adamw_equals_one_flat_step():
 def test_autograd_seam_reference_training_call_site(use_c):
     """SURVEY §8b / VERDICT round 2: after the swap the reference's own call site (transformer_normalize_monkey_patch.py:183-249) —
     `loss = model(**inputs).loss; loss.backward(); optimizer.step(); model.zero_grad()` — must produce gradients.  `.grad` of every
-    parameter vs fp32 autograd through the oracle (cosine >= 0.99), gradient accumulation over two micro-batches, a torch optimizer step
+    parameter vs fp32 autograd through the oracle (cosine >= 0.999), gradient accumulation over two micro-batches, a torch optimizer step
     on the parameters, zero_grad(set_to_none=True) and a fresh backward."""
     from oracle import vila_oracle as O
     from vila_amd import configs, synthetic
@@ -448,9 +459,9 @@ def test_autograd_seam_reference_training_call_site(use_c):
         if gref is None or float(gref.norm()) < 1e-6:            # never reached by hidden_states[-2] (27th ViT layer, post_layernorm): zero here
             assert float(got.float().norm()) < 1e-3, name
             continue
-        cos = float(F.cosine_similarity(got.float().cpu().flatten(), gref.flatten(), dim=0))
+        cos = grad_cos("seam", name, got.float().cpu(), gref)
         worst = min(worst, cos)
-        assert cos >= 0.99, (name, cos)
+        assert cos >= _cos_bound("seam", name), (name, cos)
     # gradient accumulation: a second micro-batch adds to .grad (same batch -> doubled, up to bf16 rounding of the sum)
     g1 = {n: p.grad.float().clone() for n, p in params.items()}
     (model(**inputs).loss * 0.5).backward()                       # upstream scaling (loss / gradient_accumulation_steps) reaches the grads
@@ -559,9 +570,9 @@ def test_sft_step_with_video_media_matches_oracle_autograd(use_c):
         if float(gref.norm()) < 1e-6:
             assert float(got.norm()) < 1e-3, name
             continue
-        cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
+        cos = grad_cos("video", name, got, gref)
         worst = min(worst, cos)
-        assert cos >= 0.99, (name, cos)
+        assert cos >= _cos_bound("video", name), (name, cos)
     if not use_c:
         # the reference's call site: model(**inputs).loss with media = {"image": [...], "video": [...]} through the autograd seam
         m2 = build_model(cfg, weights=w)
@@ -572,7 +583,7 @@ def test_sft_step_with_video_media_matches_oracle_autograd(use_c):
         assert abs(float(out.loss) - float(ref)) < 1e-2 * abs(float(ref))
         out.loss.backward()
         p = dict(m2.mm_projector.named_parameters())["layers.1.weight"]
-        assert p.grad is not None and float(F.cosine_similarity(p.grad.float().cpu().flatten(), wr["mm_projector.layers.1.weight"].grad.flatten(), dim=0)) >= 0.99
+        assert p.grad is not None and grad_cos("video/seam", "mm_projector.layers.1.weight", p.grad.float().cpu(), wr["mm_projector.layers.1.weight"].grad) >= GRAD_COS_MIN
     print(f"SFT with video media ({'one C-ABI call' if use_c else 'python-orchestrated'}): loss {float(loss):.5f} vs oracle {float(ref):.5f}, worst cosine {worst:.4f}")
 
 
@@ -648,17 +659,17 @@ def test_sft_step_with_tsp_video_encoder_matches_oracle_autograd(pool_sizes, sta
         if float(gref.norm()) < 1e-6:
             assert float(got.norm()) < 1e-3, name
             continue
-        cos = float(F.cosine_similarity(got.flatten(), gref.flatten(), dim=0))
+        cos = grad_cos("tsp", name, got, gref)
         worst = min(worst, cos)
         n_checked += 1
-        assert cos >= 0.99, (name, cos)
+        assert cos >= _cos_bound("tsp", name), (name, cos)
     assert n_checked > 20
     # the tower's gradient exists only through the pooled rows for the videos: it must be there
     assert float(grads["vision_tower.vision_tower.vision_model.embeddings.patch_embedding.weight"].float().norm()) > 0
     # the encoder's own tokens were trained: their embedding rows carry gradient, as in the oracle
     ge, ge_ref = grads["llm.model.embed_tokens.weight"].float().cpu(), wr["llm.model.embed_tokens.weight"].grad
     for t in (tok(start) or []) + (tok(end) or []) + (tok(sep) or []):
-        assert float(ge_ref[t].norm()) > 0 and float(F.cosine_similarity(ge[t], ge_ref[t], dim=0)) >= 0.98, t
+        assert float(ge_ref[t].norm()) > 0 and grad_cos("tsp", f"embed_tokens.row{t}", ge[t], ge_ref[t]) >= _cos_bound("tsp", f"embed_tokens.row{t}"), t
     # the one-call driver (`vila_sft_fwd_bwd` with the batch's `pools` array): same loss, same gradients
     tr_c = SFTTrainer(make(), optimizer_state=False)
     loss_c = tr_c.forward_backward_c(ids, [p.cuda() for p in images], labels, mask, n_items, None, videos=[vid_a.cuda(), vid_b.cuda()])
@@ -667,7 +678,7 @@ def test_sft_step_with_tsp_video_encoder_matches_oracle_autograd(pool_sizes, sta
     grads_c = tr_c.flat.named_grads()
     for name, got in grads.items():
         if float(got.float().norm()) > 1e-6:
-            assert float(F.cosine_similarity(grads_c[name].float().flatten(), got.float().flatten(), dim=0)) >= 0.995, name
+            assert grad_cos("tsp/c_vs_py", name, grads_c[name].float(), got.float()) >= GRAD_COS_MIN, name
     # the autograd seam on the same batch (the reference's call site)
     m2 = make()
     m2.enable_autograd(use_c_abi=False)
@@ -677,7 +688,7 @@ def test_sft_step_with_tsp_video_encoder_matches_oracle_autograd(pool_sizes, sta
     assert abs(float(out.loss) - float(ref)) < 1e-2 * abs(float(ref))
     out.loss.backward()
     p = dict(m2.mm_projector.named_parameters())["layers.1.weight"]
-    assert p.grad is not None and float(F.cosine_similarity(p.grad.float().cpu().flatten(), wr["mm_projector.layers.1.weight"].grad.flatten(), dim=0)) >= 0.99
+    assert p.grad is not None and grad_cos("tsp/seam", "mm_projector.layers.1.weight", p.grad.float().cpu(), wr["mm_projector.layers.1.weight"].grad) >= GRAD_COS_MIN
     print(f"SFT with TSPVideoEncoder {pool_sizes} start={start!r} end={end!r} sep={sep!r}: loss {float(loss):.5f} vs oracle {float(ref):.5f}, "
           f"worst cosine {worst:.4f} over {n_checked} tensors")
 

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libvila_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "attn.hip", "elementwise.hip", "gemv.hip", "train.hip", "attn_bwd.hip", "gemm256.hip", "s2.hip", "gemv_w4.hip", "gemm_ring.hip", "video.hip", "gemm256_cm.hip", "gemm_i8.hip", "sample.hip", "sft.hip", "attn_bwd_dma.hip", "decode_batch.hip", "gemm_ring_splitk.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attn.hip", "elementwise.hip", "gemv.hip", "train.hip", "attn_bwd.hip", "gemm256.hip", "s2.hip", "gemv_w4.hip", "gemm_ring.hip", "video.hip", "gemm256_cm.hip", "gemm_i8.hip", "sample.hip", "sft.hip", "attn_bwd_dma.hip", "decode_batch.hip", "gemm_ring_splitk.hip", "decode_persist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]  # fp-contract off: keep the HF rounding order (bf16(q*cos)+bf16(rot*sin)) explicit
 

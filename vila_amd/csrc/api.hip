@@ -5,6 +5,7 @@
 #include "../../include/vila_hip.h"
 #include "../../include/vila_hip_tuning.h"
 #include "kernels.h"
+#include "decode_persist.h"
 #include "train.h"
 #include "w4.h"
 
@@ -429,7 +430,12 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
 static inline int dec_splits(int max_ctx) { return cdiv(max_ctx, 64); }
 // kernel launches of one vila_llm_decode_step: prologue + per layer {qkv, attention (1 launch up to 2048 cached positions, else
 // split-KV + merge), o_proj, gate/up, down} + lm_head + argmax x2 + advance
+static int decode_persist_mode();
+static bool decode_persist_ok(const VilaLlmShape& sh, int max_ctx) {
+    return decode_persist_mode() != 0 && decode_persist_supported(sh.hidden, sh.inter, sh.q_heads, sh.kv_heads, sh.head_dim, sh.n_layers, max_ctx, sh.vocab);
+}
 extern "C" int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx) {
+    if (decode_persist_ok(*s, max_ctx)) return 5;                 // prologue, the persistent token kernel, argmax x2, advance
     return 1 + s->n_layers * (max_ctx <= 2048 ? 5 : 6) + 4;      // a sampled step: + 1 (three selection launches instead of two argmax stages)
 }
 extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx) {
@@ -453,6 +459,13 @@ extern "C" void vila_decode_force_attn(int mode) { g_decode_attn = mode; }
 static int decode_attn_mode() {
     if (g_decode_attn < 0) { const char* e = getenv("VILA_DECODE_ATTN"); g_decode_attn = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
     return g_decode_attn;
+}
+// The token as ONE persistent launch (decode_persist.hip): VILA_DECODE_PERSIST=0 / vila_decode_force_persist(0) selects the 145-launch step.
+static int g_decode_persist = -1;
+extern "C" void vila_decode_force_persist(int on) { g_decode_persist = on ? 1 : 0; }
+static int decode_persist_mode() {
+    if (g_decode_persist < 0) { const char* e = getenv("VILA_DECODE_PERSIST"); g_decode_persist = (e && e[0] == '0') ? 0 : 1; }
+    return g_decode_persist;
 }
 static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
                             const VilaSampling* sp, vila_stream_t stream);
@@ -547,6 +560,30 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
     void* smp_ws = a.take<char>(sample_workspace_bytes());
     VILA_REQUIRE(a.ok(), "llm_decode: workspace arena overflow");
 
+    if (decode_persist_ok(sh, cache->max_ctx) && !decode_chain_mode() && cache->n_slots >= 1) {
+        // ---- the persistent token: prologue (embedding row, RoPE row, barrier words) + ONE launch for 28 layers and the head ----
+        DpArgs d{};
+        const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
+        for (int l = 0; l < sh.n_layers; ++l) {
+            const VilaLlmLayer& L = w->layers[l];
+            const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
+                               (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
+            VILA_REQUIRE(fused, "llm_decode: q/k/v projection weights and biases must be views of one fused [q+2kv, hidden] buffer");
+            d.layer[l] = DpLayer{B(L.ln1_w), B(L.wq), B(L.bq), B(L.wo), B(L.ln2_w), B(L.w_gate), B(L.w_up), B(L.w_down)};
+        }
+        d.norm_w = B(w->norm_w); d.lm_head = B(w->lm_head); d.logits = st->logits;
+        d.kcache = B(cache->k); d.vcache = B(cache->v); d.kv_layer_stride = (int64_t)per_layer;
+        d.pos_ptr = st->pos; d.rope_cs = rope_cs; d.x0 = x; d.x1 = x2; d.q = q; d.act = act; d.part_o = part_o; d.part_ml = part_ml;
+        d.sync = chain_mem;
+        d.n_layers = sh.n_layers; d.H = H; d.F = F; d.nq = sh.q_heads; d.nkv = sh.kv_heads; d.hd = hd; d.vocab = sh.vocab; d.max_ctx = cache->max_ctx;
+        d.eps = sh.rms_eps; d.scale = 1.0f / sqrtf((float)hd);
+        VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s, chain_mem + 64, 1));
+        VILA_TRY(launch_decode_persist(d, s));
+        if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
+        else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
+        VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));
+        return 0;
+    }
     const bool split256 = decode_attn_mode() >= 1 && cache->max_ctx <= 2048 && hd == 128;
     ChainStreams* cs = nullptr;
     if (decode_chain_mode() && split256) {                      // (the long-context split-KV + merge pair stays unchained)
