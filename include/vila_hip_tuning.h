@@ -19,9 +19,13 @@ void vila_decode_force_attn(int mode);
  * finishes, then waits on its done counter): 0 = off (default: measured 10 % slower than the plain step, profiles/r04_decode_chain_ab.log), 1 = on */
 void vila_decode_force_chain(int on);
 /* the batch-1 decode token as ONE persistent launch (decode_persist.hip: 28 layers x 5 phases + lm_head behind fence-free grid barriers, the
- * next phase's weights streaming across every barrier): 1 = on (default where the shape is supported), 0 = the per-kernel step (prologue +
- * 5 launches per layer + lm_head); environment: VILA_DECODE_PERSIST=0.  Logits are bit-identical either way. */
+ * next phase's weights streaming across every barrier) + lm_head: 1 = on where the shape is supported, 0 = the per-kernel step (prologue +
+ * 5 launches per layer + lm_head; the default: the two measure within 1.5 % of each other); environment: VILA_DECODE_PERSIST=1.  Logits are
+ * bit-identical either way (tests/test_gpu_model.py::test_persistent_decode_step_equals_the_launch_path). */
 void vila_decode_force_persist(int on);
+/* measurement hook of the persistent token kernel: `buf` = device memory for [n_blocks][n_layers * 5 + 1][12] 64-bit s_memrealtime stamps (100 MHz)
+ * written by blocks < n_blocks of every following launch (tools/decode_persist_trace.py); NULL = off (default) */
+void vila_decode_persist_trace(void* buf, int n_blocks);
 /* tuning hook: output rows per tile of the 256-wide kernel: 0 = automatic (192 when it saves tile-times), 192, 256 */
 void vila_gemm_force_bm(int bm);
 /* tuning / test hook: 0 = automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA, 5 = split-K if possible,

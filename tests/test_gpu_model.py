@@ -215,6 +215,49 @@ def test_chained_decode_step_equals_the_plain_step():
     assert torch.equal(ids1, ids0) and torch.equal(free1, free0) and torch.equal(again, free0)
 
 
+@pytest.mark.parametrize("shape", ["8b_width", "tiny", "lite3b_width"])
+def test_persistent_decode_step_equals_the_launch_path(shape):
+    """Round 6: the batch-1 decode token as ONE persistent launch (decode_persist.hip: 5 phases per layer behind fence-free grid barriers, the
+    next phase's weights streaming across every barrier) against the per-kernel step (prologue + 5 launches per layer + lm_head).  Same
+    arithmetic operation for operation, so the logits must be equal BIT FOR BIT — eager and through the captured graph, over a context that
+    crosses a 256-key slice boundary, and no bounded wait may give up.  Shapes: NVILA-8B widths (28 / 4 heads, K = 3584 / 18944), the tiny
+    config of the golden fixtures, Lite-3B widths (16 / 2 heads, hidden 2048: a row pair does not fill its 7-chunk batch)."""
+    from vila_amd import _lib
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    if shape == "8b_width":
+        cfg = configs.reduced_8b(layers_v=2, layers_l=3, vocab=32000)
+        cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+        S = 250                                                       # 250 + 12 steps crosses key 256: a second slice appears mid-run
+    elif shape == "lite3b_width":
+        cfg = configs.nvila_lite_3b()
+        cfg.llm.num_hidden_layers, cfg.vision.num_hidden_layers = 2, 2
+        S = 120
+    else:
+        cfg = configs.tiny("mlp_downsample")
+        S = 20
+    model = build_model(cfg, seed=12)
+    g = torch.Generator().manual_seed(12)
+    e = (torch.randn(1, S, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    n = 12
+    try:
+        lib.vila_decode_force_persist(0)
+        model.llm._invalidate()
+        ids0, lg0 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, use_graph=False, eos_token_id=-1)
+        free0 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)
+        lib.vila_decode_force_persist(1)
+        model.llm._invalidate()
+        ids1, lg1 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, return_logits=True, use_graph=False, eos_token_id=-1)
+        free1 = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)      # raises if a wait gave up
+        again = model.llm.generate(inputs_embeds=e, max_new_tokens=n, use_graph=True, eos_token_id=-1)      # replay: barrier words re-zeroed per token
+    finally:
+        lib.vila_decode_force_persist(0)
+        model.llm._invalidate()
+    assert torch.isfinite(lg1).all()
+    assert torch.equal(lg1, lg0), f"persistent vs per-kernel decode logits differ: max {float((lg1 - lg0).abs().max()):.3e}"
+    assert torch.equal(ids1, ids0) and torch.equal(free1, free0) and torch.equal(again, free0)
+
+
 def test_vlm_generate_end_to_end(case):
     cfg, seed, fx, w, model = case
     px = synthetic.make_pixels(cfg, 2, seed).to(torch.bfloat16)

@@ -135,6 +135,7 @@ PROTOTYPES = {
     "vila_decode_force_attn": (None, [c_int]),
     "vila_decode_force_chain": (None, [c_int]),
     "vila_decode_force_persist": (None, [c_int]),
+    "vila_decode_persist_trace": (None, [c_void_p, c_int]),
     "vila_llm_decode_chain_error": (c_int, [c_void_p, c_void_p]),
     "vila_gemm_bf16_t": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -435,7 +435,7 @@ static bool decode_persist_ok(const VilaLlmShape& sh, int max_ctx) {
     return decode_persist_mode() != 0 && decode_persist_supported(sh.hidden, sh.inter, sh.q_heads, sh.kv_heads, sh.head_dim, sh.n_layers, max_ctx, sh.vocab);
 }
 extern "C" int vila_llm_decode_launches(const VilaLlmShape* s, int max_ctx) {
-    if (decode_persist_ok(*s, max_ctx)) return 5;                 // prologue, the persistent token kernel, argmax x2, advance
+    if (decode_persist_ok(*s, max_ctx)) return 6;                 // prologue, the persistent layers kernel, lm_head, argmax x2, advance
     return 1 + s->n_layers * (max_ctx <= 2048 ? 5 : 6) + 4;      // a sampled step: + 1 (three selection launches instead of two argmax stages)
 }
 extern "C" size_t vila_llm_decode_workspace_bytes(const VilaLlmShape* s, int max_ctx) {
@@ -460,11 +460,15 @@ static int decode_attn_mode() {
     if (g_decode_attn < 0) { const char* e = getenv("VILA_DECODE_ATTN"); g_decode_attn = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
     return g_decode_attn;
 }
-// The token as ONE persistent launch (decode_persist.hip): VILA_DECODE_PERSIST=0 / vila_decode_force_persist(0) selects the 145-launch step.
+// The 28 layers of a token as ONE persistent launch (decode_persist.hip): VILA_DECODE_PERSIST=1 / vila_decode_force_persist(1).  OFF by default:
+// bit-identical logits, and measured AT PARITY with the per-kernel step (336.7 vs 341.9 tok/s, profiles/r06_decode_persist_ab.log) — both spend
+// ~7 us per all-to-all edge around phases that stream at 7.1-7.3 TB/s (profiles/r06_persist_trace.txt has the per-phase anatomy).
 static int g_decode_persist = -1;
 extern "C" void vila_decode_force_persist(int on) { g_decode_persist = on ? 1 : 0; }
+// measurement hook: device buffer [n_blocks][n_layers * 5 + 1][12] of s_memrealtime stamps written by the next persistent launches (null: off)
+extern "C" void vila_decode_persist_trace(void* buf, int n_blocks) { decode_persist_set_trace((unsigned long long*)buf, n_blocks); }
 static int decode_persist_mode() {
-    if (g_decode_persist < 0) { const char* e = getenv("VILA_DECODE_PERSIST"); g_decode_persist = (e && e[0] == '0') ? 0 : 1; }
+    if (g_decode_persist < 0) { const char* e = getenv("VILA_DECODE_PERSIST"); g_decode_persist = (e && e[0] == '1') ? 1 : 0; }
     return g_decode_persist;
 }
 static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, const VilaDecodeState* st, void* workspace, size_t workspace_bytes,
@@ -579,6 +583,11 @@ static int decode_step_impl(const VilaLlmWeights* w, const VilaKvCache* cache, c
         d.eps = sh.rms_eps; d.scale = 1.0f / sqrtf((float)hd);
         VILA_TRY(launch_decode_prologue(B(w->embed), st->token, x, H, sh.vocab, st->pos, rope_cs, hd, sh.rope_theta, s, chain_mem + 64, 1));
         VILA_TRY(launch_decode_persist(d, s));
+        // the head as its own launch: final RMSNorm + lm_head rows -> fp32 logits (152 064 x 3584: 1.09 GB, 7 TB/s in gemv_kernel<0,7>).  The
+        // last layer's residual stream is in `x` (an even number of buffer swaps per layer).
+        GemvArgs lm{};
+        lm.x = x; lm.norm_w = B(w->norm_w); lm.eps = sh.rms_eps; lm.W = B(w->lm_head); lm.y_f32 = st->logits; lm.N = sh.vocab; lm.K = H; lm.mode = 0;
+        VILA_TRY(launch_gemv(lm, s));
         if (sp != nullptr) VILA_TRY(launch_sample(st->logits, sh.vocab, sp->temperature, sp->top_k, sp->top_p, sp->seed, sp->seed_dev, st->pos, st->token, smp_ws, nullptr, s));
         else VILA_TRY(launch_argmax(st->logits, sh.vocab, st->token, tv, ti, s));
         VILA_TRY(launch_decode_advance(st->pos, st->token, st->out_ids, st->n_out, st->max_out, s));

@@ -18,7 +18,13 @@ struct DpArgs {
     int n_layers, H, F, nq, nkv, hd, vocab, max_ctx;
     float eps, scale;
     int lds_scratch, lds_outq, lds_attn, lds_wsm;                     // LDS carve (filled by the launcher)
+    // measurement hook (vila_decode_persist_trace; null in product): blocks < trace_blocks stamp s_memrealtime (100 MHz) at 5 points of every
+    // phase: [phase][0] worker wave 0 starts its rows, [1] it is done, [2] every worker of the block is done, [3] the sync wave's stores are
+    // drained, [4] the grid barrier opened, [5 + w] worker wave w is done.  Layout [block][n_layers * 5 + 1 phases][12].
+    unsigned long long* trace; int trace_blocks;
+    int skew_f;                 // gate/up groups per block moved from the odd (slower) XCDs' blocks to the even ones (VILA_DECODE_PERSIST_SKEW, default 2: measured 0 / 1 / 2 / 3 -> per-XCD arrival lags even out at 2)
 };
 bool decode_persist_supported(int H, int F, int nq, int nkv, int hd, int n_layers, int max_ctx, int vocab);
 int decode_persist_blocks();
 int launch_decode_persist(DpArgs& a, hipStream_t s);
+void decode_persist_set_trace(unsigned long long* buf, int n_blocks);

@@ -815,8 +815,9 @@ class HipQwen2ForCausalLM(_HipModule):
         toks = out.tolist()
         if int(st.ws[:4].view(torch.int32).item()) != 0:    # (the stream is drained: out.tolist() above)
             st.ws[:4].zero_()
-            raise RuntimeError("chained decode step: a kernel's bounded wait for its predecessor gave up, the generated tokens are invalid "
-                               "(vila_llm_decode_chain_error; VILA_DECODE_CHAIN=0 selects the plain single-stream step)")
+            raise RuntimeError("decode step: a bounded device-side wait gave up (the persistent token kernel's grid barrier, or the chained step's "
+                               "wait for its predecessor), the generated tokens are invalid (vila_llm_decode_chain_error; VILA_DECODE_PERSIST=0 / "
+                               "VILA_DECODE_CHAIN=0 select the plain per-kernel step)")
         if forced_ids is None:
             for i, t in enumerate(toks):                    # HF stops AFTER emitting eos
                 if t in eos_set:
