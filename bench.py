@@ -335,7 +335,12 @@ def cpu_baseline(cfg, n_prompt: int, threads: int):
     nl, nv = cfg.llm.num_hidden_layers, cfg.vision.num_used_layers
     t_full = (t_tok - t_head) * (nl / L) + t_head
     ttft = t_vit * (nv / LV) + t_proj + t_prefill * (nl / L) + t_head
-    return {"value": round(1.0 / t_full, 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+    del w, wv, head
+    hf = hf_reference_leg(cfg, n_prompt, threads)
+    live = hf is not None and "decode_tokens_per_s" in hf
+    # `value`: the reference's own decoder (HF Qwen2) timed in THIS run when transformers could build it ("reference"), else the oracle port
+    return {"value": hf["decode_tokens_per_s"] if live else round(1.0 / t_full, 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(),
+            "kind": "reference" if live else "port", "reference_live": hf, "port_tokens_per_s": round(1.0 / t_full, 3),
             "cores_note": "cores = torch threads actually used (calibrated: all hardware threads measured slower); host_cpus = os.cpu_count()",
             "sample": f"oracle/vila_oracle.py fp32 at NVILA-8B widths: {L} of {nl} decoder layers + full lm_head, {n_prompt}-token prefill "
                       f"({t_prefill:.2f}s, layers only) then {n_tok} decode tokens ({t_tok*1e3:.0f} ms/token measured; layer part scaled x{nl // L}); "
@@ -343,6 +348,67 @@ def cpu_baseline(cfg, n_prompt: int, threads: int):
             "prefill_s_sample": round(t_prefill, 3), "vit_s_sample": round(t_vit, 3), "projector_s": round(t_proj, 3),
             "ttft_s": round(ttft, 2), "ttft_note": "CPU TTFT estimate for the same 1 image + prompt workload (scaled from the samples above)",
             "reference_full_depth": _reference_cpu_timing()}
+
+
+def hf_reference_leg(cfg, n_prompt: int, threads: int, L: int = 2, n_tok: int = 4):
+    """The reference's OWN decoder class timed live on this host, in this invocation ("missing" 6): HF `Qwen2ForCausalLM` — what
+    llava/model/language_model/builder.py:64 instantiates; `transformers` ships with the image, so unlike /root/reference it IS on the GPU box —
+    at NVILA-8B widths with L of the 28 layers, fp32 eager attention, random weights: an n_prompt-token prefill through `forward(inputs_embeds=...)`
+    and n_tok decode tokens through its KV cache (llava_arch.py:833 -> GenerationMixin's per-token forward).  Per-token time of the full model =
+    layer part x 28 / L + the measured lm_head.  Returns None when transformers cannot build the model here."""
+    try:
+        import transformers
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+        c = cfg.llm
+        hc = Qwen2Config(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size, num_hidden_layers=L,
+                         num_attention_heads=c.num_attention_heads, num_key_value_heads=c.num_key_value_heads, rms_norm_eps=c.rms_norm_eps,
+                         rope_theta=c.rope_theta, tie_word_embeddings=False, max_position_embeddings=4096, use_sliding_window=False,
+                         attention_dropout=0.0, pad_token_id=None, bos_token_id=None)
+        hc._attn_implementation = "eager"
+        torch.set_num_threads(threads)
+        init = torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters
+        torch.nn.Linear.reset_parameters = lambda self: None
+        torch.nn.Embedding.reset_parameters = lambda self: None
+        try:
+            llm = Qwen2ForCausalLM(hc).eval().float()
+        finally:
+            torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters = init
+        g = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            for n_, prm in llm.named_parameters():
+                if prm.dim() > 1:
+                    prm.normal_(0.0, 0.02, generator=g)
+                elif "norm" in n_:
+                    prm.fill_(1.0)
+                else:
+                    prm.zero_()
+            e = torch.randn(1, n_prompt, c.hidden_size, generator=g) * 0.5
+            t0 = time.perf_counter()
+            r = llm(inputs_embeds=e, use_cache=True, logits_to_keep=1)
+            t_prefill = time.perf_counter() - t0
+            past = r.past_key_values
+            tok = torch.tensor([[1]])
+            r = llm(input_ids=tok, past_key_values=past, use_cache=True)          # warm (allocations of the cache growth)
+            past = r.past_key_values
+            t0 = time.perf_counter()
+            for _ in range(n_tok):
+                r = llm(input_ids=tok, past_key_values=past, use_cache=True)
+                past = r.past_key_values
+            t_tok = (time.perf_counter() - t0) / n_tok
+            h = torch.randn(1, 1, c.hidden_size)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                llm.lm_head(h)
+            t_head = (time.perf_counter() - t0) / 3
+        nl = c.num_hidden_layers
+        t_full = max(t_tok - t_head, 1e-9) * (nl / L) + t_head
+        return {"decode_tokens_per_s": round(1.0 / t_full, 3), "decode_s_per_token": round(t_full, 4), "prefill_s_scaled": round(t_prefill * nl / L, 3),
+                "measured": {"layers": L, "prefill_s": round(t_prefill, 3), "decode_s_per_token": round(t_tok, 4), "lm_head_s": round(t_head, 4)},
+                "threads": threads, "dtype": "fp32", "hf_version": transformers.__version__,
+                "what": f"HF Qwen2ForCausalLM (the reference's decoder class) executed on THIS host in THIS run: {L} of {nl} layers at NVILA-8B widths + "
+                        f"the full lm_head, {n_prompt}-token prefill then {n_tok} decode tokens through its KV cache; layer part scaled x{nl / L:g}"}
+    except Exception as ex:                                   # pragma: no cover  (an HF API drift must not take the bench line down)
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def _reference_cpu_timing():
@@ -429,8 +495,23 @@ def exchange_summary(tr, world: int) -> dict:
     """What one step hands to the process group: the distinct gradient buckets the reducer announced (bf16 slices of the flat buffer)."""
     spans = {pre: (s0, e0) for pre, s0, e0 in tr.reducer.log}
     nbytes = sum(e0 - s0 for s0, e0 in spans.values()) * tr.flat.grads.element_size()
-    return {"world": world, "grad_exchange": tr.reducer.describe(),
-            "exchange_bytes": int(nbytes), "exchange_active": bool(tr.reducer.active())}
+    out = {"world": world, "grad_exchange": tr.reducer.describe(), "exchange_algo": tr.reducer.algo,
+           "exchange_bytes": int(nbytes), "exchange_active": bool(tr.reducer.active())}
+    out.update(rccl_ranks_seen(tr.reducer.dist if tr.reducer.active() else None, tr.flat.grads.device))
+    return out
+
+
+def rccl_ranks_seen(dist, dev) -> dict:
+    """The ranks the process group REALLY connects, counted through the group itself (an all-gather of every rank's id and device index on the
+    compute device): the driver's SCALE record can confirm that --gpus N ran N ranks over RCCL and not N copies of a world of one."""
+    if dist is None:
+        return {"rccl_ranks_seen": 1, "rccl_backend": "none"}
+    w = dist.get_world_size()
+    mine = torch.tensor([dist.get_rank(), torch.cuda.current_device() if dev.type == "cuda" else -1], device=dev, dtype=torch.int64)
+    got = [torch.empty_like(mine) for _ in range(w)]
+    dist.all_gather(got, mine)
+    ranks = sorted({int(t[0]) for t in got})
+    return {"rccl_ranks_seen": len(ranks), "rccl_rank_ids": ranks, "rccl_devices": [int(t[1]) for t in got], "rccl_backend": dist.get_backend()}
 
 
 def sft_side_measurement(model, cfg, a, rank, world, dev, dist):

@@ -259,14 +259,21 @@ int vila_add_bf16(const void* a, const void* b, void* y, int64_t n, vila_stream_
  * backward into the fp32 / param-dtype .grad, transformer_normalize_monkey_patch.py:236-249): the running sum `acc` is fp32.
  * mode 0: acc = g;  mode 1: acc += g;  mode 2: out = bf16(acc + g) (acc untouched, out may alias g).  g, out: bf16[n]; n % 8 == 0. */
 int vila_grad_accum_f32(float* acc, const void* g, void* out, int64_t n, int mode, vila_stream_t stream);
-/* out[c] (+)= sum_r x[r][c] (scratch: cols fp32); period > 0: out[p][c] = sum over rows r == p (mod period) (position-embedding gradient) */
+/* Reductions of the SFT step are DETERMINISTIC (round 6): every block writes fp32 partials into the caller's scratch and a second kernel adds
+ * them in a fixed order — no atomics, so two identical steps produce identical bits (a resumed run equals the uninterrupted one). */
+size_t vila_colsum_scratch_floats(int rows, int cols);
+size_t vila_norm_bwd_scratch_floats(int rows, int cols);
+#define VILA_SUMSQ_SCRATCH_FLOATS 2048
+/* out[c] (+)= sum_r x[r][c] (scratch: vila_colsum_scratch_floats fp32); period > 0: out[p][c] = sum over rows r == p (mod period) (position-embedding gradient, no scratch) */
 int vila_colsum_bf16(const void* x, void* out, float* scratch, int rows, int cols, int64_t ld, int accumulate, int period, vila_stream_t stream);
-/* LayerNorm (rms=0) / RMSNorm (rms=1) backward; scratch = 2*cols fp32 */
+/* LayerNorm (rms=0) / RMSNorm (rms=1) backward; scratch = vila_norm_bwd_scratch_floats(rows, cols) fp32 */
 int vila_norm_bwd_bf16(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, float* scratch, int rows, int cols,
                        float eps, int rms, int accumulate, vila_stream_t stream);
-/* softmax-CE over fp32 logits rows: loss += sum_i (lse_i - z_i[label_i]) * scale ; dlogits = (softmax - onehot) * scale (bf16) */
-int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, int rows, int vocab, int64_t ld_logits,
+/* softmax-CE over fp32 logits rows: loss += sum_i (lse_i - z_i[label_i]) * scale ; dlogits = (softmax - onehot) * scale (bf16);
+ * row_loss = scratch of `rows` floats (the per-row losses, summed in a fixed order) */
+int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, float* row_loss, int rows, int vocab, int64_t ld_logits,
                      float scale, vila_stream_t stream);
+/* dst[rows[i]] += src[i] (embedding gradient); repeated ids are summed in fp32 in ascending i by the first occurrence's block and rounded once */
 int vila_scatter_add_rows_bf16(const void* src, void* dst, const int32_t* rows, int n, int hidden, vila_stream_t stream);
 int vila_depth_to_space_bf16(const void* dy, void* dx, int n_images, int grid, int channels, int k, vila_stream_t stream);
 int vila_im2col_bf16(const void* pixels, void* out, int n_images, int channels, int H, int W, int patch, int k_padded, vila_stream_t stream);
@@ -292,7 +299,8 @@ int vila_adamw_step(float* master, float* m, float* v, const void* grad, void* p
  * stream (per-bucket optimizer overlapped with the backward of the layers below); results identical to vila_adamw_step */
 int vila_adamw_step_lean(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream);
-int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream);
+/* *out += sum x^2 (global gradient norm); scratch = VILA_SUMSQ_SCRATCH_FLOATS floats */
+int vila_sumsq_bf16(const void* x, int64_t n, float* out, float* scratch, vila_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------

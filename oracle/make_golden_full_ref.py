@@ -40,7 +40,7 @@ SRC = os.path.join(ROOT, "tests", "golden", "nvila8b_full_depth.npz")
 OUT = os.path.join(ROOT, "tests", "golden", "nvila8b_full_depth_ref.npz")
 
 
-def build_hf_llm_streaming(cfg, w):
+def build_hf_llm_streaming(cfg, w, dtype=torch.float32):
     """HF Qwen2ForCausalLM in fp32 with the weights copied in ONE TENSOR AT A TIME (the lazily drawn bf16 values upcast), so the peak is the
     model itself (30 GB) plus one tensor."""
     import transformers
@@ -65,7 +65,7 @@ def build_hf_llm_streaming(cfg, w):
     torch.nn.Embedding.reset_parameters = lambda self: None
     try:
         with ctx:
-            model = Qwen2ForCausalLM(hc).eval().float()
+            model = Qwen2ForCausalLM(hc).eval().to(dtype)
     finally:
         torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters = init
     sd = model.state_dict()

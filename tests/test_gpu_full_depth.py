@@ -160,6 +160,62 @@ def test_full_depth_sft_forward_loss_and_logits_rows_vs_reference(nvila8b):
     assert abs(loss - want) <= 1e-2, f"packed training forward loss {loss:.5f} vs HF {want:.5f}"
 
 
+FULL_DEPTH_COS_MIN = 0.998      # the stated exception to GRAD_COS_MIN = 0.999 for weight gradients 54 bf16 layers deep (see the test's docstring)
+
+
+def test_full_depth_backward_probe_gradients_vs_reference(nvila8b):
+    """Round 6 (parity hardening ii): the BACKWARD at the full 26 + 28 layer depth.  One sample of configs[2] (1 image + 512
+    tokens, S = 769, 256 targets) through `SFTTrainer.forward_backward`; the gradients of 14 probe tensors that together see the whole chain —
+    the patch embedding (its gradient has crossed all 54 layers), tower layers 0 / 25, both projector tensors, decoder layers 0 / 13 / 27, the
+    final norm, lm_head — against torch autograd through the REFERENCE'S OWN modules in fp32 (reference SigLIP + projector by file path, HF
+    Qwen2ForCausalLM with HF's loss; oracle/make_golden_full_grads_ref.py, tests/golden/nvila8b_full_depth_grads_ref.npz: a seeded random subset of
+    <= 16 384 elements per tensor + the full tensor's norm).
+    Bounds.  SURVEY 8c states cosine >= 0.999; at THIS depth that is a statement about bf16, not about the kernels: a weight gradient dY^T X
+    inherits the error of its X, and bf16 activations 54 layers deep differ from fp32 by a few % (the forward pins allow rel-L2 2e-2 per stage).
+    Stated per-tensor exception for this test, with the measurements it was read from (profiles/r06_full_depth_backward_probes.txt): every probe
+    >= 0.998 (measured 0.99847 ... 0.99981; >= 0.999 for the last layer's o_proj, the final norm and lm_head), AND — the fixture's second pass —
+    every probe at least as close to the fp32 gradient as THE REFERENCE'S OWN MODULES RUN IN BF16 are (`cosb_<k>`: 0.985 ... 0.999 on the same
+    tensors: the HIP step's fp32 accumulation and fp32 softmax / norm statistics put it an order of magnitude closer than a plain bf16 run).
+    Norms within 3 %, the loss within 1e-2."""
+    from oracle.make_golden_full import sft_batch
+    from tests.gpu_util import GRAD_COS_MIN, grad_cos
+    from vila_amd.train import SFTTrainer
+    fx, cfg, seed, model = nvila8b
+    gx = np.load(os.path.join(os.path.dirname(__file__), "golden", "nvila8b_full_depth_grads_ref.npz"))
+    tail = cfg.lm_head_tail
+    cfg.lm_head_tail = 0.0                                        # the plain synthetic head, as in the forward pin above
+    specs = {n: (shape, kind) for n, shape, kind in synthetic.all_specs(cfg)}
+    with torch.no_grad():
+        model.llm.lm_head.weight.copy_(synthetic._draw("llm.lm_head.weight", *specs["llm.lm_head.weight"], cfg, seed, "cpu"))
+    cfg.lm_head_tail = tail
+    spx, sids, slabels = sft_batch(cfg, seed)
+    assert int(gx["seed"]) == seed and np.array_equal(sids[0].numpy(), gx["input_ids"]) and np.array_equal(slabels[0].numpy(), gx["labels"])
+    assert np.array_equal(spx[0].reshape(-1)[:16].numpy(), gx["fp_pixels"])
+    n_items = int(gx["num_items"])
+    tr = SFTTrainer(model, lr=0.0, weight_decay=0.0, optimizer_state=False)
+    loss = float(tr.forward_backward(sids[0:1], [spx[0].to(torch.bfloat16).cuda()], slabels[0:1], None, n_items))
+    torch.cuda.synchronize()
+    want = float(gx["loss"])
+    print(f"full-depth one-sample loss: HIP {loss:.5f} vs reference {want:.5f}")
+    assert abs(loss - want) <= 1e-2 * max(1.0, abs(want)), (loss, want)
+    grads = tr.flat.named_grads()
+    report, bad = [], []
+    for k, name in enumerate(gx["names"].tolist()):
+        idx = torch.from_numpy(gx[f"gi_{k}"]).long()
+        ref = torch.from_numpy(gx[f"gv_{k}"])
+        got = grads[name].reshape(-1)[idx.cuda()].float().cpu()
+        cos = grad_cos("full_depth", name, got, ref)
+        cos_ref_bf16 = float(gx[f"cosb_{k}"])
+        ratio = float(got.double().norm() / ref.double().norm())
+        full = float(grads[name].float().norm()) / float(gx[f"gn_{k}"])
+        report.append(f"{name.split('.', 2)[-1][-48:]:48s} cos {cos:.5f} (reference in bf16: {cos_ref_bf16:.5f}) |subset| ratio {ratio:.4f} |full| ratio {full:.4f}")
+        tight = name in ("llm.model.layers.27.self_attn.o_proj.weight", "llm.model.norm.weight", "llm.lm_head.weight")
+        if cos < (GRAD_COS_MIN if tight else FULL_DEPTH_COS_MIN) or cos < cos_ref_bf16 or not (0.97 <= ratio <= 1.03) or not (0.97 <= full <= 1.03):
+            bad.append((name, round(cos, 5), round(ratio, 4), round(full, 4)))
+    print("\n".join(report))
+    assert not bad, bad
+
+
 def test_lite3b_full_depth_vs_reference_executed_golden():
     """BASELINE configs[0] at its real size: NVILA-Lite-3B-shaped widths (hidden 2048, 16/2 heads, FFN 11008, tied head, 3x3 projector), 26 ViT +
     36 decoder layers, 1 image + 32-token prompt (S = 154), against the REFERENCE-EXECUTED fixture (reference SigLIP + projector + HF Qwen2 in

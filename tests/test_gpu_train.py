@@ -335,6 +335,75 @@ def test_sft_dynamic_s2_at_8b_widths_matches_oracle_autograd():
               f"{ref:.5f}; worst grad cosine {worst[0]:.4f}, worst rel-L2 {worst[1]:.4f}")
 
 
+def test_two_identical_steps_produce_identical_bits():
+    """Round 6 (parity hardening iii): no reduction of the step is order-dependent any more — the column sums (bias gradients),
+    the norm backward's dw / db, the CE row sum, the embedding-row scatter with REPEATED token ids and the clipping norm are fixed-order two-pass
+    sums (train.hip).  Two fresh trainers on the same batch: gradients, loss and the post-step master weights are equal BIT FOR BIT, with the
+    weight-gradient GEMMs on their side stream and the per-bucket optimizer on its own."""
+    from vila_amd import configs, synthetic
+    from vila_amd.train import SFTTrainer
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny("mlp_downsample")
+    px = synthetic.make_pixels(cfg, 2, 6).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 40, (2, 24), generator=g)                    # a 40-id alphabet over 48 positions: every id repeats
+    ids[:, 0] = cfg.image_token_id
+    labels = ids.clone(); labels[:, :6] = -100
+    outs = []
+    for _ in range(2):
+        tr = SFTTrainer(build_model(cfg, seed=6), lr=1e-3, max_grad_norm=1.0)
+        loss = float(tr.forward_backward(ids, [p.cuda() for p in px], labels))
+        torch.cuda.synchronize()
+        grads = tr.flat.grads.clone()
+        tr2 = SFTTrainer(build_model(cfg, seed=6), lr=1e-3, max_grad_norm=1.0)
+        l2 = [float(tr2.step(ids, [p.cuda() for p in px], labels)) for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((loss, grads, l2, tr2.flat.master.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and torch.equal(outs[0][3], outs[1][3])
+    assert float(outs[0][1].float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("algo", ["all_reduce", "direct"])
+def test_gradient_exchange_over_nccl_in_a_world_of_one_equals_the_step_without_exchange(algo):
+    """Round 6 (VERDICT round 5, item 9 i): the data-parallel exchange on the backend the driver's --gpus N uses.  backend "nccl" (= RCCL) is
+    brought up in a world of ONE and `GradReducer(force=True)` pushes EVERY gradient bucket of a real forward + backward through it — the
+    per-bucket all-reduce and the all-pairs form (all-to-all of shards + rank-ordered fp32 sum + all-gather) — on the optimizer stream, with
+    the per-bucket AdamW behind each.  A sum over one rank is the identity, and the step's reductions are deterministic, so gradients and
+    post-step masters must equal the no-exchange step's BIT FOR BIT; every bucket must have been handed to the group."""
+    import torch.distributed as dist
+    from vila_amd import configs, synthetic
+    from vila_amd.train import GradReducer, SFTTrainer
+    from vila_amd.vlm import build_model
+    cfg = configs.tiny("mlp_downsample")
+    px = synthetic.make_pixels(cfg, 2, 9).to(torch.bfloat16)
+    ids = torch.stack([synthetic.make_prompt(cfg, 20, 1, 90 + i) for i in range(2)], 0)
+    labels = ids.clone(); labels[:, :9] = -100
+
+    def run(tr):
+        losses = [float(tr.step(ids, [p.cuda() for p in px], labels)) for _ in range(2)]
+        torch.cuda.synchronize()
+        return losses, tr.flat.grads.clone(), tr.flat.master.clone()
+    plain = run(SFTTrainer(build_model(cfg, seed=9), lr=1e-3))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr = SFTTrainer(build_model(cfg, seed=9), lr=1e-3)
+        tr.reducer = GradReducer(tr.flat, None, force=True, algo=algo)
+        assert tr.reducer.active() and dist.get_backend() == "nccl"
+        got = run(tr)
+        n_buckets = len({p for p, _, _ in tr.reducer.log})
+        assert n_buckets >= cfg.llm.num_hidden_layers + cfg.vision.num_used_layers + 3
+        assert tr.reducer.exchanged_bytes >= 2 * tr.flat.numel * 2 * 0.99          # two steps x every parameter's bf16 gradient
+    finally:
+        dist.destroy_process_group()
+    assert got[0] == plain[0], (got[0], plain[0])
+    assert torch.equal(got[1], plain[1]) and torch.equal(got[2], plain[2])
+
+
 def test_sft_step_updates_parameters_and_lowers_loss():
     from vila_amd import configs, synthetic
     from vila_amd.train import SFTTrainer, count_targets

@@ -422,7 +422,20 @@ def test_continuous_batcher_returns_the_slot_when_admission_fails_and_survives_a
             fd.result(timeout=30)
         with pytest.raises(RuntimeError, match="worker died"):
             b.submit("F:3", 48).result(timeout=30)
+        # ADVICE round 5, the race: a request that passes `submit`'s first check while the worker is alive, and whose put lands BEHIND the dying
+        # worker's drain, used to sit in a queue nobody reads.  Replayed deterministically: the first check sees a live worker, the put "loses the
+        # race" (the queue is already drained and `dead` set by the time it returns) — the re-check behind the put must fail the request.
+        err, real_put = b.dead, b._q.put
+        assert err is not None
+        b.dead = None
+        def late_put(item):
+            real_put(item)
+            b.dead = err
+        b._q.put = late_put
+        with pytest.raises(RuntimeError, match="worker died"):
+            b.submit("G:5", 48).result(timeout=5)
     finally:
+        b._q.put = real_put
         b.close()
 
 

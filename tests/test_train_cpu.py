@@ -153,8 +153,8 @@ def _adamw_reference(master, m, v, grad, param, lr, b1, b2, eps, wd, step, grad_
     param.copy_(master.to(param.dtype))
 
 
-def _dp_step_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _dp_step_worker(rank, world, port, q, algo="all_reduce"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VILA_GRAD_EXCHANGE=algo)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vila_amd import ops
@@ -162,7 +162,9 @@ def _dp_step_worker(rank, world, port, q):
         torch.manual_seed(0)
         m = _tiny_model()                                    # same weights on every rank (same seed)
         ops.adamw_step = _adamw_reference                    # no GPU here: the optimizer kernel is replaced by its torch restatement
+        ops.grad_accum = _grad_accum_reference               # (the direct exchange's rank-ordered fp32 sum)
         tr = SFTTrainer(m, lr=1e-2, weight_decay=0.01)
+        assert tr.reducer.algo == algo
         tr.flat.grads = tr.flat.grads.float()                # gloo has no bf16 sum on every build; the logic is dtype-agnostic
         cfg = m.cfg
         # every rank has a different batch: different target counts (rank 0: 5 targets, rank 1: 9)
@@ -226,15 +228,18 @@ def _decays_like_the_reference(name, shape):
     return True
 
 
-def test_dp_step_gloo_world2_global_count_loss_scaling_and_identical_masters():
+@pytest.mark.parametrize("algo", ["all_reduce", "direct"])
+def test_dp_step_gloo_world2_global_count_loss_scaling_and_identical_masters(algo):
     """the whole data-parallel step around the (stubbed) forward+backward on two gloo ranks —
     `global_num_items` sums the per-rank target counts (transformer_normalize_monkey_patch.py:261-263), each rank's loss is its
     sum CE / GLOBAL count so that the SUM over ranks is the global mean (:242-247), every bucket is exchanged, and after the optimizer
-    step both ranks hold bit-identical fp32 masters equal to what a single process with both batches computes."""
+    step both ranks hold bit-identical fp32 masters equal to what a single process with both batches computes.
+    Round 6 (VERDICT round 5, item 9 ii): both exchange algorithms — the per-bucket all-reduce and the all-pairs form (all-to-all of shards,
+    rank-ordered fp32 sum by the owner, all-gather: `GradReducer(algo="direct")`, VILA_GRAD_EXCHANGE=direct) — end in the same masters."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + (7 if algo == "direct" else 0)
+    procs = [ctx.Process(target=_dp_step_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])

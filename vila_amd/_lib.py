@@ -158,7 +158,7 @@ PROTOTYPES = {
     "vila_grad_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vila_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "vila_norm_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p]),
-    "vila_ce_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),
+    "vila_ce_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),
     "vila_scatter_add_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vila_depth_to_space_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vila_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -173,7 +173,9 @@ PROTOTYPES = {
                                 c_float, c_void_p]),
     "vila_adamw_step_lean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
                                      c_float, c_void_p]),
-    "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "vila_sumsq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vila_colsum_scratch_floats": (c_size_t, [c_int, c_int]),
+    "vila_norm_bwd_scratch_floats": (c_size_t, [c_int, c_int]),
     "vila_gemv_w4_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_void_p]),
     "vila_llm_decode_step_w4": (c_int, [C.POINTER(VilaLlmWeights), C.POINTER(VilaLlmLayerW4), C.POINTER(VilaKvCache),

@@ -812,9 +812,9 @@ extern "C" int vila_norm_bwd_bf16(const void* x, const void* w, const void* dy, 
                                   float eps, int rms, int accumulate, vila_stream_t stream) {
     return launch_norm_bwd(B(x), B(w), B(dy), B(dx), B(dw), B(db), scratch, rows, cols, eps, rms, accumulate, S(stream));
 }
-extern "C" int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, int rows, int V, int64_t ldl, float scale,
+extern "C" int vila_ce_loss_f32(const float* logits, const int64_t* labels, void* dlogits, float* loss, float* row_loss, int rows, int V, int64_t ldl, float scale,
                                 vila_stream_t stream) {
-    return launch_ce(logits, labels, B(dlogits), loss, rows, V, ldl, scale, S(stream));
+    return launch_ce(logits, labels, B(dlogits), loss, row_loss, rows, V, ldl, scale, S(stream));
 }
 extern "C" int vila_scatter_add_rows_bf16(const void* src, void* dst, const int32_t* rows, int n, int H, vila_stream_t stream) {
     return launch_scatter_add_rows(B(src), B(dst), rows, n, H, S(stream));
@@ -866,7 +866,9 @@ extern "C" int vila_adamw_step_lean(float* master, float* m, float* v, const voi
                                     float eps, float weight_decay, int step, float grad_scale, vila_stream_t stream) {
     return launch_adamw_lean(master, m, v, B(grad), B(param), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
 }
-extern "C" int vila_sumsq_bf16(const void* x, int64_t n, float* out, vila_stream_t stream) { return launch_sumsq(B(x), n, out, S(stream)); }
+extern "C" int vila_sumsq_bf16(const void* x, int64_t n, float* out, float* scratch, vila_stream_t stream) { return launch_sumsq(B(x), n, out, scratch, S(stream)); }
+extern "C" size_t vila_colsum_scratch_floats(int rows, int cols) { return colsum_scratch_floats(rows, cols); }
+extern "C" size_t vila_norm_bwd_scratch_floats(int rows, int cols) { return norm_bwd_scratch_floats(rows, cols); }
 
 // dynamic_s2: merge_chessboard + area interpolation + concat + split_chessboard in one gather
 extern "C" int vila_s2_merge_bf16(const void* feats, void* out, const int32_t* desc, int n_blocks, int grid, int channels, int n_scales,

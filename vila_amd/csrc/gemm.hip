@@ -211,7 +211,7 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_t s);
 bool gemm_ring_supported(const GemmArgs& a);
 int launch_gemm_ring(const GemmArgs& a, int stages, hipStream_t s);
-int gemm_ring_splitk_slices(const GemmArgs& a);      // gemm_ring_splitk.hip: K-sliced 128x64 ring for short prompts (unmeasured, opt-in)
+int gemm_ring_splitk_slices(const GemmArgs& a);      // gemm_ring_splitk.hip: K-sliced 128x64 ring for short prompts (measured in round 5: the default for M < 512; VILA_RING_SPLITK=0 turns it off)
 int launch_gemm_ring_splitk(const GemmArgs& a, int splits, hipStream_t s);
 static int g_force_tile = 0;   // test / tuning hook: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 256x128, 4 = 256x256 LDS-DMA kernel, 5 = split-K, 6 / 7 = 128x64 DMA ring with 4 / 3 stages, 8 = 128x128 DMA ring (2 stages), 11 = K-sliced 128x64 ring (needs a workspace), 12 / 13 / 14 = rings 7 / 8 / 6 with the PIPE 2 fragment schedule whatever VILA_RING_PIPE says, 15 / 16 / 17 = the same three with the plain schedule
 extern "C" void vila_gemm_force_tile(int t) { g_force_tile = t; }

@@ -295,7 +295,8 @@ static int launch_ring_epi(const GemmArgs& a, hipStream_t s) {
 }
 
 // variant: 3 = 128x64 tile, 3 stages (2 blocks / CU); 4 = 128x64, 4 stages (1 block / CU); 8 = 128x128 tile, 2 stages (2 blocks / CU).
-// + 200 = PIPE 2 explicitly, + 300 = the plain fragment schedule explicitly (tests / tools/gemm_bench); otherwise VILA_RING_PIPE decides (default 2).
+// + 200 = PIPE 2 explicitly, + 300 = the plain fragment schedule explicitly (tests / tools/gemm_bench); otherwise VILA_RING_PIPE decides: "0" = the plain schedule, anything else (or unset) = PIPE 2 — the compiler-scheduled PIPE 1 of round 4 was
+// measured and deleted in round 5, so VILA_RING_PIPE=1 means PIPE 2 today.
 static int ring_pipe_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VILA_RING_PIPE"); v = (e && e[0] == '0') ? 0 : 2; }

@@ -62,7 +62,7 @@ int linear_bwd(Ctx& c, const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_
                int M, int N, int K, bool cm, bool use_ws = false) {
     if (cm && M >= 128 && N >= 128 && N % 8 == 0 && K % 8 == 0) {
         VILA_TRY(gemm(c, dy, N, x, K, nullptr, nullptr, 0, gw, K, N, K, M, EPI_NONE, 0, 1, 1, 0, use_ws));          // dW = dY^T X
-        if (gb) { float* scr = c.w->take<float>(N); RUN(launch_colsum(dy, gb, scr, M, N, N, 0, 0, c.s)); }
+        if (gb) { float* scr = c.w->take<float>(colsum_scratch_floats(M, N)); RUN(launch_colsum(dy, gb, scr, M, N, N, 0, 0, c.s)); }
         if (dx) VILA_TRY(gemm(c, dy, N, w, K, nullptr, dx_res, K, dx, K, M, K, N, EPI_NONE, 0, 0, 1, 0, use_ws));   // dX = dY W
         return 0;
     }
@@ -72,7 +72,7 @@ int linear_bwd(Ctx& c, const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_
     RUN(launch_transpose(dy, dyt, M, N, N, Mp, c.s));
     RUN(launch_transpose(x, xt, M, K, K, Mp, c.s));
     VILA_TRY(gemm(c, dyt, Mp, xt, Mp, nullptr, nullptr, 0, gw, K, N, K, Mp));
-    if (gb) { float* scr = c.w->take<float>(N); RUN(launch_colsum(dy, gb, scr, M, N, N, 0, 0, c.s)); }
+    if (gb) { float* scr = c.w->take<float>(colsum_scratch_floats(M, N)); RUN(launch_colsum(dy, gb, scr, M, N, N, 0, 0, c.s)); }
     if (dx) {
         const int Np = (N + 63) / 64 * 64;
         bf16_t* wt = c.w->take<bf16_t>((size_t)K * Np);
@@ -84,7 +84,7 @@ int linear_bwd(Ctx& c, const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_
 }
 
 int norm_bwd(Ctx& c, const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, int rows, int cols, float eps, int rms) {
-    float* scr = c.w->take<float>(2 * (size_t)cols);
+    float* scr = c.w->take<float>(norm_bwd_scratch_floats(rows, cols));
     RUN(launch_norm_bwd(x, w, dy, dx, dw, db, scr, rows, cols, eps, rms, 0, c.s));
     return 0;
 }
@@ -261,9 +261,10 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         float* logits = a.take<float>((size_t)nt * ls.vocab);
         bf16_t* dlog = a.take<bf16_t>((size_t)nt * ls.vocab);
         bf16_t* dhv = a.take<bf16_t>((size_t)nt * H);
+        float* row_loss = a.take<float>((size_t)nt);
         RUN(launch_copy_rows(hn, hv, b->target_rows, nullptr, nt, H, c.s));
         VILA_TRY(gemm(c, hv, H, B(llm->lm_head), H, nullptr, nullptr, 0, logits, ls.vocab, nt, ls.vocab, H, EPI_NONE, 1));
-        RUN(launch_ce(logits, b->targets, dlog, loss_out, nt, ls.vocab, ls.vocab, b->loss_scale, c.s));
+        RUN(launch_ce(logits, b->targets, dlog, loss_out, row_loss, nt, ls.vocab, ls.vocab, b->loss_scale, c.s));
         VILA_TRY(linear_bwd(c, hv, B(llm->lm_head), dlog, g_head, nullptr, dhv, nullptr, nt, ls.vocab, H, true, true));
         RUN(launch_copy_rows(dhv, dhn, nullptr, b->target_rows, nt, H, c.s));
     }
@@ -418,7 +419,7 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
         bf16_t* dvt = a.take<bf16_t>((size_t)D * Mp);
         bf16_t* pt = a.take<bf16_t>((size_t)Kp * Mp);
         bf16_t* gwp = a.take<bf16_t>((size_t)D * Kp);
-        float* scr = a.take<float>(D);
+        float* scr = a.take<float>(colsum_scratch_floats(Mv, D));
         RUN(launch_transpose(dv, dvt, Mv, D, D, Mp, c.s));
         RUN(launch_transpose(patches, pt, Mv, Kp, Kp, Mp, c.s));
         VILA_TRY(gemm(c, dvt, Mp, pt, Mp, nullptr, nullptr, 0, gwp, Kp, D, Kp, Mp));

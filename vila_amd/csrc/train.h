@@ -25,7 +25,7 @@ int launch_grad_accum(float* acc, const bf16_t* g, bf16_t* out, int64_t n, int m
 int launch_colsum(const bf16_t* x, bf16_t* out, float* scratch, int R, int C, int64_t ld, int accumulate, int period, hipStream_t s);
 int launch_norm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* dy, bf16_t* dx, bf16_t* dw, bf16_t* db, float* scratch,
                     int rows, int cols, float eps, int rms, int accumulate, hipStream_t s);
-int launch_ce(const float* logits, const int64_t* labels, bf16_t* dlogits, float* loss, int rows, int V, int64_t ldl, float scale, hipStream_t s);
+int launch_ce(const float* logits, const int64_t* labels, bf16_t* dlogits, float* loss, float* row_loss, int rows, int V, int64_t ldl, float scale, hipStream_t s);
 int launch_scatter_add_rows(const bf16_t* src, bf16_t* dst, const int32_t* rows, int n, int H, hipStream_t s);
 int launch_depth_to_space(const bf16_t* dy, bf16_t* dx, int B, int g, int C, int k, hipStream_t s);
 int launch_rope_bwd(bf16_t* dqkv, const float* cs, const float* sn, int S, int nq, int nkv, int hd, hipStream_t s);
@@ -33,4 +33,7 @@ int launch_adamw(float* master, float* m, float* v, const bf16_t* grad, bf16_t* 
                  float wd, int step, float grad_scale, hipStream_t s);
 int launch_adamw_lean(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
                       float wd, int step, float grad_scale, hipStream_t s);
-int launch_sumsq(const bf16_t* x, int64_t n, float* out, hipStream_t s);
+#define SUMSQ_PARTS 2048
+int launch_sumsq(const bf16_t* x, int64_t n, float* out, float* scratch, hipStream_t s);
+size_t colsum_scratch_floats(int R, int C);
+size_t norm_bwd_scratch_floats(int rows, int cols);

@@ -308,19 +308,22 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 def grad_accum(acc: torch.Tensor, g: torch.Tensor, out: Optional[torch.Tensor] = None, mode: int = 1) -> None:
     """Gradient accumulation in fp32 (vila_grad_accum_f32): mode 0 acc = g, 1 acc += g, 2 out = bf16(acc + g)."""
     assert acc.dtype == torch.float32 and g.dtype == torch.bfloat16 and acc.numel() == g.numel() and acc.is_contiguous() and g.is_contiguous()
+    assert int(mode) in (0, 1, 2) and g.numel() % 8 == 0, (mode, g.numel())
+    if int(mode) == 2:       # ADVICE round 5: a mode-2 call without (or with a mis-shaped) output used to be caught only inside the library
+        assert out is not None and out.dtype == torch.bfloat16 and out.numel() == g.numel() and out.is_contiguous() and out.device == g.device
     check(_L().vila_grad_accum_f32(acc.data_ptr(), g.data_ptr(), _p(out), g.numel(), int(mode), _stream()), "grad_accum")
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False, period: int = 0) -> None:
     assert x.dim() == 2 and x.stride(1) == 1 and out.is_contiguous()
-    scratch = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32) if period == 0 else None
+    scratch = torch.empty((int(_L().vila_colsum_scratch_floats(x.shape[0], x.shape[1])),), device=x.device, dtype=torch.float32) if period == 0 else None
     check(_L().vila_colsum_bf16(x.data_ptr(), out.data_ptr(), _p(scratch), x.shape[0], x.shape[1], x.stride(0), int(accumulate), period, _stream()), "colsum")
 
 
 def norm_bwd(x, w, dy, dw_out, db_out, eps: float, rms: bool, accumulate: bool = False) -> torch.Tensor:
     x2, dy2 = x.reshape(-1, x.shape[-1]), dy.reshape(-1, x.shape[-1])
     dx = torch.empty_like(x2)
-    scratch = torch.empty((2 * x2.shape[1],), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((int(_L().vila_norm_bwd_scratch_floats(x2.shape[0], x2.shape[1])),), device=x.device, dtype=torch.float32)
     check(_L().vila_norm_bwd_bf16(x2.data_ptr(), w.data_ptr(), dy2.data_ptr(), dx.data_ptr(), dw_out.data_ptr(), _p(db_out),
                                   scratch.data_ptr(), x2.shape[0], x2.shape[1], eps, int(rms), int(accumulate), _stream()), "norm_bwd")
     return dx.view(x.shape)
@@ -331,7 +334,9 @@ def ce_loss(logits: torch.Tensor, labels: torch.Tensor, loss_acc: torch.Tensor, 
     _need(logits, dtype=torch.float32, name="logits")
     n, V = logits.shape
     d = torch.empty((n, V), device=logits.device, dtype=torch.bfloat16)
-    check(_L().vila_ce_loss_f32(logits.data_ptr(), labels.data_ptr(), d.data_ptr(), loss_acc.data_ptr(), n, V, logits.stride(0), scale, _stream()), "ce_loss")
+    row_loss = torch.empty((max(n, 1),), device=logits.device, dtype=torch.float32)
+    check(_L().vila_ce_loss_f32(logits.data_ptr(), labels.data_ptr(), d.data_ptr(), loss_acc.data_ptr(), row_loss.data_ptr(), n, V, logits.stride(0), scale,
+                                _stream()), "ce_loss")
     return d
 
 
@@ -408,7 +413,8 @@ def adamw_step(master, m, v, grad, param, lr, beta1, beta2, eps, wd, step: int, 
 
 def sumsq(x: torch.Tensor) -> torch.Tensor:
     out = torch.zeros((1,), device=x.device, dtype=torch.float32)
-    check(_L().vila_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sumsq")
+    scratch = torch.empty((2048,), device=x.device, dtype=torch.float32)          # VILA_SUMSQ_SCRATCH_FLOATS
+    check(_L().vila_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), scratch.data_ptr(), _stream()), "sumsq")
     return out
 
 

@@ -584,6 +584,7 @@ class ContinuousBatcher:
         self.events: List[tuple] = []                    # ("admit" | "retire" | "solo" | "run", ...) — observability / tests
         self.thread_ids = set()
         self._stop = False
+        self.dead: Optional[BaseException] = None        # set (BEFORE the queue is drained) when the worker thread has died
         self._thread = threading.Thread(target=self._loop, daemon=True)
         self._thread.start()
 
@@ -595,10 +596,15 @@ class ContinuousBatcher:
         from concurrent.futures import Future
         f: Future = Future()
         req = SimpleNamespace(prompt=prompt, max_new=int(max_new_tokens), system=system, gen=gen, fut=f, stream=stream)
-        if getattr(self, "dead", None) is not None:
+        if self.dead is not None:
             self._fail(req, self.dead)
             return f
         self._q.put(req)
+        # the worker may have died between the check above and the put — it sets `dead` BEFORE it drains the queue, so a request
+        # that slipped in behind the drain sees `dead` here and fails now instead of waiting in a queue nobody reads (a request the drain did
+        # reach is failed there; failing a future / stream twice is harmless: `_fail` ignores the second)
+        if self.dead is not None:
+            self._fail(req, self.dead)
         return f
 
     def close(self):
@@ -613,6 +619,9 @@ class ContinuousBatcher:
 
     @staticmethod
     def _fail(req, ex) -> None:
+        if getattr(req, "_failed", False):               # (a dying worker's drain and `submit`'s re-check may both reach a request)
+            return
+        req._failed = True
         if not req.fut.done():
             req.fut.set_exception(ex)
         if getattr(req, "stream", None) is not None:
@@ -654,6 +663,7 @@ class ContinuousBatcher:
         except BaseException as ex:                                    # noqa: BLE001 — the thread is going away either way
             self._stop = True
             err = RuntimeError(f"batcher worker died: {ex!r}")
+            self.dead = err                                             # first: `submit` re-checks it behind its put (see there)
             for r in list(rows.values()):
                 self._fail(r.req, err)
             for p in pending:
@@ -665,7 +675,6 @@ class ContinuousBatcher:
                     break
                 if item is not None:
                     self._fail(item, err)
-            self.dead = err
 
     def _loop_body(self, pending, rows):
         import queue

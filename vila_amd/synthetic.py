@@ -146,6 +146,12 @@ def make_prompt(cfg: VilaConfig, n_text: int, n_images: int = 1, seed: int = 0) 
     g = torch.Generator(device="cpu").manual_seed(2000 + seed)
     hi = min(cfg.llm.vocab_size, cfg.image_token_id, cfg.llm.eos_token_id) - 1
     ids = torch.randint(0, hi, (n_text,), generator=g, dtype=torch.int64)
+    # `_media_plan` registers the video token too, so a stray video id without a video would raise.  The committed fixtures pin the draw above
+    # (their configs keep the video id at or above `hi`), so a config whose video id lies INSIDE the range has those draws moved off it instead
+    # of the range changed
+    vid = getattr(cfg, "video_token_id", None)
+    if vid is not None and 0 <= vid < hi:
+        ids = torch.where(ids == vid, torch.full_like(ids, vid - 1 if vid > 0 else 1), ids)
     img = torch.full((n_images,), cfg.image_token_id, dtype=torch.int64)
     return torch.cat([img, ids])
 

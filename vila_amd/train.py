@@ -153,12 +153,27 @@ class FlatParams:
         return runs
 
 
-class GradReducer:
-    """Bucketed SUM all-reduce of slices of the flat gradient buffer, one bucket per layer, issued as soon as the layer's
-    backward has been enqueued (DDP-style overlap; RCCL runs on its own stream, ordered after the compute stream at call time).
-    With no process group (single GPU) it only records the order — which the CPU/gloo test checks."""
+class _Done:
+    """Handle of an exchange that was issued synchronously with respect to the calling stream."""
 
-    def __init__(self, flat: FlatParams, group=None, force: Optional[bool] = None):
+    def wait(self) -> None:
+        return None
+
+
+class GradReducer:
+    """Bucketed SUM exchange of slices of the flat gradient buffer, one bucket per layer, issued as soon as the layer's backward has been
+    enqueued (DDP-style overlap; RCCL runs on its own stream, ordered after the compute stream at call time).  With no process group (single
+    GPU) it only records the order — which the CPU/gloo test checks.
+
+    Two algorithms (`algo`, environment VILA_GRAD_EXCHANGE), same result up to the summation order of the W contributions:
+      "all_reduce" (default): one async `all_reduce(SUM)` per bucket — the algorithm is RCCL's choice (a ring is single-link bound on xGMI:
+                   SURVEY 8e computes 184 ms for 16 GB);
+      "direct"    : the all-pairs form SURVEY 8e asks for — `all_to_all_single` of the bucket cut into W shards (every GPU sends shard j
+                   straight to GPU j: all 7 xGMI links of a GPU carry 1/8 of the bucket each), the owner adds the W pieces in RANK order in
+                   fp32 (`vila_grad_accum_f32`: one rounding, and the same bits whatever the arrival order), `all_gather_into_tensor` of the
+                   summed shards.  2 x (W-1)/W of the bucket per GPU, like a ring, but over W-1 links at once."""
+
+    def __init__(self, flat: FlatParams, group=None, force: Optional[bool] = None, algo: Optional[str] = None):
         self.flat = flat
         self.group = group
         self.handles = []
@@ -169,20 +184,56 @@ class GradReducer:
         # force: issue the collectives even in a world of one (exercises the RCCL call path, its stream ordering and wait() on a
         # 1-GPU box: bench.py sets it under VILA_BENCH_FORCE_DIST)
         self.force = bool(os.environ.get("VILA_BENCH_FORCE_DIST")) if force is None else force
+        self.algo = algo or os.environ.get("VILA_GRAD_EXCHANGE", "all_reduce")
+        if self.algo not in ("all_reduce", "direct"):
+            raise ValueError(f"VILA_GRAD_EXCHANGE: unknown algorithm {self.algo!r} (all_reduce | direct)")
+        self._send = self._recv = self._acc = None          # direct: grow-only staging of one bucket (bf16 send / recv, fp32 sum of a shard)
+        self.exchanged_bytes = 0
 
     def active(self) -> bool:
         return self.dist is not None and (self.dist.get_world_size(self.group) > 1 or self.force)
 
     def ready(self, prefix: str):
-        """Announce that every gradient under `prefix` is final; returns the async work handle (None without an exchange).  The
+        """Announce that every gradient under `prefix` is final; returns a work handle (None without an exchange).  The
         collective is ordered after the CURRENT stream, so call it inside the stream context that produced / waited for the grads."""
         a, b = self.flat.span(prefix)
         self.log.append((prefix, a, b))
         if not self.active():
             return None
-        h = self.dist.all_reduce(self.flat.grads[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.exchanged_bytes += (b - a) * 2
+        if self.algo == "direct":
+            h = self._direct(self.flat.grads[a:b])
+        else:
+            h = self.dist.all_reduce(self.flat.grads[a:b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
         return h
+
+    def _direct(self, g: torch.Tensor):
+        """all-to-all of W shards -> owner sums in rank order (fp32) -> all-gather; in place on `g` (a slice of the flat bf16 buffer)."""
+        dist = self.dist
+        W = dist.get_world_size(self.group)
+        n = g.numel()
+        shard = (-(-n // W) + 7) // 8 * 8                     # 16-byte multiples per shard
+        P = shard * W
+        if self._send is None or self._send.numel() < P:
+            self._send = torch.empty((P,), device=g.device, dtype=g.dtype)
+            self._recv = torch.empty((P,), device=g.device, dtype=g.dtype)
+            self._acc = torch.empty((shard,), device=g.device, dtype=torch.float32)
+        send, recv, acc = self._send[:P], self._recv[:P], self._acc[:shard]
+        send[:n].copy_(g)
+        if P > n:
+            send[n:].zero_()
+        dist.all_to_all_single(recv, send, group=self.group)                     # recv[k * shard : (k + 1) * shard] = rank k's copy of MY shard
+        mine = send[:shard]                                                      # (send is free again: the summed shard is built in its head)
+        if W == 1:
+            mine.copy_(recv[:shard])
+        else:
+            for k in range(W):                                                   # acc = p0; acc += p1 ...; out = bf16(acc + p_{W-1}): rank order, fp32
+                piece = recv[k * shard:(k + 1) * shard]
+                ops.grad_accum(acc, piece, mine if k == W - 1 else None, mode=0 if k == 0 else (2 if k == W - 1 else 1))
+        dist.all_gather_into_tensor(recv, mine, group=self.group)
+        g.copy_(recv[:n])
+        return _Done()
 
     def wait(self) -> None:
         for h in self.handles:
@@ -193,7 +244,8 @@ class GradReducer:
         w = self.dist.get_world_size(self.group) if self.dist is not None else 1
         be = self.dist.get_backend(self.group) if self.dist is not None else "none"
         nb = len(self.log)
-        return (f"{nb} buckets (one per layer, reverse order), SUM all-reduce of flat bf16 grad slices, backend={be}, world={w}"
+        how = "SUM all-reduce" if self.algo == "all_reduce" else "all-to-all shards + rank-ordered fp32 sum + all-gather (all-pairs)"
+        return (f"{nb} buckets (one per layer, reverse order), {how} of flat bf16 grad slices, backend={be}, world={w}"
                 + ("" if w > 1 else (" (collectives issued in a world of one)" if self.active() else " (single rank: no exchange issued)")))
 
 
@@ -984,6 +1036,8 @@ class SFTTrainer:
         n_global = self._global_counts(n_local, len(images) + len(videos or []) > 0)
         # per-bucket AdamW needs the update to be a function of the bucket alone: not with global-norm clipping
         self._bucket_step = self.opt is not None and self.max_grad_norm is None and self.flat.master is not None
+        self._acc = None          # a plain step holds no accumulator: the fp32 sum of `step_accumulated` (4 B per parameter, 32 GB at 8 B
+        #                           parameters) is released as soon as accumulation is not in use
         try:
             fb = self.forward_backward_c if self.use_c_abi else self.forward_backward
             loss = fb(input_ids, images, labels, attention_mask, n_global, block_sizes, **({"videos": videos} if videos else {}))
