@@ -219,20 +219,27 @@ class GradReducer:
             self._send = torch.empty((P,), device=g.device, dtype=g.dtype)
             self._recv = torch.empty((P,), device=g.device, dtype=g.dtype)
             self._acc = torch.empty((shard,), device=g.device, dtype=torch.float32)
-        send, recv, acc = self._send[:P], self._recv[:P], self._acc[:shard]
-        send[:n].copy_(g)
-        if P > n:
+        recv, acc = self._recv[:P], self._acc[:shard]
+        whole = P == n                                        # every decoder / tower layer bucket: the slice itself is the send AND the gather buffer
+        if whole:
+            send = g
+        else:
+            send = self._send[:P]
+            send[:n].copy_(g)
             send[n:].zero_()
         dist.all_to_all_single(recv, send, group=self.group)                     # recv[k * shard : (k + 1) * shard] = rank k's copy of MY shard
-        mine = send[:shard]                                                      # (send is free again: the summed shard is built in its head)
+        mine = self._send[:shard]                                                # the summed shard (the staging buffer's head is free in both cases)
         if W == 1:
             mine.copy_(recv[:shard])
         else:
             for k in range(W):                                                   # acc = p0; acc += p1 ...; out = bf16(acc + p_{W-1}): rank order, fp32
                 piece = recv[k * shard:(k + 1) * shard]
                 ops.grad_accum(acc, piece, mine if k == W - 1 else None, mode=0 if k == 0 else (2 if k == W - 1 else 1))
-        dist.all_gather_into_tensor(recv, mine, group=self.group)
-        g.copy_(recv[:n])
+        if whole:
+            dist.all_gather_into_tensor(g, mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(recv, mine, group=self.group)
+            g.copy_(recv[:n])
         return _Done()
 
     def wait(self) -> None:
