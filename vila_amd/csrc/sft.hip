@@ -257,14 +257,21 @@ int run(const VilaVitWeights* vit, const VilaVitWeights* vg, const VilaProjWeigh
     const bool tied = llm->lm_head == llm->embed;
     bf16_t* g_head = tied ? B((void*)lg->embed) : B((void*)lg->lm_head);
     if (nt > 0) {
+        // lm_head + CE in chunks of SFT_LOGIT_CHUNK target rows: the fp32 logits are never materialised for the whole batch (SURVEY §7 step 7;
+        // the reference does, llava_llama.py:134-149) — 256 x vocab x 4 B at a time, the bf16 dlogits of all rows feed ONE wgrad / dgrad pair
+        constexpr int SFT_LOGIT_CHUNK = 256;
+        const int lc = nt < SFT_LOGIT_CHUNK ? nt : SFT_LOGIT_CHUNK;
         bf16_t* hv = a.take<bf16_t>((size_t)nt * H);
-        float* logits = a.take<float>((size_t)nt * ls.vocab);
+        float* logits = a.take<float>((size_t)lc * ls.vocab);
         bf16_t* dlog = a.take<bf16_t>((size_t)nt * ls.vocab);
         bf16_t* dhv = a.take<bf16_t>((size_t)nt * H);
-        float* row_loss = a.take<float>((size_t)nt);
+        float* row_loss = a.take<float>((size_t)lc);
         RUN(launch_copy_rows(hn, hv, b->target_rows, nullptr, nt, H, c.s));
-        VILA_TRY(gemm(c, hv, H, B(llm->lm_head), H, nullptr, nullptr, 0, logits, ls.vocab, nt, ls.vocab, H, EPI_NONE, 1));
-        RUN(launch_ce(logits, b->targets, dlog, loss_out, row_loss, nt, ls.vocab, ls.vocab, b->loss_scale, c.s));
+        for (int r0 = 0; r0 < nt; r0 += lc) {
+            const int rn = nt - r0 < lc ? nt - r0 : lc;
+            VILA_TRY(gemm(c, hv + (size_t)r0 * H, H, B(llm->lm_head), H, nullptr, nullptr, 0, logits, ls.vocab, rn, ls.vocab, H, EPI_NONE, 1));
+            RUN(launch_ce(logits, b->targets + r0, dlog + (size_t)r0 * ls.vocab, loss_out, row_loss, rn, ls.vocab, ls.vocab, b->loss_scale, c.s));
+        }
         VILA_TRY(linear_bwd(c, hv, B(llm->lm_head), dlog, g_head, nullptr, dhv, nullptr, nt, ls.vocab, H, true, true));
         RUN(launch_copy_rows(dhv, dhn, nullptr, b->target_rows, nt, H, c.s));
     }

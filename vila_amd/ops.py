@@ -329,11 +329,12 @@ def norm_bwd(x, w, dy, dw_out, db_out, eps: float, rms: bool, accumulate: bool =
     return dx.view(x.shape)
 
 
-def ce_loss(logits: torch.Tensor, labels: torch.Tensor, loss_acc: torch.Tensor, scale: float) -> torch.Tensor:
-    """logits [n, V] fp32, labels [n] i64 -> dlogits [n, V] bf16; loss_acc (fp32 scalar on device) += sum CE * scale."""
+def ce_loss(logits: torch.Tensor, labels: torch.Tensor, loss_acc: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits [n, V] fp32, labels [n] i64 -> dlogits [n, V] bf16 (into `out` when given); loss_acc (fp32 scalar on device) += sum CE * scale."""
     _need(logits, dtype=torch.float32, name="logits")
     n, V = logits.shape
-    d = torch.empty((n, V), device=logits.device, dtype=torch.bfloat16)
+    d = torch.empty((n, V), device=logits.device, dtype=torch.bfloat16) if out is None else out
+    assert d.shape == (n, V) and d.dtype == torch.bfloat16 and d.is_contiguous() and labels.is_contiguous()
     row_loss = torch.empty((max(n, 1),), device=logits.device, dtype=torch.float32)
     check(_L().vila_ce_loss_f32(logits.data_ptr(), labels.data_ptr(), d.data_ptr(), loss_acc.data_ptr(), row_loss.data_ptr(), n, V, logits.stride(0), scale,
                                 _stream()), "ce_loss")

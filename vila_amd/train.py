@@ -153,6 +153,9 @@ class FlatParams:
         return runs
 
 
+LOGIT_CHUNK = 256          # rows of fp32 logits alive at a time in the SFT step's lm_head + CE
+
+
 class _Done:
     """Handle of an exchange that was issued synchronously with respect to the calling stream."""
 
@@ -924,8 +927,15 @@ class SFTTrainer:
             rows32 = valid.to(torch.int32)
             hv = torch.empty((n_valid, H), device=dev, dtype=torch.bfloat16)
             ops.copy_rows(saved.hn, hv, rows32, None, n_valid)
-            logits = ops.gemm(hv, head, out_f32=True)                                    # [n_valid, V] fp32 only
-            dlog = ops.ce_loss(logits, tgt_valid, loss, 1.0 / max(n_items, 1))
+            # lm_head + CE in row chunks (llava_llama.py:134-149 materialises [sum S, V] fp32 logits; SURVEY §7 step 7: never do that): the
+            # rows WITH a target only (the others' gradient is exactly zero), LOGIT_CHUNK of them at a time — the fp32 logits buffer is
+            # bounded (256 x 152 064 x 4 B = 156 MB, resident in the 256-MB infinity cache for the CE kernel's three passes) whatever the
+            # batch; the bf16 dlogits of all rows are kept for the ONE wgrad / dgrad pair below
+            dlog = torch.empty((n_valid, head.shape[0]), device=dev, dtype=torch.bfloat16)
+            for r0 in range(0, n_valid, LOGIT_CHUNK):
+                r1 = min(n_valid, r0 + LOGIT_CHUNK)
+                logits = ops.gemm(hv[r0:r1], head, out_f32=True)                         # [<= LOGIT_CHUNK, V] fp32
+                ops.ce_loss(logits, tgt_valid[r0:r1], loss, 1.0 / max(n_items, 1), out=dlog[r0:r1])
             del logits
             dhv = linear_bwd(hv, head, dlog, G(head_name), cm=self.cm, ws=self.ws)
             ops.copy_rows(dhv, dhn, None, rows32, n_valid)
