@@ -465,7 +465,7 @@ def sft_flops_per_sample(cfg, S: int, n_targets: int = 256) -> float:
 def _sft_gemm_traffic():
     """L2-fill bytes per GEMM of the contraction-major (wgrad) kernel on the four decoder shapes of the step, from the committed rocprofv3 --pmc
     passes (tools/pmc_gemm_sft.sh -> profiles/r0N_pmc_gemm_sft.json, newest round first; cannot be collected inside this process), next to the algorithmic bytes."""
-    name = next((n_ for n_ in ("r05_pmc_gemm_sft.json", "r04_pmc_gemm_sft.json", "r03_pmc_gemm_sft.json") if os.path.exists(os.path.join(ROOT, "profiles", n_))), None)
+    name = next((n_ for n_ in ("r06_pmc_gemm_sft.json", "r05_pmc_gemm_sft.json", "r04_pmc_gemm_sft.json", "r03_pmc_gemm_sft.json") if os.path.exists(os.path.join(ROOT, "profiles", n_))), None)
     if name is None:
         return None
     tj = os.path.join(ROOT, "profiles", name)
@@ -728,7 +728,7 @@ def decode_main(a, rank, world, dev, dist):
     encode_ms = ev_a.elapsed_time(ev_b) / 3
     prefill_flops = vit_flops(cfg, n_tiles) + projector_flops(cfg, n_tiles) + llm_prefill_flops(cfg, S)
     pre_traffic = None          # L2-fill bytes of the prefill's dominant kernel (fused gate/up GEMM) from the committed --pmc passes of THIS command
-    tj = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(p_)), None)
+    tj = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")) if os.path.exists(p_)), None)
     if a.config == "nvila_8b" and not a.dynamic_s2 and tj is not None:
         with open(tj) as f:
             pre_traffic = json.load(f).get("prefill_gateup")
@@ -849,7 +849,7 @@ def decode_main(a, rank, world, dev, dist):
     # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
     # rocprofv3 --pmc passes of THIS command (tools/pmc.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic, traffic_src = None, None
-    for tj_name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tj_name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tj = os.path.join(ROOT, "profiles", tj_name)
         if a.config == "nvila_8b" and not a.w4 and os.path.exists(tj):
             with open(tj) as f:

@@ -19,6 +19,7 @@ cpy val_bench_kernel_stats.csv bench_kernel_stats.csv
 cpy val_ttft_timeline.txt ttft_timeline.txt
 cpy val_sft_forcedist.json sft_forcedist_world1_nccl.json
 cpy val_bench_forcedist.json bench_forcedist_world1_nccl.json
+cpy val_persist_ab.log decode_persist_ab_final.log
 : > "$P/${R}_sft_step_final${SFX}.jsonl"
 for f in val_sft_1.json val_sft_2.json val_sft_c.json val_sft_s2.json; do [ -s "$O/$f" ] && tail -1 "$O/$f" >> "$P/${R}_sft_step_final${SFX}.jsonl"; done
 echo "  $P/${R}_sft_step_final${SFX}.jsonl"

@@ -31,6 +31,12 @@ except Exception as e:
     print("bench parse failed", e)
 P
 : > "$O/val_other_modes.jsonl"
+# the persistent decode layers kernel (opt-in) beside the default per-kernel step, same box
+for m in 0 1 0 1; do
+  VILA_DECODE_PERSIST=$m timeout 300 python bench.py --no-sft --no-sustain --no-cpu-baseline 2>>"$O/val_persist.err" | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('VILA_DECODE_PERSIST=$m: value', d['value'], 'tok/s, ms/step', d['ms_per_step'], '|', d.get('config', {}).get('decode'))" | tee -a "$O/val_persist_ab.log"
+done
 for args in "--w4" "--w8-vit" "--dynamic-s2" "--mode video" "--mode video --tsp" "--prompt-tokens 32"; do
   timeout 400 python bench.py $args --no-sft --no-sustain --no-cpu-baseline 2>>"$O/val_other_modes.err" | tail -1 >> "$O/val_other_modes.jsonl"
 done
@@ -67,7 +73,7 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemv_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
   [ -n "$DB" ] && python tools/pmc_summary.py "$DB" gemm256_kernel | head -8 >> "$O/val_pmc_hbm_counters.txt"
 done
-python tools/pmc_traffic_json.py "$O/val_pmc_hbm_counters.txt" "$O/val_pmc_traffic.json" r05 | cut -c1-200
+python tools/pmc_traffic_json.py "$O/val_pmc_hbm_counters.txt" "$O/val_pmc_traffic.json" r06 | cut -c1-200
 find "$O" -path "*pmc_val_*" -name "*.db" -delete
 # HBM traffic of the contraction-major (wgrad) GEMMs with THIS build's tile order (the round-3 json predated the 8 x 4 patches)
 timeout 900 bash tools/pmc_gemm_sft.sh 2>&1 | tail -6
