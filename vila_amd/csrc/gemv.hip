@@ -102,15 +102,22 @@ __device__ __forceinline__ void wave_rows_dot(const bf16_t* const (&wrow)[R], co
 // U = 16-B loads in flight per row and lane: 7 covers a whole K = 3584 row in ONE round trip (the short K=hidden GEMVs are
 // latency-bound), 4 is enough for the long rows (K = 18944) where many iterations pipeline anyway.
 template <int MODE, int U>   // MODE 0 plain, 1 gate/up, 2 plain with x = merged attention partials
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups, int ncu, int skew) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = p.K >> 3;
     constexpr int R = (MODE == 1) ? 4 : 2;
+    // ncu > 0: the CU-balanced map (gemv_common.h CuMap; the grid is ncu x blocks-per-CU); ncu == 0: small grids, the plain grid-stride walk
+    const CuMap cm(n_groups, ncu > 0 ? ncu : 8, ncu > 0 ? skew : 0);
+    const int cu = ncu > 0 ? (int)(blockIdx.x % ncu) : 0;
+    const int wpc = ncu > 0 ? (int)(gridDim.x / ncu) * 4 : 0;                 // waves dealing the CU's groups
+    const int cnt = ncu > 0 ? cm.count(cu) : 0;
+    int j = ncu > 0 ? (int)(blockIdx.x / ncu) * 4 + wave : 0;
     const int stride = gridDim.x * 4;
-    int g = blockIdx.x * 4 + wave;
+    int g = ncu > 0 ? (j < cnt ? cm.gid(cu, j) : n_groups) : blockIdx.x * 4 + wave;
+    auto next_group = [&]() { if (ncu > 0) { j += wpc; g = j < cnt ? cm.gid(cu, j) : n_groups; } else g += stride; };
 
     auto rows_of = [&](int gg, const bf16_t* (&rows)[R]) {
         const int n = gg * 2;
@@ -188,9 +195,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p, int n_groups) {
         fma_batch<R, U>(b0, sx, 0, lane, nch, acc);
         wave_rows_dot<R, U>(rows, sx, p.K, lane, acc, 64 * U);
         finish(g, acc);
-        g += stride;
+        next_group();
     }
-    for (; g < n_groups; g += stride) {
+    for (; g < n_groups; next_group()) {
         rows_of(g, rows);
         epi_fetch(g);
         float acc[R];
@@ -212,38 +219,71 @@ static int gemv_default_bpc() {           // VILA_GEMV_BPC (1..4): tuning / A-B 
     if (v < 0) { const char* e = getenv("VILA_GEMV_BPC"); v = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; }
     return v;
 }
-static inline int balanced_grid(int n_groups, int bpc = 0) {
+static int gemv_cu_count() {
+    static thread_local int per_dev[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n = per_dev[dev & 15];
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+// VILA_GEMV_CU_MAP=0: the grid-stride walk of rounds 1-5 (A/B switch); VILA_GEMV_SKEW=n: row groups per CU moved from odd to even XCDs (gate/up)
+static int gemv_cu_map_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_GEMV_CU_MAP"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+static int gemv_skew() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_GEMV_SKEW"); v = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 1; }
+    return v;
+}
+// grid of an HBM-bound GEMV: (CUs) x (blocks per CU, 1..4) so that blocks b, b + CUs, ... share a CU and deal that CU's row groups among their
+// waves (*ncu_out = CUs); small problems (fewer groups than one block per CU would hold) keep one block per 4 groups and the plain walk (*ncu_out = 0)
+static inline int balanced_grid(int n_groups, int bpc, int* ncu_out) {
+    const int ncu = gemv_cu_count();
     int want = cdiv(n_groups, 4);
-    const int cap = 256 * (bpc >= 1 && bpc <= 4 ? bpc : gemv_default_bpc());
-    if (want > cap) want = cap;
-    return want <= 256 ? want : cdiv(want, 256) * 256;
+    const int b = (bpc >= 1 && bpc <= 4) ? bpc : gemv_default_bpc();
+    if (want <= ncu || !gemv_cu_map_on()) {
+        if (ncu_out) *ncu_out = 0;
+        const int cap = ncu * b;
+        if (want > cap) want = cap;
+        return want <= ncu ? want : cdiv(want, ncu) * ncu;
+    }
+    int per = cdiv(want, ncu); if (per > b) per = b;
+    if (ncu_out) *ncu_out = ncu;
+    return ncu * per;
 }
 
 int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
     VILA_REQUIRE(a.K % 8 == 0 && a.K > 0 && a.N > 0, "gemv: K=%d must be a positive multiple of 8", a.K);
     VILA_REQUIRE((uintptr_t)a.W % 16 == 0, "gemv: weight pointer alignment");
     const int n_groups = cdiv(a.N, 2);
-    int grid = balanced_grid(n_groups, a.max_bpc);
+    int ncu = 0;
+    int grid = balanced_grid(n_groups, a.max_bpc, &ncu);
     size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
     const bool short_k = a.K <= 3584;
     GemvArgs b = a;                                              // (the chain link learns the grid it is launched with)
     if (a.mode == 1) {
         VILA_REQUIRE(a.W2 != nullptr && a.y != nullptr && (uintptr_t)a.x % 16 == 0, "gemv: gate/up mode needs W2, bf16 y, aligned x");
         b.chain.done_blocks = (uint32_t)grid;
-        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        hipLaunchKernelGGL((gemv_kernel<1, 4>), dim3(grid), dim3(256), lds, s, b, n_groups, ncu, gemv_skew());
     } else if (a.mode == 2) {
         VILA_REQUIRE(a.part_o != nullptr && a.part_ml != nullptr && a.pos_ptr != nullptr && a.K % 128 == 0, "gemv: attention-merge mode needs partials");
         lds += (size_t)a.n_splits * (a.K / 128) * 4;
         const int cap = a.grid_cap > 0 ? a.grid_cap : 256;           // the merge prologue is paid per block: default ~1 block per CU
-        if (grid > cap) grid = cap;
+        if (grid > cap) grid = ncu > 0 ? (cap / ncu >= 1 ? (cap / ncu) * ncu : ncu) : cap;
         b.chain.done_blocks = (uint32_t)grid;
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
-        else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<2, 7>), dim3(grid), dim3(256), lds, s, b, n_groups, ncu, 0);
+        else hipLaunchKernelGGL((gemv_kernel<2, 4>), dim3(grid), dim3(256), lds, s, b, n_groups, ncu, 0);
     } else {
         VILA_REQUIRE((uintptr_t)a.x % 16 == 0, "gemv: x alignment");
         b.chain.done_blocks = (uint32_t)grid;
-        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups);
-        else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups);
+        if (short_k) hipLaunchKernelGGL((gemv_kernel<0, 7>), dim3(grid), dim3(256), lds, s, b, n_groups, ncu, 0);
+        else hipLaunchKernelGGL((gemv_kernel<0, 4>), dim3(grid), dim3(256), lds, s, b, n_groups, ncu, 0);
     }
     VILA_LAUNCH_CHECK();
     if (grid_out != nullptr) *grid_out = grid;
@@ -256,7 +296,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s, int* grid_out) {
 // decode_prologue_kernel (already rounded to bf16 like HF's cast of cos/sin to the activation dtype).
 // ------------------------------------------------------------------------------------------------
 template <int U>
-__global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
+__global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p, int ncu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sx = (bf16_t*)smem;
     float* scratch = (float*)(smem + ((p.K * 2 + 15) & ~15));
@@ -265,8 +305,14 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
     const int gph = half;                                      // groups (row pairs) per head
     const int n_groups = (p.nq + 2 * p.nkv) * gph;
     const int nch = p.K >> 3;
+    const CuMap cm(n_groups, ncu > 0 ? ncu : 8, 0);
+    const int cu = ncu > 0 ? (int)(blockIdx.x % ncu) : 0;
+    const int wpc = ncu > 0 ? (int)(gridDim.x / ncu) * 4 : 0;
+    const int cnt = ncu > 0 ? cm.count(cu) : 0;
+    int j = ncu > 0 ? (int)(blockIdx.x / ncu) * 4 + wave : 0;
     const int stride = gridDim.x * 4;
-    int g = blockIdx.x * 4 + wave;
+    int g = ncu > 0 ? (j < cnt ? cm.gid(cu, j) : n_groups) : blockIdx.x * 4 + wave;
+    auto next_group = [&]() { if (ncu > 0) { j += wpc; g = j < cnt ? cm.gid(cu, j) : n_groups; } else g += stride; };
 
     int rows_i[2];
     const bf16_t* rows[2];
@@ -321,9 +367,9 @@ __global__ __launch_bounds__(256) void qkv_decode_kernel(QkvDecodeArgs p) {
         fma_batch<2, U>(b0, sx, 0, lane, nch, acc);
         wave_rows_dot<2, U>(rows, sx, p.K, lane, acc, 64 * U);
         finish(g, acc);
-        g += stride;
+        next_group();
     }
-    for (; g < n_groups; g += stride) {
+    for (; g < n_groups; next_group()) {
         rows_of(g);
         epi_fetch(g);
         float acc[2] = {0.f, 0.f};
@@ -338,11 +384,12 @@ int launch_qkv_decode(const QkvDecodeArgs& a, hipStream_t s, int* grid_out) {
     const int n_groups = (a.nq + 2 * a.nkv) * (a.hd / 2);
     const size_t lds = ((size_t)a.K * 2 + 15) / 16 * 16 + 16;
     // one rotate-half pair per wave; K <= 3584: the whole row pair (14 x 16 B per lane) is in flight in ONE round trip
-    const int grid = balanced_grid(n_groups, a.max_bpc);
+    int ncu = 0;
+    const int grid = balanced_grid(n_groups, a.max_bpc, &ncu);
     QkvDecodeArgs b = a;
     b.chain.done_blocks = (uint32_t)grid;
-    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b);
-    else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(grid), dim3(256), lds, s, b);
+    if (a.K <= 3584) hipLaunchKernelGGL(qkv_decode_kernel<7>, dim3(grid), dim3(256), lds, s, b, ncu);
+    else hipLaunchKernelGGL(qkv_decode_kernel<4>, dim3(grid), dim3(256), lds, s, b, ncu);
     VILA_LAUNCH_CHECK();
     if (grid_out != nullptr) *grid_out = grid;
     return 0;

@@ -79,6 +79,37 @@ __device__ __forceinline__ u32x4 ldx16(const bf16_t* x, __amdgpu_buffer_rsrc_t r
     else return *(const u32x4*)(x + c * 8);
 }
 
+// ---- CU-balanced row-group map (round 6) -------------------------------------------------------------------------------------------
+// The grid-stride walk of rounds 1-5 (group = block * 4 + wave, += grid * 4) balances WAVES, not CUs: blocks b and b + 256 share a CU under
+// round-robin dispatch, so with 448 working blocks of a 512-block grid 192 CUs streamed 8 row pairs of down_proj and 64 CUs 4, and 64 CUs took
+// 40 of gate/up's groups against 36 on the others — the kernel ends when the fullest CU does.  Here a CU owns groups {j * ncu + cu}: every
+// shape of NVILA-8B divides evenly (37 / 7 / 9 / 297 groups per CU), and the waves of the CU's blocks deal its groups among themselves.
+// On top, `skew` groups per CU move from the odd XCDs' CUs to the even ones' (the round-6 trace: blocks with an odd (block % 8) stream ~7 %
+// slower): every CU takes cf = n / ncu - skew groups by the interleaved map, the rest goes to the even CUs only.
+struct CuMap {
+    int ncu, cf, n_fast, rem;
+    __device__ __forceinline__ CuMap(int n_groups, int ncu_, int skew) {
+        ncu = ncu_; n_fast = ncu_ >> 1;
+        const bool can = (ncu_ & 7) == 0;
+        cf = n_groups / ncu_ - (can ? skew : 0); cf = cf < 0 ? 0 : cf;
+        rem = n_groups - cf * ncu_;
+        if (!can) { cf = 0x3fffffff; rem = 0; }          // odd grids: the plain interleaved map (count() below handles the bound)
+        n_total = n_groups;
+    }
+    int n_total;
+    __device__ __forceinline__ int rank(int cu) const { return (cu >> 3) * 4 + ((cu & 7) >> 1); }
+    __device__ __forceinline__ int count(int cu) const {
+        if (cf == 0x3fffffff) return n_total > cu ? (n_total - cu + ncu - 1) / ncu : 0;
+        const bool fast = (cu & 1) == 0;
+        const int r = rank(cu);
+        return cf + ((fast && rem > r) ? (rem - r + n_fast - 1) / n_fast : 0);
+    }
+    __device__ __forceinline__ int gid(int cu, int j) const {
+        if (cf == 0x3fffffff || j < cf) return j * ncu + cu;
+        return cf * ncu + (j - cf) * n_fast + rank(cu);
+    }
+};
+
 // ---- activation staging -------------------------------------------------------------------------
 // stage x (optionally RMS-normalised with gain, HF rounding order) as bf16 into LDS; all 256 threads participate.
 // Single pass for K <= 8192 (x kept in registers between the sum of squares and the scaling).
