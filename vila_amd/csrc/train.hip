@@ -757,9 +757,109 @@ __global__ __launch_bounds__(256) void adamw_lean_kernel(float* master, float* m
         __builtin_amdgcn_raw_buffer_store_b32(pack2bf(p0, p1), rq, i * 4u, 0, 2);
     }
 }
+// Round 6: the form that is meant to run BESIDE a resident 256x256 GEMM block instead of between two of them.  A GEMM block holds 2 x 224-232
+// VGPRs per SIMD lane and 128-132 KB of LDS, so exactly ONE block of this kernel fits next to it (<= 48 VGPRs, 28 KB of LDS requested and never
+// touched: the request is what keeps a CU that is momentarily free from filling up with optimizer blocks a GEMM block would then have to wait
+// out).  Blocks are SHORT (256 threads x U element pairs, all 7 U loads requested up front) — the persistent grid-stride kernel above keeps a CU's
+// slots for ~0.4 ms per block and streams 1.8 KB per wave; this one streams 7 KB per wave and leaves after a few microseconds.
+template <int U>
+__global__ __launch_bounds__(256) void adamw_stream_kernel(float* master, float* m, float* v, const uint32_t* grad, uint32_t* param, unsigned n2,
+                                                           float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float grad_scale) {
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(master, 0, n2 * 8u, 0x00020000);      // range-checked: loads beyond n2 read 0,
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(m, 0, n2 * 8u, 0x00020000);           // stores beyond n2 are dropped
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(v, 0, n2 * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)grad, 0, n2 * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(param, 0, n2 * 4u, 0x00020000);
+  for (unsigned base = blockIdx.x * (256u * U) + threadIdx.x; base - threadIdx.x < n2; base += gridDim.x * (256u * U)) {
+    u32x2 pw[U], mw[U], vw[U];
+    unsigned g2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = base + 256u * u;
+        pw[u] = __builtin_amdgcn_raw_buffer_load_b64(rp, i * 8u, 0, 2);
+        mw[u] = __builtin_amdgcn_raw_buffer_load_b64(rm, i * 8u, 0, 2);
+        vw[u] = __builtin_amdgcn_raw_buffer_load_b64(rv, i * 8u, 0, 2);
+        g2[u] = __builtin_amdgcn_raw_buffer_load_b32(rg, i * 4u, 0, 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = base + 256u * u;
+        float p0 = __uint_as_float(pw[u][0]), m0 = __uint_as_float(mw[u][0]), v0 = __uint_as_float(vw[u][0]);
+        adamw_one(p0, m0, v0, lo_bf(g2[u]) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        asm volatile("" : "+v"(p0), "+v"(m0), "+v"(v0));
+        float p1 = __uint_as_float(pw[u][1]), m1 = __uint_as_float(mw[u][1]), v1 = __uint_as_float(vw[u][1]);
+        adamw_one(p1, m1, v1, hi_bf(g2[u]) * grad_scale, lr, b1, b2, eps, wd, bc1, bc2);
+        const u32x2 po = {__float_as_uint(p0), __float_as_uint(p1)}, mo = {__float_as_uint(m0), __float_as_uint(m1)}, vo = {__float_as_uint(v0), __float_as_uint(v1)};
+        __builtin_amdgcn_raw_buffer_store_b64(mo, rm, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(vo, rv, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(po, rp, i * 8u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(pack2bf(p0, p1), rq, i * 4u, 0, 2);
+        asm volatile("" ::: "memory");
+    }
+  }
+}
+// VILA_SFT_ADAMW_STREAM = U (0 = the grid-stride lean kernel, 2 / 4 = element pairs per thread of the stream kernel); VILA_SFT_ADAMW_LDS = bytes of
+// LDS each stream block asks for (co-residency cap; default 28672)
+// Blocks of the grid-stride lean kernel: ONE PER CU by default (round 6).  The kernel exists to run beside the backward's 256x256 GEMM blocks; a
+// GEMM block leaves room for exactly one 4-wave block of it per CU (2 x 224-232 + 40 VGPRs per SIMD lane).  With 1024 blocks (rounds 2-5) the
+// surplus blocks took over every CU a GEMM block had just left and the next GEMM block waited for them — persistent blocks live ~1 ms — so the
+// "overlap" was time-slicing: wgrad 733 us against 498 with the optimizer deferred, and the step cost the same either way (CHANGELOG round 6).
+// One block per CU is always resident beside a GEMM block and never in its way: 2.2 TB/s spread over the whole backward, wgrad 615 us,
+// SFT step 191.6 -> 176-180 ms.  (More bytes in flight per block — the `adamw_stream_kernel` forms below — made the GEMMs slower again:
+// 203-218 ms; what the backward can spare is ~2 TB/s of the HBM pipe.)  VILA_SFT_ADAMW_GRID overrides (0 / unset = CU count).
+static int adamw_lean_grid() {
+    static thread_local int per_dev[16] = {0};
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("VILA_SFT_ADAMW_GRID"); env = (e && atoi(e) >= 1) ? atoi(e) : -1; }
+    if (env > 0) return env;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n = per_dev[dev & 15];
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+static int adamw_stream_u() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_SFT_ADAMW_STREAM"); v = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0; }
+    return v;
+}
+static int adamw_stream_lds() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_SFT_ADAMW_LDS"); v = (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 28672; }
+    return v;
+}
 int launch_adamw_lean(float* master, float* m, float* v, const bf16_t* grad, bf16_t* param, int64_t n, float lr, float b1, float b2, float eps,
                       float wd, int step, float grad_scale, hipStream_t s) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    const int su = adamw_stream_u();
+    if (su == 2 || su == 3 || su == 4) {
+        VILA_REQUIRE(((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) % 8 == 0 && ((uintptr_t)grad | (uintptr_t)param) % 4 == 0, "adamw_stream: buffer alignment");
+        const int64_t chunk = (int64_t)1 << 28, n2 = n >> 1;
+        int64_t done = 0;
+        while (done < n2) {
+            const int64_t c = (n2 - done) < chunk ? (n2 - done) : chunk;
+            const int64_t per = 256 * su;
+            unsigned grid = (unsigned)((c + per - 1) / per);
+            if (grid > (unsigned)adamw_lean_grid()) grid = (unsigned)adamw_lean_grid();
+            if (su == 3) hipLaunchKernelGGL(adamw_stream_kernel<3>, dim3(grid), dim3(256), adamw_stream_lds(), s, master + 2 * done, m + 2 * done, v + 2 * done,
+                                            (const uint32_t*)(grad + 2 * done), (uint32_t*)(param + 2 * done), (unsigned)c, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
+            else if (su == 2) hipLaunchKernelGGL(adamw_stream_kernel<2>, dim3(grid), dim3(256), adamw_stream_lds(), s, master + 2 * done, m + 2 * done, v + 2 * done,
+                                            (const uint32_t*)(grad + 2 * done), (uint32_t*)(param + 2 * done), (unsigned)c, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
+            else hipLaunchKernelGGL(adamw_stream_kernel<4>, dim3(grid), dim3(256), adamw_stream_lds(), s, master + 2 * done, m + 2 * done, v + 2 * done,
+                                    (const uint32_t*)(grad + 2 * done), (uint32_t*)(param + 2 * done), (unsigned)c, lr, b1, b2, eps, wd, bc1, bc2, grad_scale);
+            VILA_LAUNCH_CHECK();
+            done += c;
+        }
+        if (n & 1) {                                                  // odd tail element: the lean kernel's single-thread path on a zero-pair launch
+            hipLaunchKernelGGL(adamw_lean_kernel, dim3(1), dim3(256), 0, s, master + 2 * n2, m + 2 * n2, v + 2 * n2, (const uint32_t*)(grad + 2 * n2),
+                               (uint32_t*)(param + 2 * n2), 0u, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, 1);
+            VILA_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     VILA_REQUIRE(((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) % 8 == 0 && ((uintptr_t)grad | (uintptr_t)param) % 4 == 0, "adamw_lean: buffers must be 8-B (fp32) / 4-B (bf16) aligned");
     const int64_t chunk = (int64_t)1 << 28;                          // pairs per launch: 2 GiB of fp32 state per descriptor
     int64_t done = 0;
@@ -767,7 +867,8 @@ int launch_adamw_lean(float* master, float* m, float* v, const bf16_t* grad, bf1
     do {
         const int64_t c = (n2 - done) < chunk ? (n2 - done) : chunk;
         const int last = (done + c >= n2) ? 1 : 0;
-        int grid = (int)((c + 255) / 256 < 1024 ? (c + 255) / 256 : 1024);
+        const int gcap = adamw_lean_grid();
+        int grid = (int)((c + 255) / 256 < gcap ? (c + 255) / 256 : gcap);
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL(adamw_lean_kernel, dim3(grid), dim3(256), 0, s, master + 2 * done, m + 2 * done, v + 2 * done, (const uint32_t*)(grad + 2 * done),
                            (uint32_t*)(param + 2 * done), (unsigned)c, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, (last && (n & 1)) ? 1 : 0);
