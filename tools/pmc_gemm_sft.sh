@@ -5,6 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 O=$REPO/gpurun_out/pmc_gemm_sft; mkdir -p "$O"
+[ -x "$REPO/tools/gemm_bench" ] || (cd "$REPO" && python -c "from vila_amd import build as b; b.build(); b.build_tools()") || { echo "tools/gemm_bench missing and not buildable"; exit 2; }
 cd /tmp && export TMPDIR=/tmp
 for IDX in 5 6 7 8; do
   for CTR in FETCH_SIZE WRITE_SIZE; do

@@ -79,6 +79,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_tools(force: bool = False) -> str:
+    """tools/gemm_bench: the torch-free GEMM micro-benchmark the wgrad PMC passes (tools/pmc_gemm_sft.sh) run under rocprofv3.  Built next
+    to the library so that it travels to the GPU box with it (git-ignored, not gpurun-ignored)."""
+    root = os.path.dirname(HERE)
+    src, exe = os.path.join(root, "tools", "gemm_bench.cpp"), os.path.join(root, "tools", "gemm_bench")
+    if not os.path.exists(src):
+        return ""
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return exe
+    r = subprocess.run([hipcc(), "-O2", "-std=c++17", src, "-o", exe, "-L" + LIBDIR, "-lvila_hip", "-Wl,-rpath,$ORIGIN/../vila_amd/lib"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on tools/gemm_bench.cpp:\n{r.stderr[-4000:]}")
+    return exe
+
+
 if __name__ == "__main__":
     p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(p)
+    print(build_tools(force="--force" in sys.argv))
