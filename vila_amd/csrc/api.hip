@@ -278,6 +278,12 @@ extern "C" int vila_copy_rows(const void* src, void* dst, const int32_t* src_row
 // =================================================================================================
 // LLM prefill
 // =================================================================================================
+// VILA_PREFILL_OPROJ_SPLITK=0: o_proj never takes the K-sliced path for the sake of the fused post-attention norm (A/B switch)
+static bool prefill_oproj_norm() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_PREFILL_OPROJ_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T) {
     const size_t H = s->hidden, F = s->inter, QKV = (size_t)(s->q_heads + 2 * s->kv_heads) * s->head_dim;
     size_t b = 0;
@@ -378,8 +384,13 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
             }
             break;
         }
-        VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes));   // x += o_proj(attn)
-        VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
+        // x += o_proj(attn).  The post-attention RMSNorm is offered to the GEMM: where its grid is K-sliced (S = 769: 42 tiles x 6 slices) the
+        // reduce holds whole rows and writes h = norm(x) as well (h is free: the GEMM kernel that read it has finished when the reduce runs)
+        int ln2_done = 0;
+        NextNorm n2;
+        n2.w = L.ln2_w; n2.eps = sh.rms_eps; n2.rms = 1; n2.out = h; n2.done = &ln2_done;
+        VILA_TRY(gemm(h, QS, L.wo, QS, nullptr, x, H, x, H, T, H, QS, EPI_NONE, s, nullptr, 0, skws, skws_bytes, 0, prefill_oproj_norm() ? &n2 : nullptr));
+        if (!ln2_done) VILA_TRY(launch_rmsnorm(x, B(L.ln2_w), h, T, H, sh.rms_eps, s));
         // MLP.  A prompt of 3 x 256 + 1 tokens (the benchmark's 769) would spend a whole extra row-tile round on ONE row in the two
         // big GEMMs; those 1-4 leftover rows go through the decode GEMV kernels instead (the weights stream once more at HBM rate:
         // 44 + 25 us per row against 94 + 40 us for the extra tile round)

@@ -294,15 +294,24 @@ template <int N, int cnt> __device__ __forceinline__ void pv_retire(u32x2 (&v)[4
     else { lds_wait<N>(v[0][0], v[0][1], v[1][0], v[1][1]); lds_wait<N>(v[2][0], v[2][1]); }
 }
 
-template <int HD, int QF, bool CAUSAL>
+// KS (round 6): key split inside the block.  KS = 1: 8 waves x QF*16 query rows, every wave walks every K / V tile.  KS = 2: 4 query groups
+// x 2 key groups — waves 0-3 take the even tiles, waves 4-7 the odd ones, for the SAME 4 x QF*16 rows — and the two partial (m, l, O) of a
+// row meet through LDS at the end.  Why: at the path's sizes (S = 769 causal: 196 blocks; one 448^2 tile: 128 blocks) the kernel is ONE block per
+// CU walking <= 13 (16) dependent tiles, and with 16 rows per wave (QF = 1, taken to keep 196 blocks) each of the 8 waves reads the whole
+// 32-KB K / V stage per tile: 256 KB of LDS reads = 2048 cycles per tile for 512 cycles of MFMA.  32 rows per wave halve the LDS bytes per
+// row, the key split keeps the block at 128 rows: the same grid, half the dependent steps.
+template <int HD, int QF, bool CAUSAL, int KS = 1>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
     using C = AttnDma<HD>;
     constexpr int KK = C::KK, DN = C::DN, CH = C::CH, CHP = C::CHP, ROWB = C::ROWB, KT = C::KT, NST = C::NST, P = C::P, PW = C::PW;
-    constexpr int BQ = 8 * QF * 16;
+    static_assert(KS == 1 || KS == 2, "key split: 1 or 2");
+    constexpr int WQ = 8 / KS;                     // query groups (waves per key group)
+    constexpr int BQ = WQ * QF * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = KS == 1 ? wave : (wave & (WQ - 1)), ksp = KS == 1 ? 0 : wave / WQ;
     const int l15 = lane & 15, lg = lane >> 4;
     // ---- block -> (sequence, kv head, query head of the group, query block): consecutive ids share K / V and share an XCD ----
     const int G = p.n_q_heads / p.n_kv_heads;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
     };
 
     // ---- Q fragments (B operand of S^T): lane holds Q[q0 + f*16 + l15][kk*32 + lg*8 .. +8]; requested before the DMA burst ----
-    const int qw0 = qb0 + wave * QF * 16;
+    const int qw0 = qb0 + wq * QF * 16;
     bf16x8 qf_[QF][KK];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
         }
     }
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
+    for (int t = 0; t < NST - KS; ++t)
         if (t < ntiles) issue_tile(t);
     // pin the Q registers as "arrived" in front of the loop: left pending, the compiler's wait for them lands INSIDE the loop body as
     // a vmcnt(0) in front of the first MFMA of every tile, which would also drain the whole DMA ring
@@ -420,14 +429,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
     const int qw_last = qw0 + QF * 16 - 1;
     const bool wave_has_rows = qw0 < seqlen;
 
-    for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed once at most `ahead` younger tiles (P instructions each) are still in flight
-        wait_tiles_ahead<P, NST - 2>(ntiles - 1 - t);
-        __builtin_amdgcn_s_barrier();                       // everyone's pieces of tile t are in; everyone is done with tile t-1
+    // step s consumes tiles s*KS .. s*KS + KS-1 (key group ksp takes tile s*KS + ksp) and refills the stages of step s-1 with tiles
+    // s*KS + NST-KS .. s*KS + NST-1; at its top `issued` tiles have been requested and the first `need` of them must have landed
+    const int nsteps = (ntiles + KS - 1) / KS;
+    for (int st = 0; st < nsteps; ++st) {
+        {
+            const int issued = (st * KS + NST - KS) < ntiles ? (st * KS + NST - KS) : ntiles;
+            const int need = (st * KS + KS) < ntiles ? (st * KS + KS) : ntiles;
+            wait_tiles_ahead<P, (NST - 2 * KS > 0 ? NST - 2 * KS : 0)>(issued - need);
+        }
+        __builtin_amdgcn_s_barrier();                       // everyone's pieces of this step's tiles are in; everyone is done with step st-1
         asm volatile("" ::: "memory");
+        const int t = st * KS + ksp;
         const int key0 = t * KT;
-        const bool active = wave_has_rows && !(CAUSAL && key0 > qw_last);   // else nothing of this tile is visible to this wave's rows
-        const char* cK = smem + (t % NST) * C::STAGE;
+        const bool active = wave_has_rows && t < ntiles && !(CAUSAL && key0 > qw_last);   // else nothing of this tile is visible to this wave's rows
+        const char* cK = smem + ((t < ntiles ? t : 0) % NST) * C::STAGE;
         v_lds = lds_addr(cK + C::IMG);
 
         // ---- S^T = K Q^T ----
@@ -467,7 +483,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
         }
         // the refill of the stage tile t-1 was read from is issued BEHIND the MFMAs of this tile (the matrix pipe works through them
         // while the wave spends its 100-180 issue cycles per DMA instruction), not in front of them on the tile's critical path
-        if (t + NST - 1 < ntiles) issue_tile(t + NST - 1);
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            if (st * KS + NST - KS + j < ntiles) issue_tile(st * KS + NST - KS + j);
         if (!active) continue;
 
         // ---- mask (sequence end / causal diagonal) ----
@@ -566,7 +584,42 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
 
     // ---- normalise, stage O[q][d] through LDS (per-wave region), store whole 16-B row chunks ----
     __syncthreads();                                         // every wave is done with the K / V ring
-    bf16_t* so = (bf16_t*)smem + wave * (QF * 16) * C::OSTR;
+    constexpr int MRG_LANE = DN * QF * 16 + QF * 8;          // bytes per lane of a key group's partial result: O^T accumulators, m, l
+    if constexpr (KS == 2) {
+        // the odd-tile group hands (m, l, O^T) to its even-tile partner (same rows, same lanes) through LDS, lane-linear: f32x4 slot i of lane
+        // l at i * 1024 + l * 16; then  m = max(m0, m1), O = O0 * 2^((m0-m)c) + O1 * 2^((m1-m)c), l likewise (per lane: both partial sums are
+        // over the same lane's key slots).  An empty side (m = NEG_BIG, l = 0, O = 0) scales by 2^(-huge) = 0 or, both empty, by 1 on zeros.
+        char* mg = smem + (size_t)wq * 64 * MRG_LANE;
+        if (ksp == 1) {
+#pragma unroll
+            for (int dn = 0; dn < DN; ++dn)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) *(f32x4*)(mg + (dn * QF + f) * 1024 + lane * 16) = oacc[dn][f];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                *(float*)(mg + DN * QF * 1024 + (2 * f) * 256 + lane * 4) = m_run[f];
+                *(float*)(mg + DN * QF * 1024 + (2 * f + 1) * 256 + lane * 4) = l_run[f];
+            }
+        }
+        __syncthreads();
+        if (ksp == 1) return;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const float m1 = *(const float*)(mg + DN * QF * 1024 + (2 * f) * 256 + lane * 4);
+            const float l1 = *(const float*)(mg + DN * QF * 1024 + (2 * f + 1) * 256 + lane * 4);
+            const float m = fmaxf(m_run[f], m1);
+            const float a0 = __builtin_amdgcn_exp2f((m_run[f] - m) * c), a1 = __builtin_amdgcn_exp2f((m1 - m) * c);
+            m_run[f] = m;
+            l_run[f] = l_run[f] * a0 + l1 * a1;
+#pragma unroll
+            for (int dn = 0; dn < DN; ++dn) {
+                const f32x4 o1 = *(const f32x4*)(mg + (dn * QF + f) * 1024 + lane * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dn][f][r] = oacc[dn][f][r] * a0 + o1[r] * a1;
+            }
+        }
+    }
+    bf16_t* so = (bf16_t*)(smem + (KS == 2 ? (size_t)WQ * 64 * MRG_LANE : 0)) + wq * (QF * 16) * C::OSTR;
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         float l = l_run[f];
@@ -601,30 +654,38 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p, int nqb) {
     }
 }
 
-template <int HD, bool CAUSAL, int QF>
+template <int HD, bool CAUSAL, int QF, int KS = 1>
 static int launch_attn_q(const AttnArgs& a, hipStream_t s) {
     using C = AttnDma<HD>;
-    const size_t ring = (size_t)C::NST * C::STAGE, ost = (size_t)8 * QF * 16 * C::OSTR * 2;
+    constexpr int WQ = 8 / KS;
+    const size_t ring = (size_t)C::NST * C::STAGE;
+    const size_t ost = (size_t)WQ * QF * 16 * C::OSTR * 2 + (KS == 2 ? (size_t)WQ * 64 * (C::DN * QF * 16 + QF * 8) : 0);
     const size_t lds = ring > ost ? ring : ost;
     static bool attr_set = false;
     if (!attr_set) {
-        VILA_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, QF, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VILA_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, QF, CAUSAL, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int nqb = cdiv(a.max_seqlen, 8 * QF * 16);
+    const int nqb = cdiv(a.max_seqlen, WQ * QF * 16);
     const int64_t blocks = (int64_t)nqb * a.n_q_heads * a.n_seq;
     VILA_REQUIRE(blocks < (1ll << 31), "attn: grid too large");
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, QF, CAUSAL>), dim3((unsigned)blocks), dim3(512), lds, s, a, nqb);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, QF, CAUSAL, KS>), dim3((unsigned)blocks), dim3(512), lds, s, a, nqb);
     VILA_LAUNCH_CHECK();
     return 0;
 }
 
-// 32 query rows per wave (QF = 2) halve the LDS bytes per MFMA; 16 rows per wave (QF = 1) double the grid: taken while the 256-row
-// blocks would give the 256 CUs fewer than two rounds (one 448^2 tile, the S = 769 prefill, the 4 x 769 SFT batch)
+// 32 query rows per wave (QF = 2) halve the LDS bytes per MFMA.  While 256-row blocks would give the 256 CUs fewer than two rounds (one
+// 448^2 tile, the S = 769 prefill, the 4 x 769 SFT batch) the block stays at 128 rows and its waves split the KEYS two ways instead (KS = 2,
+// round 6).  VILA_ATTN_KS=0: rounds 3-5's choice for those grids, 16 rows per wave and every wave on every tile (A/B switch).
+static int attn_ks_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_ATTN_KS"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
 template <int HD, bool CAUSAL>
 static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
     const int64_t blocks2 = (int64_t)cdiv(a.max_seqlen, 256) * a.n_q_heads * a.n_seq;
-    if (blocks2 < 512) return launch_attn_q<HD, CAUSAL, 1>(a, s);
+    if (blocks2 < 512) return attn_ks_env() ? launch_attn_q<HD, CAUSAL, 2, 2>(a, s) : launch_attn_q<HD, CAUSAL, 1>(a, s);
     return launch_attn_q<HD, CAUSAL, 2>(a, s);
 }
 
