@@ -46,6 +46,10 @@ void vila_gemm_force_fuse_norm(int on);
 /* LayerNorm / RMSNorm over rows wider than 1536 columns: every load (x, w, b) requested up front instead of x -> reduce -> w (elementwise.hip
  * norm_block_lat_kernel; bit-identical outputs; on by default since round 5): -1 = VILA_NORM_LAT from the environment (default 1), 0 = off, 1 = on */
 void vila_norm_force_lat(int on);
+/* prefill (round 6): q/k/v projection K-sliced with bias + RoPE + KV-cache scatter in its reduce (instead of ring GEMM + rope_kv_kernel), and o_proj
+ * K-sliced with the post-attention RMSNorm in its reduce (instead of ring GEMM + norm launch); both only where the grid is K-sliced at all
+ * (>= 512 rows).  -1 = the environment's choice (VILA_PREFILL_QKV_SPLITK / VILA_PREFILL_OPROJ_SPLITK, default on), 0 = off, 1 = on */
+void vila_prefill_force_fusions(int qkv_rope, int oproj_norm);
 #ifdef __cplusplus
 }
 #endif

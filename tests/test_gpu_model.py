@@ -184,6 +184,48 @@ def test_norm_fused_into_the_splitk_reduce_equals_the_separate_launches():
     assert rel_l2(out[1][2], out[0][2]) < 2e-3, f"tower features fused vs separate LayerNorm rel={rel_l2(out[1][2], out[0][2]):.3e}"
 
 
+def test_rope_and_kv_scatter_fused_into_the_qkv_reduce_equal_the_separate_launches():
+    """Round 6: at >= 512 rows the prefill's q/k/v projection is K-sliced and its reduce adds the bias, rotates q and k (HF's roundings) and writes
+    K / V into the cache (gemm256.hip splitk_reduce_rope_kernel) — rope_kv_kernel's work; o_proj is K-sliced with the post-attention RMSNorm in its
+    reduce.  With every eligible GEMM pinned to the K-sliced kernel (force_tile 5) the fused and the separate forms run the SAME GEMM kernels, the
+    same slice order and the same per-element expressions -> hidden states, logits and the KV cache must be BIT-equal.  Against the ring-GEMM path of
+    rounds 1-5 (another fp32 summation order) the logits agree to bf16 rounding.  Packed: two sequences, so seq_of_tok / positions index the cache."""
+    from vila_amd import _lib
+    from vila_amd.vlm import build_model
+    lib = _lib.load()
+    cfg = configs.reduced_8b(layers_v=1, layers_l=3, vocab=32000)
+    cfg.image_token_id, cfg.llm.eos_token_id = 31999, 31998
+    model = build_model(cfg, seed=17)
+    g = torch.Generator().manual_seed(17)
+    lens = [400, 369]                                              # T = 769 = 3 x 256 + 1: the benchmark's row count (extra-row fragment path)
+    T = sum(lens)
+    e = (torch.randn(T, cfg.llm.hidden_size, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).cuda()
+    cu = torch.tensor([0, lens[0], T], dtype=torch.int32, device="cuda")
+    seq = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(lens)]).cuda()
+    out = {}
+    try:
+        for name, tile, fuse in (("ring", 0, 0), ("sliced", 5, 0), ("fused", 5, 1), ("default", 0, 1)):
+            lib.vila_gemm_force_tile(tile)
+            lib.vila_prefill_force_fusions(fuse, fuse)
+            cache = model.llm.new_cache(512, n_slots=2)
+            r = model.llm.prefill_packed(e, pos, cu, max(lens), cache=cache, seq_of_tok=seq, want_all_logits=True, want_layer_hidden=True)
+            out[name] = (r.all_logits.clone(), r.layer_hidden.clone(), cache.k.clone(), cache.v.clone())
+    finally:
+        lib.vila_gemm_force_tile(0)
+        lib.vila_prefill_force_fusions(-1, -1)
+    for i, what in enumerate(("logits", "hidden states", "K cache", "V cache")):
+        assert torch.equal(out["sliced"][i], out["fused"][i]), f"{what} differ between the fused reduce and reduce + rope_kv / norm launches"
+    assert rel_l2(out["default"][0], out["fused"][0]) < 2e-3          # (force_tile 5 also moves gate/up off the 256-wide kernel: not bit-comparable)
+    assert torch.equal(out["default"][2][0], out["fused"][2][0]), "layer 0's K cache: the default dispatch is not the fused K-sliced path at 769 rows"
+    assert float(out["fused"][2].float().abs().sum()) > 0 and float(out["fused"][3].float().abs().sum()) > 0
+    for s, n in enumerate(lens):                                   # rows beyond a sequence's length stay untouched
+        assert float(out["fused"][2][:, s, :, n:].float().abs().sum()) == 0
+    # three layers of bf16 activations with another fp32 summation order in two GEMMs per layer: measured 7.7e-3 (the path's stated logits tolerance is 3e-2)
+    assert rel_l2(out["fused"][0], out["ring"][0]) < 2e-2, f"K-sliced vs ring path logits rel={rel_l2(out['fused'][0], out['ring'][0]):.3e}"
+    assert rel_l2(out["fused"][2], out["ring"][2]) < 2e-2
+
+
 def test_chained_decode_step_equals_the_plain_step():
     """The opt-in chained decode step (vila_decode_force_chain(1): kernels alternate over two streams, stream their weights while the predecessor
     finishes and wait on device-side arrival counts; api.hip — measured slower than the plain step and OFF by default, profiles/

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "vila_gemm_force_ex": (None, [c_int]),
     "vila_gemm_force_group": (None, [c_int]),
     "vila_gemm_force_fuse_norm": (None, [c_int]),
+    "vila_prefill_force_fusions": (None, [c_int, c_int]),
     "vila_norm_force_lat": (None, [c_int]),
     "vila_decode_force_attn": (None, [c_int]),
     "vila_decode_force_chain": (None, [c_int]),

@@ -64,10 +64,15 @@ inline bf16_t* B(void* p) { return (bf16_t*)p; }
 
 // the NEXT block's normalisation, offered to a GEMM whose split-K reduce can take it along (kernels.h GemmArgs::norm_*)
 struct NextNorm { const void* w = nullptr; const void* b = nullptr; float eps = 0.f; int rms = 0; bf16_t* out = nullptr; int* done = nullptr; };
+// the q/k/v projection's follow-up (bias -> RoPE -> K / V into the cache), offered to its GEMM in the same way (kernels.h GemmArgs::rope_*)
+struct NextRope { const float* cs = nullptr; const float* sn = nullptr; const int32_t* pos = nullptr; const int32_t* seq = nullptr; bf16_t* kc = nullptr; bf16_t* vc = nullptr;
+                  int nq = 0, nkv = 0, hd = 0, max_ctx = 0; int* done = nullptr; };
 int gemm(const bf16_t* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const bf16_t* res, int64_t ldr,
          void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s, const void* W2 = nullptr, int out_f32 = 0,
-         float* ws = nullptr, size_t ws_bytes = 0, int res_mod = 0, const NextNorm* nn = nullptr) {
+         float* ws = nullptr, size_t ws_bytes = 0, int res_mod = 0, const NextNorm* nn = nullptr, const NextRope* nr = nullptr) {
     GemmArgs g;
+    if (nr != nullptr) { g.rope_cs = nr->cs; g.rope_sn = nr->sn; g.rope_pos = nr->pos; g.rope_seq = nr->seq; g.rope_kc = nr->kc; g.rope_vc = nr->vc;
+                         g.rope_nq = nr->nq; g.rope_nkv = nr->nkv; g.rope_hd = nr->hd; g.rope_max_ctx = nr->max_ctx; g.rope_done = nr->done; }
     if (nn != nullptr) { g.norm_w = B(nn->w); g.norm_b = B(nn->b); g.norm_eps = nn->eps; g.norm_rms = nn->rms; g.norm_out = nn->out; g.norm_done = nn->done; }
     g.ws = ws; g.ws_bytes = ws_bytes; g.res_mod = res_mod;
     g.A = A; g.lda = lda; g.W = B(W); g.ldw = ldw; g.W2 = B(W2); g.bias = B(bias); g.residual = res; g.ldr = ldr;
@@ -279,9 +284,20 @@ extern "C" int vila_copy_rows(const void* src, void* dst, const int32_t* src_row
 // LLM prefill
 // =================================================================================================
 // VILA_PREFILL_OPROJ_SPLITK=0: o_proj never takes the K-sliced path for the sake of the fused post-attention norm (A/B switch)
-static bool prefill_oproj_norm() {
+static bool prefill_oproj_norm();
+static bool prefill_oproj_norm_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VILA_PREFILL_OPROJ_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+// tuning / test hook (vila_hip_tuning.h): -1 = the environment's choice (default on), 0 / 1 = off / on
+static int g_prefill_qkv_rope = -1, g_prefill_oproj_norm = -1;
+extern "C" void vila_prefill_force_fusions(int qkv_rope, int oproj_norm) { g_prefill_qkv_rope = qkv_rope; g_prefill_oproj_norm = oproj_norm; }
+static bool prefill_oproj_norm() { return g_prefill_oproj_norm >= 0 ? g_prefill_oproj_norm != 0 : prefill_oproj_norm_env(); }
+static bool prefill_qkv_rope() {
+    if (g_prefill_qkv_rope >= 0) return g_prefill_qkv_rope != 0;
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VILA_PREFILL_QKV_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
 extern "C" size_t vila_llm_prefill_workspace_bytes(const VilaLlmShape* s, int T) {
@@ -340,19 +356,25 @@ extern "C" int vila_llm_prefill(const VilaLlmWeights* w, const void* embeds, con
         ln1_done = 0;
         const bool fused = (B(L.wk) == B(L.wq) + (size_t)QS * H) && (B(L.wv) == B(L.wk) + (size_t)KS * H) &&
                            (B(L.bk) == B(L.bq) + QS) && (B(L.bv) == B(L.bk) + KS);
-        if (fused) {
-            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QKV, H, EPI_NONE, s));
-        } else {
-            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QS, H, EPI_NONE, s));
-            VILA_TRY(gemm(h, H, L.wk, H, L.bk, nullptr, 0, qkv + QS, QKV, T, KS, H, EPI_NONE, s));
-            VILA_TRY(gemm(h, H, L.wv, H, L.bv, nullptr, 0, qkv + QS + KS, QKV, T, KS, H, EPI_NONE, s));
-        }
         bf16_t* kc = nullptr; bf16_t* vc = nullptr; int max_ctx = 0;
         if (cache != nullptr) {
             const size_t per_layer = (size_t)cache->n_slots * sh.kv_heads * cache->max_ctx * hd;
             kc = B(cache->k) + l * per_layer; vc = B(cache->v) + l * per_layer; max_ctx = cache->max_ctx;
         }
-        VILA_TRY(launch_rope_kv(qkv, cs, sn, positions, seq_of_tok, kc, vc, T, sh.q_heads, sh.kv_heads, hd, max_ctx, s));
+        int rope_done = 0;
+        if (fused) {
+            // one GEMM for q | k | v; where its grid is K-sliced (S = 769: 54 tiles x 4 slices) the reduce adds the bias, rotates q and k and
+            // writes K / V into the cache (VILA_PREFILL_QKV_SPLITK=0: ring GEMM + rope_kv_kernel as in rounds 1-5)
+            NextRope nr;
+            nr.cs = cs; nr.sn = sn; nr.pos = positions; nr.seq = seq_of_tok; nr.kc = kc; nr.vc = vc; nr.nq = sh.q_heads; nr.nkv = sh.kv_heads; nr.hd = hd;
+            nr.max_ctx = max_ctx; nr.done = &rope_done;
+            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QKV, H, EPI_NONE, s, nullptr, 0, skws, skws_bytes, 0, nullptr, prefill_qkv_rope() ? &nr : nullptr));
+        } else {
+            VILA_TRY(gemm(h, H, L.wq, H, L.bq, nullptr, 0, qkv, QKV, T, QS, H, EPI_NONE, s));
+            VILA_TRY(gemm(h, H, L.wk, H, L.bk, nullptr, 0, qkv + QS, QKV, T, KS, H, EPI_NONE, s));
+            VILA_TRY(gemm(h, H, L.wv, H, L.bv, nullptr, 0, qkv + QS + KS, QKV, T, KS, H, EPI_NONE, s));
+        }
+        if (!rope_done) VILA_TRY(launch_rope_kv(qkv, cs, sn, positions, seq_of_tok, kc, vc, T, sh.q_heads, sh.kv_heads, hd, max_ctx, s));
         AttnArgs at{};
         at.q = qkv; at.k = qkv + QS; at.v = qkv + QS + KS; at.o = h;
         at.q_tok_stride = at.k_tok_stride = at.v_tok_stride = QKV; at.o_tok_stride = QS;

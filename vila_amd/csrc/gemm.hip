@@ -253,7 +253,9 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         // ... or the caller offers the next block's normalisation (o_proj of the prefill -> post-attention RMSNorm): the reduce then replaces
         // the norm launch as well (ring 44.4 + norm 7.7 us against slices + fused reduce, round 6)
         const bool norm_offer = a.norm_out != nullptr && a.norm_w != nullptr && a.N % 8 == 0 && a.N <= 16384 && splits >= 4;
-        if (kt < 128 && sel == 0 && !(kt >= 64 && splits >= 6) && !norm_offer) splits = 0;
+        // ... or the q/k/v projection's RoPE + KV scatter (72 tiles -> 54 with the extra row fragment, 4 slices: the reduce replaces rope_kv_kernel)
+        const bool rope_offer = gemm_rope_offer(a) && splits >= 4;
+        if (kt < 128 && sel == 0 && !(kt >= 64 && splits >= 6) && !norm_offer && !rope_offer) splits = 0;
         // measured at M = 769 (tools/microbench.py prefill): N=3584,K=18944 233 -> 122 us; N=3584,K=3584 51 -> 41 us;
         // N=4608 (72 tiles) only breaks even, so require at least 4 slices
         if (splits >= 4 || (splits && sel == 5)) return launch_gemm256_splitk(a, splits, a.ws, s);

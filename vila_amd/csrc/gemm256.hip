@@ -22,6 +22,17 @@
 // round trip of a K-tile costs as much as its 64 MFMAs, so an "empty" tile is not cheaper than a full one.)
 #include "gemm256_kernel.h"
 
+// Sum of `splits` fp32 slices of 4 consecutive columns, slice 0 first: the order every reduce of this file keeps.
+// (Round 6 measured a variant with the slice count as a template parameter and every slice's load requested before the first add: the reduce
+// launches of the prefill stayed at 15.4-16.0 us — they move 57-66 MB of slabs at ~4.3 TB/s, memory-bound, not latency-chained — removed.)
+__device__ __forceinline__ f32x4 sum_slices4(const float* __restrict__ p, int64_t stride, int splits) {
+    f32x4 v = *(const f32x4*)p;
+    for (int s = 1; s < splits; ++s) {
+        const f32x4 w = *(const f32x4*)(p + s * stride);
+        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    return v;
+}
 
 // tail round of a gate/up GEMM: out[m][col0 + c] = bf16(silu(sum_s gate_s[m][c]) * sum_s up_s[m][c]); slab = [splits][2][M][tc] fp32
 __global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int splits, bf16_t* __restrict__ out, int64_t ldc, int M, int tc, int col0) {
@@ -29,13 +40,8 @@ __global__ void splitk_gu_reduce_kernel(const float* __restrict__ slab, int spli
     const int64_t total = (int64_t)M * n4, plane = (int64_t)M * tc;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), c = (int)(i % n4) * 4;
-        f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < splits; ++sidx) {
-            const float* b = slab + (int64_t)sidx * 2 * plane + (int64_t)m * tc + c;
-            const f32x4 a = *(const f32x4*)b, w = *(const f32x4*)(b + plane);
-            g[0] += a[0]; g[1] += a[1]; g[2] += a[2]; g[3] += a[3];
-            u[0] += w[0]; u[1] += w[1]; u[2] += w[2]; u[3] += w[3];
-        }
+        const float* b = slab + (int64_t)m * tc + c;
+        const f32x4 g = sum_slices4(b, 2 * plane, splits), u = sum_slices4(b + plane, 2 * plane, splits);
         u32x2 o;
         o[0] = pack2bf(silu_f(g[0]) * u[0], silu_f(g[1]) * u[1]);
         o[1] = pack2bf(silu_f(g[2]) * u[2], silu_f(g[3]) * u[3]);
@@ -50,11 +56,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     const int64_t total = (int64_t)M * n4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), c = (int)(i % n4) * 4;
-        f32x4 v = *(const f32x4*)(slab + (int64_t)m * N + c);
-        for (int s = 1; s < splits; ++s) {
-            const f32x4 w = *(const f32x4*)(slab + s * slab_stride + (int64_t)m * N + c);
-            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
-        }
+        f32x4 v = sum_slices4(slab + (int64_t)m * N + c, slab_stride, splits);
         if (bias != nullptr) {
             const u32x2 b = *(const u32x2*)(bias + c);
             v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
@@ -68,14 +70,72 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
     }
 }
 
+// The reduce of a K-sliced q/k/v projection with rope_kv_kernel's work fused in (round 6): one thread per (token, head, 8-wide chunk of the low half
+// of the head) sums the slices of its 8 + 8 columns in slice order, adds the bias and rounds to bf16 exactly as splitk_reduce_kernel does, then
+// applies HF's rotation with HF's roundings (bf16(x * cos) + bf16(rot * sin), elementwise.hip rope_kv_kernel: same expressions) to the q and k
+// heads, stores the row into the fused qkv buffer and the k / v heads into the cache.  One launch and one round trip of the qkv buffer less.
+__global__ void splitk_reduce_rope_kernel(const float* __restrict__ slab, int splits, int64_t slab_stride, const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                          int64_t ldc, int S, int N, const float* __restrict__ cs, const float* __restrict__ sn, const int32_t* __restrict__ pos,
+                                          const int32_t* __restrict__ seq_of_tok, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int nq, int nkv, int hd,
+                                          int max_ctx) {
+    const int half = hd >> 1, cpr = half >> 3, heads = nq + 2 * nkv;
+    const int64_t total = (int64_t)S * heads * cpr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int ch = (int)(r % cpr); r /= cpr;
+        const int hh = (int)(r % heads); r /= heads;
+        const int s = (int)r;
+        const int col = hh * hd + ch * 8;
+        u32x4 x1, x2;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c0 = col + hf * half;
+            const float* p0 = slab + (int64_t)s * N + c0;
+            f32x4 a = sum_slices4(p0, slab_stride, splits), b = sum_slices4(p0 + 4, slab_stride, splits);
+            if (bias != nullptr) {
+                const u32x4 bv = *(const u32x4*)(bias + c0);
+                a[0] += lo_bf(bv[0]); a[1] += hi_bf(bv[0]); a[2] += lo_bf(bv[1]); a[3] += hi_bf(bv[1]);
+                b[0] += lo_bf(bv[2]); b[1] += hi_bf(bv[2]); b[2] += lo_bf(bv[3]); b[3] += hi_bf(bv[3]);
+            }
+            u32x4 o; o[0] = pack2bf(a[0], a[1]); o[1] = pack2bf(a[2], a[3]); o[2] = pack2bf(b[0], b[1]); o[3] = pack2bf(b[2], b[3]);
+            if (hf == 0) x1 = o; else x2 = o;
+        }
+        if (hh < nq + nkv) {
+            const float* c = cs + (int64_t)s * half + ch * 8;
+            const float* sv = sn + (int64_t)s * half + ch * 8;
+            u32x4 o1, o2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a0 = lo_bf(x1[k]), a1 = hi_bf(x1[k]), b0 = lo_bf(x2[k]), b1 = hi_bf(x2[k]);
+                const float c0 = c[2 * k], c1 = c[2 * k + 1], s0 = sv[2 * k], s1 = sv[2 * k + 1];
+                o1[k] = pack2bf(bfround(a0 * c0) + bfround(-b0 * s0), bfround(a1 * c1) + bfround(-b1 * s1));
+                o2[k] = pack2bf(bfround(b0 * c0) + bfround(a0 * s0), bfround(b1 * c1) + bfround(a1 * s1));
+            }
+            x1 = o1; x2 = o2;
+        }
+        bf16_t* base = out + (int64_t)s * ldc + col;
+        *(u32x4*)base = x1;
+        *(u32x4*)(base + half) = x2;
+        const int p = pos[s];
+        if (hh >= nq && kcache != nullptr && p >= 0 && p < max_ctx) {
+            const int sq = seq_of_tok != nullptr ? seq_of_tok[s] : 0;
+            const bool isv = hh >= nq + nkv;
+            const int kvh = isv ? hh - nq - nkv : hh - nq;
+            bf16_t* dst = (isv ? vcache : kcache) + (((int64_t)sq * nkv + kvh) * max_ctx + p) * hd + ch * 8;
+            *(u32x4*)dst = x1;
+            *(u32x4*)(dst + half) = x2;
+        }
+    }
+}
+
 // The same reduce with the NEXT block's normalisation fused in (round 4): one block per output row — sum the slices (+ bias + residual), store
 // the row (the residual stream, rounded to bf16 as the separate kernel does), then normalise those ROUNDED values (what a separate norm launch would
 // read back) and store norm_out.  Saves the norm launch and its read of the row: LayerNorm (RMS = false: (x - mean) * rstd * w + b, two-pass
 // variance) or Qwen2RMSNorm (w * bf16(x * rstd)); same per-element arithmetic as elementwise.hip norm_kernel, N % 8 == 0, N <= 16384.
 template <bool RMS>
 __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ slab, int splits, int64_t slab_stride, const bf16_t* __restrict__ bias,
-                                                                 const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int N, int res_mod,
-                                                                 const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps, bf16_t* __restrict__ nout) {
+                                                        const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc, int N, int res_mod,
+                                                        const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps, bf16_t* __restrict__ nout) {
     __shared__ float scratch[4];
     const int m = blockIdx.x, tid = threadIdx.x, nch = N >> 3;
     constexpr int MAXC = 8;
@@ -86,11 +146,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
         const int c = tid + 256 * i;
         if (c < nch) {
             const float* p = slab + (int64_t)m * N + c * 8;
-            f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-            for (int sl = 1; sl < splits; ++sl) {
-                const f32x4 a2 = *(const f32x4*)(p + sl * slab_stride), b2 = *(const f32x4*)(p + sl * slab_stride + 4);
-                a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3]; b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
-            }
+            const f32x4 a = sum_slices4(p, slab_stride, splits), b = sum_slices4(p + 4, slab_stride, splits);
             float e[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             if (bias != nullptr) {
                 const u32x4 bv = *(const u32x4*)(bias + c * 8);
@@ -162,11 +218,7 @@ __global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(const float* __
     for (int r = part * 16 + (threadIdx.x >> 6); r < part * 16 + 16; r += 4) {
         const int gm = m0 + r, gc = n0 + c;
         if (gm >= M || gc >= N) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int sl = 0; sl < splits; ++sl) {
-            const f32x4 w = *(const f32x4*)(slab + ((int64_t)sl * n_tail + t) * 65536 + r * 256 + c);
-            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
-        }
+        f32x4 v = sum_slices4(slab + (int64_t)t * 65536 + r * 256 + c, (int64_t)n_tail * 65536, splits);
         if (bias != nullptr) {
             const u32x2 b = *(const u32x2*)(bias + gc);
             v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
@@ -305,12 +357,21 @@ int launch_gemm256_splitk(const GemmArgs& a, int splits, float* slab, hipStream_
     b.C = slab; b.ldc = a.N; b.bias = nullptr; b.residual = nullptr;
     if (a.a_cm || a.b_cm) VILA_TRY(launch_gemm256_cm_splitk(b, splits, slab, per, s));
     else VILA_TRY((launch256_fwd<3, EPI_NONE>(b, s, gemm256_ex_rows(a.M) != 0, splits, 0, -1, 0, per)));      // the last slice takes the remainder
+    if (gemm_rope_offer(a)) {
+        const int64_t total = (int64_t)a.M * (a.rope_nq + 2 * a.rope_nkv) * (a.rope_hd / 16);
+        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(splitk_reduce_rope_kernel, dim3(grid), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, (bf16_t*)a.C, a.ldc, a.M, a.N,
+                           a.rope_cs, a.rope_sn, a.rope_pos, a.rope_seq, a.rope_kc, a.rope_vc, a.rope_nq, a.rope_nkv, a.rope_hd, a.rope_max_ctx);
+        VILA_LAUNCH_CHECK();
+        *a.rope_done = 1;
+        return 0;
+    }
     if (a.norm_out != nullptr && a.norm_w != nullptr && a.N % 8 == 0 && a.N <= 16384 && fused_norm_enabled()) {
         // the reduce holds whole rows: the next block's LayerNorm / RMSNorm rides along (one launch and one read of the row less)
         if (a.norm_rms) hipLaunchKernelGGL(splitk_reduce_norm_kernel<true>, dim3(a.M), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
-                                           (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
+                                      (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
         else hipLaunchKernelGGL(splitk_reduce_norm_kernel<false>, dim3(a.M), dim3(256), 0, s, slab, splits, (int64_t)a.M * a.N, a.bias, a.residual, a.ldr,
-                                (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
+                           (bf16_t*)a.C, a.ldc, a.N, a.res_mod, a.norm_w, a.norm_b, a.norm_eps, a.norm_out);
         VILA_LAUNCH_CHECK();
         if (a.norm_done != nullptr) *a.norm_done = 1;
         return 0;

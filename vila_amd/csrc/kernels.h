@@ -26,8 +26,17 @@ struct GemmArgs {
     // the split-K path (its reduce kernel holds whole rows) — then *norm_done = 1 and norm_out[M][N] = norm(C) with C as it was just stored
     const bf16_t* norm_w = nullptr; const bf16_t* norm_b = nullptr; float norm_eps = 0.f; int norm_rms = 0;
     bf16_t* norm_out = nullptr; int* norm_done = nullptr;
+    // optional fused follow-up of a q/k/v projection (prefill): bias -> bf16 -> RoPE on the q and k heads -> K / V rows into the cache, i.e. what
+    // rope_kv_kernel (elementwise.hip) does to C afterwards.  Honoured only on the split-K path (its reduce then does both) — *rope_done = 1
+    const float* rope_cs = nullptr; const float* rope_sn = nullptr; const int32_t* rope_pos = nullptr; const int32_t* rope_seq = nullptr;
+    bf16_t* rope_kc = nullptr; bf16_t* rope_vc = nullptr; int rope_nq = 0, rope_nkv = 0, rope_hd = 0, rope_max_ctx = 0; int* rope_done = nullptr;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// a complete, applicable RoPE + KV follow-up request (the output row IS the fused q|k|v row, no residual, heads of a multiple of 16)
+static inline bool gemm_rope_offer(const GemmArgs& a) {
+    return a.rope_done != nullptr && a.rope_cs != nullptr && a.rope_sn != nullptr && a.rope_pos != nullptr && a.rope_hd > 0 && a.rope_hd % 16 == 0 &&
+           a.N == (a.rope_nq + 2 * a.rope_nkv) * a.rope_hd && a.residual == nullptr && a.epi == EPI_NONE && !a.out_f32 && a.ldc % 8 == 0;
+}
 
 // ---- normalisation / elementwise (elementwise.hip) ----
 int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int cols, float eps, hipStream_t s);
