@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/r06_attn_scan.sh  -> gpurun_out/r06_attn_scan_ks{0,1}.txt : the attention forward launches of tools/r06_attn_scan.py in order
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; O=$REPO/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for KS in 0 1; do
+for KS in ${KS_LIST:-0 1}; do
   rm -rf $O/prof_attn_scan
   VILA_ATTN_KS=$KS timeout 300 rocprofv3 --kernel-trace -d $O/prof_attn_scan -o trace -- python $REPO/tools/r06_attn_scan.py > $O/prof_attn_scan.log 2>&1
   DB=$(find $O/prof_attn_scan -name "*.db" | head -1)
@@ -19,4 +19,4 @@ for i in range(0, len(rows), 6):
 PY
   find $O/prof_attn_scan -name "*.db" -delete
 done
-paste -d'\n' $O/r06_attn_scan_ks0.txt $O/r06_attn_scan_ks1.txt
+for KS in ${KS_LIST:-0 1}; do echo "== VILA_ATTN_KS=$KS"; cat $O/r06_attn_scan_ks$KS.txt; done

@@ -676,16 +676,33 @@ static int launch_attn_q(const AttnArgs& a, hipStream_t s) {
 
 // 32 query rows per wave (QF = 2) halve the LDS bytes per MFMA.  While 256-row blocks would give the 256 CUs fewer than two rounds (one
 // 448^2 tile, the S = 769 prefill, the 4 x 769 SFT batch) the block stays at 128 rows and its waves split the KEYS two ways instead (KS = 2,
-// round 6).  VILA_ATTN_KS=0: rounds 3-5's choice for those grids, 16 rows per wave and every wave on every tile (A/B switch).
+// round 6).  VILA_ATTN_KS=0: rounds 3-5's choice for those grids, 16 rows per wave and every wave on every tile (A/B switch); 1 = automatic.
+static int attn_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
 static int attn_ks_env() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VILA_ATTN_KS"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) { const char* e = getenv("VILA_ATTN_KS"); v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1; }
     return v;
 }
 template <int HD, bool CAUSAL>
 static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
     const int64_t blocks2 = (int64_t)cdiv(a.max_seqlen, 256) * a.n_q_heads * a.n_seq;
-    if (blocks2 < 512) return attn_ks_env() ? launch_attn_q<HD, CAUSAL, 2, 2>(a, s) : launch_attn_q<HD, CAUSAL, 1>(a, s);
+    if (blocks2 < 512) {
+        const int ks = attn_ks_env();
+        if (ks == 0) return launch_attn_q<HD, CAUSAL, 1>(a, s);
+        // 64-row blocks (16 rows per wave, 4 query groups x 2 key groups: half the dependent steps at the old per-step cost) while they all fit the
+        // chip at once — one 448^2 tile: 256 blocks, 20.7 -> 16.3 us; S = 769 would be 364 blocks = two rounds, 21.1 -> 22.0 us, and keeps 128 rows
+        // (profiles/r06_attn_keysplit_scan.txt).  VILA_ATTN_KS=2 / 3 force the 64- / 128-row form
+        const int64_t blocks64 = (int64_t)cdiv(a.max_seqlen, 64) * a.n_q_heads * a.n_seq;
+        if (ks == 2 || (ks == 1 && blocks64 <= attn_cu_count())) return launch_attn_q<HD, CAUSAL, 1, 2>(a, s);
+        return launch_attn_q<HD, CAUSAL, 2, 2>(a, s);
+    }
     return launch_attn_q<HD, CAUSAL, 2>(a, s);
 }
 
